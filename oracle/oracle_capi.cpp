@@ -1,0 +1,134 @@
+// oracle/oracle_capi.cpp -- TEST INFRASTRUCTURE ONLY.
+// extern "C" surface of the CPU oracle for ctypes (tests/, smoke(), bench.py cpu_baseline leg).
+// Results are returned as one JSON document so the Python side needs no struct mirroring.
+#include <chrono>
+#include <cstring>
+#include <sstream>
+#include <string>
+
+#include "bfb_oracle.hpp"
+
+using namespace oracle;
+
+namespace {
+void jstr(std::ostringstream& o, const std::string& s) {
+    o << '"';
+    for (char c : s) {
+        if (c == '"' || c == '\\') o << '\\' << c;
+        else if (c == '\n') o << "\\n";
+        else o << c;
+    }
+    o << '"';
+}
+template <class T> void jarr(std::ostringstream& o, const std::vector<T>& v) {
+    o << '[';
+    for (size_t i = 0; i < v.size(); i++) { if (i) o << ','; o << v[i]; }
+    o << ']';
+}
+void jarr2(std::ostringstream& o, const std::vector<std::vector<int>>& v) {
+    o << '[';
+    for (size_t i = 0; i < v.size(); i++) { if (i) o << ','; jarr(o, v[i]); }
+    o << ']';
+}
+void jdarr(std::ostringstream& o, const std::vector<double>& v) {
+    o << '[';
+    o.precision(17);
+    for (size_t i = 0; i < v.size(); i++) { if (i) o << ','; o << v[i]; }
+    o << ']';
+}
+char* dup(const std::string& s) { char* p = (char*)malloc(s.size() + 1); memcpy(p, s.c_str(), s.size() + 1); return p; }
+
+std::vector<std::string> split(const char* s, char d) {
+    std::vector<std::string> out; if (!s || !*s) return out;
+    std::string cur;
+    for (const char* p = s; *p; p++) { if (*p == d) { out.push_back(cur); cur.clear(); } else cur += *p; }
+    out.push_back(cur);
+    return out;
+}
+}  // namespace
+
+extern "C" {
+
+void oracle_free(char* p) { free(p); }
+
+// Runs the whole `--op bfb` flow (localhap.cpp:49-388) with the cbc step replaced by the given .sol files
+// (comma separated, one per chromosome that reaches the ILP).  flags: bit0 reversed, bit1 all, bit2 junc_info,
+// bit3 keep orders in the dump.  Returns a malloc'ed JSON string (free with oracle_free).
+char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int flags, long long maxOrders, double* seconds) {
+    RunOptions opt;
+    opt.lh = lh; opt.juncs = juncs ? juncs : "";
+    opt.solPerChr = split(sols, ',');
+    opt.reversed = flags & 1; opt.all = flags & 2; opt.juncInfo = flags & 4; opt.keepOrders = flags & 8;
+    if (maxOrders > 0) opt.maxOrders = (size_t)maxOrders;
+    auto t0 = std::chrono::steady_clock::now();
+    RunResult R = runBfb(opt);
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    std::ostringstream o;
+    o << "{\"ok\":" << (R.ok ? "true" : "false") << ",\"err\":"; jstr(o, R.err);
+    o << ",\"log\":[";
+    for (size_t i = 0; i < R.log.size(); i++) { if (i) o << ','; jstr(o, R.log[i]); }
+    o << "],\"paths\":"; jarr2(o, R.paths);
+    o << ",\"trx_run\":" << (R.trxRun ? "true" : "false") << ",\"trx_path\":"; jarr(o, R.trxPath);
+    o << ",\"target_cn\":"; jarr(o, R.targetCN);
+    o << ",\"path_len\":" << R.pathLen << ",\"cn_sum\":" << R.cnSum << ",\"max_cn\":" << R.maxCN << ",\"num_inv\":" << R.numInv;
+    o << ",\"out_juncs\":[";
+    for (size_t i = 0; i < R.outJuncs.size(); i++) { if (i) o << ','; o << '[' << R.outJuncs[i].u << ',' << R.outJuncs[i].v << ',' << R.outJuncs[i].count << ']'; }
+    o << "],\"chr\":[";
+    for (size_t c = 0; c < R.chr.size(); c++) {
+        const ChrStage& s = R.chr[c];
+        if (c) o << ',';
+        o << "{\"start\":" << s.startID << ",\"end\":" << s.endID << ",\"bias\":" << s.bias
+          << ",\"shortcut\":" << (s.shortcut ? "true" : "false") << ",\"infeasible\":" << (s.infeasible ? "true" : "false");
+        o << ",\"junc_cn\":"; jdarr(o, s.juncCN);
+        o << ",\"inv_seg\":"; jarr(o, s.invSeg);
+        o << ",\"inv_junc\":"; jarr(o, s.invJunc);
+        o << ",\"seg_cn\":"; jdarr(o, s.segCNAfterIndelBias);
+        o << ",\"node2pat\":"; jarr2(o, s.dag.node2pat);
+        o << ",\"node2loop\":"; jarr2(o, s.dag.node2loop);
+        o << ",\"adj\":"; jarr2(o, s.dag.adj);
+        o << ",\"num_orders\":" << s.numOrders;
+        o << ",\"orders\":"; jarr2(o, s.orders);
+        o << ",\"first_valid\":" << s.bfb.firstValidOrder << ",\"first_forward\":" << s.bfb.firstValidOrientationForward
+          << ",\"evaluated\":" << s.bfb.evaluated << ",\"ub\":" << (s.bfb.undefinedBehaviour ? "true" : "false");
+        o << ",\"bkp\":"; jarr(o, s.bfb.bkpFirst);
+        o << ",\"path\":"; jarr(o, s.bfb.path);
+        o << ",\"all_paths\":"; jarr2(o, s.bfb.allPaths);
+        o << ",\"indel_printed\":" << (s.indelPrinted ? "true" : "false");
+        o << ",\"path_indel\":"; jarr(o, s.pathAfterIndel);
+        o << "}";
+    }
+    o << "]}";
+    return dup(o.str());
+}
+
+// Parsed-graph dump (after calculateHapDepth/calculateCopyNum), same JSON shape as oracle/_ref's ref_graph_dump.
+char* oracle_graph_dump(const char* lh) {
+    Graph g; std::string err;
+    std::ostringstream o;
+    o.precision(17);
+    bool ok = readGraph(lh, g, err) && calculateHapDepth(g, err);
+    if (ok) calculateCopyNum(g);
+    o << "{\"ok\":" << (ok ? "true" : "false") << ",\"err\":"; jstr(o, err);
+    o << ",\"segs\":[";
+    for (size_t i = 0; i < g.segs.size(); i++) {
+        auto& s = g.segs[i];
+        if (i) o << ',';
+        o << '[' << s.id << ',' << s.chrId << ','; jstr(o, s.chrom); o << ',' << s.start << ',' << s.end << ',' << s.cov << ',' << s.cn << ']';
+    }
+    o << "],\"juncs\":[";
+    for (size_t i = 0; i < g.juncs.size(); i++) {
+        auto& j = g.juncs[i];
+        if (i) o << ',';
+        o << '[' << j.src << ",\"" << j.sdir << "\"," << j.tgt << ",\"" << j.tdir << "\"," << j.cov << ',' << j.cn << ','
+          << (j.inferred ? 1 : 0) << ',' << (j.bounded ? 1 : 0) << ']';
+    }
+    o << "],\"sources\":"; jarr(o, g.sourceIds);
+    o << ",\"sinks\":"; jarr(o, g.sinkIds);
+    o << ",\"log\":[";
+    for (size_t i = 0; i < g.log.size(); i++) { if (i) o << ','; jstr(o, g.log[i]); }
+    o << "]}";
+    return dup(o.str());
+}
+
+}  // extern "C"
