@@ -1,0 +1,473 @@
+"""ctypes binding of libambigram_hip.so (include/ambigram_hip.h) and the host-side mirror of the reference's
+`--op bfb` driver (localhap.cpp:49-388).
+
+The HIP library is the product.  There is NO CPU fallback: `load()` raises if the library is missing and the engine
+returns AMBI_ERR_NO_DEVICE without a GPU.  (Tests that run without a GPU pass the path of the test-only host
+simulation built under tests/hostsim explicitly; nothing here picks it up by itself.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libambigram_hip.so")
+
+FLAG_REVERSED = 1
+FLAG_ALL = 2
+
+ST_OK, ST_SHORTCUT, ST_INFEASIBLE, ST_NO_VALID_ORDER = 0, 1, 2, 3
+
+
+class UnitResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("bias", C.c_int32), ("n_nodes", C.c_int32), ("bkp_len", C.c_int32),
+                ("path_len", C.c_int32), ("path_indel_len", C.c_int32), ("indel_printed", C.c_int32),
+                ("n_out_junc", C.c_int32), ("first_forward", C.c_int32), ("evaluated", C.c_int32),
+                ("num_orders", C.c_int64), ("first_valid", C.c_int64), ("inv_cn_sum", C.c_double)]
+
+
+class AmbiError(RuntimeError):
+    def __init__(self, lib, code, what=""):
+        self.code = code
+        msg = lib.ambi_error_string(code).decode() if lib is not None else str(code)
+        super().__init__("%s: %s (%d)" % (what, msg, code))
+
+
+_P = C.POINTER
+
+
+def _declare(L):
+    vp = C.c_void_p
+    i32, i64, u32 = C.c_int32, C.c_int64, C.c_uint32
+    pi32, pi64, pi8, pu8, pd = _P(i32), _P(i64), _P(C.c_int8), _P(C.c_uint8), _P(C.c_double)
+    sig = {
+        "ambi_error_string": (C.c_char_p, [C.c_int]),
+        "ambi_abi_version": (C.c_int, []),
+        "ambi_backend_name": (C.c_char_p, []),
+        "ambi_device_count": (C.c_int, [_P(C.c_int)]),
+        "ambi_set_device": (C.c_int, [C.c_int]),
+        "ambi_graph_read_lh": (C.c_int, [C.c_char_p, _P(vp)]),
+        "ambi_graph_destroy": (None, [vp]),
+        "ambi_graph_sizes": (C.c_int, [vp, pi32, pi32, pi32]),
+        "ambi_graph_segments": (C.c_int, [vp, pi32, pi32, pi32, pi32, pd, pd]),
+        "ambi_graph_junctions": (C.c_int, [vp, pi32, pi8, pi32, pi8, pd, pd, pu8, pu8]),
+        "ambi_graph_chromosome": (C.c_int, [vp, i32, pi32, pi32]),
+        "ambi_graph_read_juncs": (C.c_int, [vp, C.c_char_p]),
+        "ambi_graph_log": (i64, [vp, C.c_char_p, i64]),
+        "ambi_graph_props": (C.c_int, [vp, pi32, pi32, C.c_char_p, i64]),
+        "ambi_batch_create": (C.c_int, [_P(vp)]),
+        "ambi_batch_destroy": (None, [vp]),
+        "ambi_batch_add_chromosome": (C.c_int, [vp, vp, i32, i32, pi32, pi32, i32]),
+        "ambi_batch_add_chromosome_sol": (C.c_int, [vp, vp, i32, C.c_char_p]),
+        "ambi_batch_add_unit": (C.c_int, [vp, i32, i32, pd, i32, pi32, pi32, pi8, pi8, pd, i32, pi32, pi32, pi32, pi32, i32, i32]),
+        "ambi_batch_size": (C.c_int, [vp, pi32]),
+        "ambi_batch_configure": (C.c_int, [vp, i64, i32, i32, i32]),
+        "ambi_batch_upload": (C.c_int, [vp]),
+        "ambi_batch_run": (C.c_int, [vp, u32, vp]),
+        "ambi_batch_wait": (C.c_int, [vp]),
+        "ambi_batch_download": (C.c_int, [vp]),
+        "ambi_batch_device_results": (C.c_int, [vp, _P(vp), pi64]),
+        "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
+        "ambi_batch_unit_result": (C.c_int, [vp, i32, _P(UnitResult)]),
+        "ambi_batch_unit_path": (C.c_int, [vp, i32, i32, pi32, i32]),
+        "ambi_batch_unit_bkp": (C.c_int, [vp, i32, pi32, i32]),
+        "ambi_batch_unit_prepare": (C.c_int, [vp, i32, pd, pd, pi32, pi32]),
+        "ambi_batch_unit_dag": (C.c_int, [vp, i32, pi32, pi32, _P(C.c_uint64)]),
+        "ambi_batch_unit_out_juncs": (C.c_int, [vp, i32, pi32, pi32, pi32, i32]),
+        "ambi_batch_unit_orders": (C.c_int, [vp, i32, i64, i64, pu8]),
+        "ambi_batch_set_timing": (C.c_int, [vp, i32]),
+        "ambi_batch_kernel_count": (C.c_int, [vp]),
+        "ambi_batch_kernel_time": (C.c_int, [vp, i32, _P(C.c_char_p), _P(C.c_float)]),
+        "ambi_batch_traffic": (C.c_int, [vp, pi64, pi64, pi64]),
+        "ambi_format_path": (i64, [vp, pi32, i32, C.c_char_p, i64]),
+        "ambi_translocation_bfb": (C.c_int, [vp, pi32, pi64, i32, pi32, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sorted(sig)
+
+
+_LIBS = {}
+EXPORTS = []
+
+
+def load(path=None):
+    """Load the engine library.  Fails loudly when the HIP extension has not been built."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path not in _LIBS:
+        if not os.path.exists(path):
+            raise RuntimeError("ambigram_amd: %s not found -- build the HIP extension first "
+                               "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % path)
+        L = C.CDLL(path)
+        names = _declare(L)
+        if not EXPORTS:
+            EXPORTS.extend(names)
+        _LIBS[path] = L
+    return _LIBS[path]
+
+
+def _arr(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(_P(np.ctypeslib.as_ctypes_type(dtype)))
+
+
+class Graph:
+    """Parsed .lh (replaces Graph + calculateHapDepth + calculateCopyNum + readBFBProps, localhap.cpp:65-75)."""
+
+    def __init__(self, lib, lh_path):
+        self.lib = lib
+        self.h = C.c_void_p()
+        rc = lib.ambi_graph_read_lh(lh_path.encode(), C.byref(self.h))
+        if rc != 0:
+            raise AmbiError(lib, rc, "read_lh(%s)" % lh_path)
+        n, m, c = C.c_int32(), C.c_int32(), C.c_int32()
+        lib.ambi_graph_sizes(self.h, C.byref(n), C.byref(m), C.byref(c))
+        self.n_seg, self.n_junc, self.n_chr = n.value, m.value, c.value
+
+    def close(self):
+        if self.h:
+            self.lib.ambi_graph_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _refresh(self):
+        n, m, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.ambi_graph_sizes(self.h, C.byref(n), C.byref(m), C.byref(c))
+        self.n_seg, self.n_junc, self.n_chr = n.value, m.value, c.value
+
+    def read_juncs(self, path):
+        rc = self.lib.ambi_graph_read_juncs(self.h, path.encode())
+        if rc != 0:
+            raise AmbiError(self.lib, rc, "read_juncs")
+        self._refresh()
+
+    def segments(self):
+        n = self.n_seg
+        sid, chr_, st, en = (np.zeros(n, np.int32) for _ in range(4))
+        cov, cn = np.zeros(n), np.zeros(n)
+        p = lambda a, t: a.ctypes.data_as(_P(t))
+        self.lib.ambi_graph_segments(self.h, p(sid, C.c_int32), p(chr_, C.c_int32), p(st, C.c_int32), p(en, C.c_int32),
+                                     p(cov, C.c_double), p(cn, C.c_double))
+        return dict(id=sid, chr=chr_, start=st, end=en, cov=cov, cn=cn)
+
+    def junctions(self):
+        m = self.n_junc
+        src, tgt = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        sd, td = np.zeros(m, np.int8), np.zeros(m, np.int8)
+        cov, cn = np.zeros(m), np.zeros(m)
+        inf, bnd = np.zeros(m, np.uint8), np.zeros(m, np.uint8)
+        p = lambda a, t: a.ctypes.data_as(_P(t))
+        self.lib.ambi_graph_junctions(self.h, p(src, C.c_int32), p(sd, C.c_int8), p(tgt, C.c_int32), p(td, C.c_int8),
+                                      p(cov, C.c_double), p(cn, C.c_double), p(inf, C.c_uint8), p(bnd, C.c_uint8))
+        return dict(src=src, sdir=sd, tgt=tgt, tdir=td, cov=cov, cn=cn, inferred=inf, bounded=bnd)
+
+    def chromosome(self, c):
+        s, e = C.c_int32(), C.c_int32()
+        rc = self.lib.ambi_graph_chromosome(self.h, c, C.byref(s), C.byref(e))
+        if rc != 0:
+            raise AmbiError(self.lib, rc, "chromosome")
+        return s.value, e.value
+
+    def log(self):
+        n = self.lib.ambi_graph_log(self.h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.ambi_graph_log(self.h, buf, n + 1)
+        return [l for l in buf.value.decode().split("\n") if l != ""]
+
+    def props(self):
+        ins, con = C.c_int32(), C.c_int32()
+        buf = C.create_string_buffer(256)
+        self.lib.ambi_graph_props(self.h, C.byref(ins), C.byref(con), buf, 256)
+        return ins.value, con.value, buf.value.decode()
+
+    def format_path(self, path):
+        a, p = _arr(path, np.int32)
+        n = self.lib.ambi_format_path(self.h, p, len(a), None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.ambi_format_path(self.h, p, len(a), buf, n + 1)
+        return buf.value.decode()
+
+    def translocation_bfb(self, paths):
+        """BFB-TRX stitching (LGM.cpp:4052-4193). `paths`: list of per-chromosome int arrays (may be modified)."""
+        offs = np.zeros(len(paths) + 1, np.int64)
+        for i, q in enumerate(paths):
+            offs[i + 1] = offs[i] + len(q)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(q, np.int32) for q in paths]) if offs[-1] else np.zeros(0, np.int32))
+        cap = int(offs[-1]) * 2 + 16
+        out = np.zeros(cap, np.int32)
+        n = self.lib.ambi_translocation_bfb(self.h, flat.ctypes.data_as(_P(C.c_int32)), offs.ctypes.data_as(_P(C.c_int64)),
+                                            len(paths), out.ctypes.data_as(_P(C.c_int32)), cap)
+        if n < 0:
+            raise AmbiError(self.lib, n, "translocation_bfb")
+        new_paths = [flat[offs[i]:offs[i + 1]].copy() for i in range(len(paths))]
+        return out[:n].copy(), new_paths
+
+
+class Batch:
+    """A batch of units (chromosomes of samples) resident in HBM."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p()
+        rc = lib.ambi_batch_create(C.byref(self.h))
+        if rc != 0:
+            raise AmbiError(lib, rc, "batch_create")
+
+    def close(self):
+        if self.h:
+            self.lib.ambi_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc < 0:
+            raise AmbiError(self.lib, rc, what)
+        return rc
+
+    def add_chromosome(self, graph, chr_, cols, vals, infeasible=False):
+        c, pc = _arr(cols, np.int32)
+        v, pv = _arr(vals, np.int32)
+        return self._ck(self.lib.ambi_batch_add_chromosome(self.h, graph.h, chr_, len(c), pc, pv, 1 if infeasible else 0), "add_chromosome")
+
+    def add_chromosome_sol(self, graph, chr_, sol_path):
+        return self._ck(self.lib.ambi_batch_add_chromosome_sol(self.h, graph.h, chr_, sol_path.encode()), "add_chromosome_sol")
+
+    def add_unit(self, n_seg, seg_base, seg_cn, j_src, j_tgt, j_sdir, j_tdir, j_cn, e_is_loop, e_a, e_b, e_cn,
+                 infeasible=False, has_components=False):
+        cn, pcn = _arr(seg_cn, np.float64)
+        js, pjs = _arr(j_src, np.int32); jt, pjt = _arr(j_tgt, np.int32)
+        jsd, pjsd = _arr(j_sdir, np.int8); jtd, pjtd = _arr(j_tdir, np.int8)
+        jc, pjc = _arr(j_cn, np.float64)
+        el, pel = _arr(e_is_loop, np.int32); ea, pea = _arr(e_a, np.int32); eb, peb = _arr(e_b, np.int32); ec, pec = _arr(e_cn, np.int32)
+        return self._ck(self.lib.ambi_batch_add_unit(self.h, n_seg, seg_base, pcn, len(js), pjs, pjt, pjsd, pjtd, pjc, len(ea),
+                                                      pel, pea, peb, pec, 1 if infeasible else 0, 1 if has_components else 0), "add_unit")
+
+    def size(self):
+        n = C.c_int32()
+        self.lib.ambi_batch_size(self.h, C.byref(n))
+        return n.value
+
+    def configure(self, order_arena_bytes=-1, ideal_cap=0, first_budget=0, tile_bytes=0):
+        self._ck(self.lib.ambi_batch_configure(self.h, order_arena_bytes, ideal_cap, first_budget, tile_bytes), "configure")
+
+    def upload(self):
+        self._ck(self.lib.ambi_batch_upload(self.h), "upload")
+
+    def run(self, flags=0, stream=None):
+        self._ck(self.lib.ambi_batch_run(self.h, flags, C.c_void_p(stream or 0)), "run")
+
+    def wait(self):
+        self._ck(self.lib.ambi_batch_wait(self.h), "wait")
+
+    def download(self):
+        self._ck(self.lib.ambi_batch_download(self.h), "download")
+
+    def device_results(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.ambi_batch_device_results(self.h, C.byref(p), C.byref(n)), "device_results")
+        return p.value, n.value
+
+    def pack_paths(self, which, dev_lengths_ptr, dev_cells_ptr, cell_cap, dev_total_ptr, stream=None):
+        self._ck(self.lib.ambi_batch_pack_paths(self.h, which, C.c_void_p(dev_lengths_ptr), C.c_void_p(dev_cells_ptr), cell_cap,
+                                                 C.c_void_p(dev_total_ptr), C.c_void_p(stream or 0)), "pack_paths")
+
+    def unit_result(self, u):
+        r = UnitResult()
+        self._ck(self.lib.ambi_batch_unit_result(self.h, u, C.byref(r)), "unit_result")
+        return {k: getattr(r, k) for k, _ in UnitResult._fields_}
+
+    def unit_path(self, u, which=0):
+        n = self._ck(self.lib.ambi_batch_unit_path(self.h, u, which, None, 0), "unit_path")
+        out = np.zeros(max(n, 1), np.int32)
+        self.lib.ambi_batch_unit_path(self.h, u, which, out.ctypes.data_as(_P(C.c_int32)), n)
+        return out[:n]
+
+    def unit_bkp(self, u):
+        n = self._ck(self.lib.ambi_batch_unit_bkp(self.h, u, None, 0), "unit_bkp")
+        out = np.zeros(max(n, 1), np.int32)
+        self.lib.ambi_batch_unit_bkp(self.h, u, out.ctypes.data_as(_P(C.c_int32)), n)
+        return out[:n]
+
+    def unit_prepare(self, u, n_seg):
+        jc = np.zeros(2 * (n_seg + 1)); sc = np.zeros(n_seg + 1)
+        tc = np.zeros(n_seg + 1, np.int32); ij = np.zeros(n_seg + 1, np.int32)
+        self._ck(self.lib.ambi_batch_unit_prepare(self.h, u, jc.ctypes.data_as(_P(C.c_double)), sc.ctypes.data_as(_P(C.c_double)),
+                                                   tc.ctypes.data_as(_P(C.c_int32)), ij.ctypes.data_as(_P(C.c_int32))), "unit_prepare")
+        return dict(junc_cn=jc.reshape(-1, 2), seg_cn=sc, target_cn=tc, inv_junc=ij)
+
+    def unit_dag(self, u, K):
+        pat = np.zeros((max(K, 1), 3), np.int32); loop = np.zeros((max(K, 1), 3), np.int32); succ = np.zeros(max(K, 1), np.uint64)
+        self._ck(self.lib.ambi_batch_unit_dag(self.h, u, pat.ctypes.data_as(_P(C.c_int32)), loop.ctypes.data_as(_P(C.c_int32)),
+                                               succ.ctypes.data_as(_P(C.c_uint64))), "unit_dag")
+        return pat[:K], loop[:K], succ[:K]
+
+    def unit_out_juncs(self, u):
+        n = self._ck(self.lib.ambi_batch_unit_out_juncs(self.h, u, None, None, None, 0), "unit_out_juncs")
+        a, b, c = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        p = lambda x: x.ctypes.data_as(_P(C.c_int32))
+        self.lib.ambi_batch_unit_out_juncs(self.h, u, p(a), p(b), p(c), n)
+        return [(int(a[i]), int(b[i]), int(c[i])) for i in range(n)]
+
+    def unit_orders(self, u, first, count, K):
+        out = np.zeros((max(count, 1), max(K, 1)), np.uint8)
+        self._ck(self.lib.ambi_batch_unit_orders(self.h, u, first, count, out.ctypes.data_as(_P(C.c_uint8))), "unit_orders")
+        return out[:count, :K]
+
+    def set_timing(self, on=True):
+        self.lib.ambi_batch_set_timing(self.h, 1 if on else 0)
+
+    def kernel_times(self):
+        out = {}
+        for i in range(self.lib.ambi_batch_kernel_count(self.h)):
+            name, ms = C.c_char_p(), C.c_float()
+            self.lib.ambi_batch_kernel_time(self.h, i, C.byref(name), C.byref(ms))
+            out[name.value.decode()] = ms.value
+        return out
+
+    def traffic(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.lib.ambi_batch_traffic(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(input_bytes=a.value, order_bytes=b.value, result_bytes=c.value)
+
+
+def read_sol(path):
+    """Token scan of a CBC .sol (localhap.cpp:192-212) -> (infeasible, objective, cols, vals)."""
+    cols, vals, infeasible, obj = [], [], False, 0.0
+    with open(path) as f:
+        toks = f.read().split()
+    i = 0
+    while i < len(toks):
+        t = toks[i]
+        if t == "Infeasible":
+            infeasible = True
+            break
+        if t == "value" and i + 1 < len(toks):
+            try:
+                obj += float(toks[i + 1])
+            except ValueError:
+                pass
+            i += 1
+        elif t[0] == 'x' and i + 1 < len(toks):
+            cols.append(int(t[1:]))
+            vals.append(int(float(toks[i + 1])) if toks[i + 1].lstrip('-').replace('.', '', 1).isdigit() else 0)
+            i += 1
+        i += 1
+    return infeasible, obj, cols, vals
+
+
+def merge_out_juncs(acc, unit_list, increase=True):
+    """localhap.cpp:267-289: merge one path's junction steps (already aggregated per unit) in first-appearance order."""
+    for (u, v, c) in unit_list:
+        for j in acc:
+            if (j[0] == u and j[1] == v) or (j[0] == -v and j[1] == -u):
+                if increase:
+                    j[2] += c
+                break
+        else:
+            acc.append([u, v, c])
+
+
+def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, first_budget=0, order_arena_bytes=-1,
+                       tile_bytes=0, keep_orders=False):
+    """Host-side mirror of `Ambigram --op bfb` (localhap.cpp:49-388) with the external `cbc` call replaced by the given
+    .sol files (one per chromosome that reaches the ILP, in order).  Returns a dict shaped like the oracle's dump."""
+    g = Graph(lib, lh)
+    log = ["bfb"] + g.log()
+    n_log0 = len(g.log())
+    if juncs:
+        g.read_juncs(juncs)
+        log += g.log()[n_log0:]
+    b = Batch(lib)
+    b.configure(order_arena_bytes=order_arena_bytes, first_budget=first_budget, tile_bytes=tile_bytes)
+    # a chromosome reaches the ILP unless it has no fold-back inversion; the engine decides (status SHORTCUT), so the
+    # caller hands a .sol to every chromosome for which one exists, consuming them in order for non-shortcut units.
+    # To know which chromosomes are shortcuts before assigning .sol files, run a solution-less probe batch first.
+    probe = Batch(lib)
+    for c in range(g.n_chr):
+        probe.add_chromosome(g, c, [], [])
+    probe.upload(); probe.run(0); probe.download()
+    shortcut = [probe.unit_result(c)["status"] == ST_SHORTCUT for c in range(g.n_chr)]
+    probe.close()
+    cursor = 0
+    for c in range(g.n_chr):
+        if shortcut[c]:
+            b.add_chromosome(g, c, [], [])
+        else:
+            if cursor >= len(sols):
+                raise RuntimeError("missing .sol for chromosome %d" % c)
+            b.add_chromosome_sol(g, c, sols[cursor])
+            cursor += 1
+    flags = (FLAG_REVERSED if reversed_ else 0) | (FLAG_ALL if all_ else 0)
+    b.upload(); b.run(flags); b.download()
+    res = dict(ok=True, err="", log=log, chr=[], paths=[], out_juncs=[], trx_run=False, trx_path=[])
+    out_acc = []
+    for c in range(g.n_chr):
+        r = b.unit_result(c)
+        s, e = g.chromosome(c)
+        st = dict(start=s, end=e, status=r["status"], bias=r["bias"], num_orders=r["num_orders"], first_valid=r["first_valid"],
+                  first_forward=r["first_forward"], evaluated=r["evaluated"], K=r["n_nodes"])
+        if r["status"] < 0 or r["status"] == ST_NO_VALID_ORDER:
+            res["ok"] = False
+            res["err"] = lib.ambi_error_string(r["status"]).decode()
+            res["chr"].append(st)
+            res["paths"].append([])
+            continue
+        path = b.unit_path(c, 0)
+        path_ind = b.unit_path(c, 1)
+        prep = b.unit_prepare(c, e - s + 1)
+        st.update(path=path.tolist(), path_indel=path_ind.tolist(), bkp=b.unit_bkp(c).tolist(),
+                  junc_cn=prep["junc_cn"], seg_cn=prep["seg_cn"], target_cn=prep["target_cn"], inv_junc=prep["inv_junc"],
+                  indel_printed=bool(r["indel_printed"]), shortcut=r["status"] == ST_SHORTCUT,
+                  infeasible=r["status"] == ST_INFEASIBLE)
+        if r["status"] == ST_OK:
+            pat, loop, succ = b.unit_dag(c, r["n_nodes"])
+            st.update(node2pat=pat.tolist(), node2loop=loop.tolist(), succ=[int(x) for x in succ])
+            if keep_orders:
+                st["orders"] = b.unit_orders(c, 0, r["num_orders"], r["n_nodes"]).tolist()
+        if r["status"] == ST_SHORTCUT:
+            log.append(g.format_path(path))
+        else:
+            log += ["Declare done", "ILP formula done", "Variable constrains done"]   # BFB_ILP progress lines
+            log.append(g.format_path(path))
+            if r["status"] == ST_INFEASIBLE:
+                log.append("ILP is unsolvable.")
+            elif r["indel_printed"]:
+                log.append("BFB path with insertion, deletion, or duplication:")
+                log.append(g.format_path(path_ind))
+        res["chr"].append(st)
+        res["paths"].append(path_ind.tolist())
+        merge_out_juncs(out_acc, b.unit_out_juncs(c))
+    ins_mode, con_mode, main_chr = g.props()
+    if res["ok"] and (ins_mode == 2 or con_mode == 2):
+        if not main_chr:
+            res["ok"] = False
+            res["err"] = "BFB-TRX without M:<chr> (reference segfaults)"
+        else:
+            trx, new_paths = g.translocation_bfb([np.asarray(p, np.int32) for p in res["paths"]])
+            res["trx_run"] = True
+            res["trx_path"] = trx.tolist()
+            res["paths"] = [p.tolist() for p in new_paths]
+            log.append("BFB with translocation:")
+            log.append(g.format_path(trx))
+            steps = []
+            for i in range(len(trx) - 1):
+                u, v = int(trx[i]), int(trx[i + 1])
+                if not (abs(abs(u) - abs(v)) == 1 and (u > 0) == (v > 0)):
+                    steps.append((u, v, 1))
+            merge_out_juncs(out_acc, steps, increase=False)
+    res["out_juncs"] = [tuple(j) for j in out_acc]
+    b.close()
+    g.close()
+    return res

@@ -1,0 +1,43 @@
+// ambi_backend.hpp -- what the C-ABI layer (ambi_capi.cpp) needs from an execution backend.
+// The product links exactly one implementation: the HIP engine (ambi_engine.hip).  tests/hostsim links the same
+// C-ABI layer against a 1-thread host simulation of the SAME stage code for CPU-only checks; it is never shipped
+// in ambigram_amd/ and never selected at run time.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "ambi_pack.hpp"
+
+namespace ambi {
+
+struct EngineConfig {
+    int64_t order_arena_bytes = 0;   // 0: sized from the first run
+    int32_t first_budget = 64;
+    int32_t tile_bytes = 8192;
+};
+
+struct KernelTime { const char* name; float ms; };
+
+class Backend {
+  public:
+    virtual ~Backend() {}
+    virtual const char* name() const = 0;
+    virtual int device_count(int* n) = 0;
+    virtual int set_device(int d) = 0;
+    virtual int upload(const HostBatch& hb, const EngineConfig& cfg) = 0;
+    virtual int run(uint32_t flags, void* stream) = 0;
+    virtual int wait() = 0;
+    virtual int download(std::vector<uint8_t>& blob) = 0;
+    virtual int device_results(void** ptr, int64_t* bytes) = 0;
+    virtual int pack_paths(int which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap, int64_t* dev_total,
+                           void* stream) = 0;
+    virtual int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) = 0;
+    virtual int copy_dag(int unit, Dag* out) = 0;
+    virtual void set_timing(bool on) = 0;
+    virtual const std::vector<KernelTime>& kernel_times() = 0;
+    virtual int64_t order_bytes_written() const = 0;
+};
+
+Backend* make_backend();   // defined by the linked backend
+
+}  // namespace ambi

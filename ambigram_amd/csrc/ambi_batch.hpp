@@ -1,0 +1,116 @@
+// ambi_batch.hpp -- HBM layout of a batch of units and the kernel argument block.
+//
+// Inputs (uploaded once, resident in HBM while a batch is run any number of times):
+//   UnitIn[U]           fixed-size descriptor per unit: sizes + offsets into the pools below
+//   seg_cn   f64        (n+1) per unit, slot 0 unused, indexed by LOCAL segment id      ("8n"  of SURVEY 8d)
+//   juncs    Junction   24-byte records, reference junction order preserved             ("24m")
+//   elems    Element    16-byte records (solution columns with value > 0)               ("16K")
+// Working set (device only): per-unit Dag, ideal tables, the order-table arena (R x K uint8 rows, 16-byte aligned
+// per unit), bkp cells.
+// Results: one contiguous blob  [UnitOut[U]] [per-unit variable part ...]  so that a whole batch is fetched by a
+// single D2H copy or gathered by a single RCCL collective.
+#pragma once
+#include "ambi_common.hpp"
+#include "ambi_finish.hpp"
+
+namespace ambi {
+
+struct UnitIn {
+    int32_t n_seg;        // n: local segments 1..n
+    int32_t seg_base;     // absolute id = local + seg_base
+    int32_t n_junc;       // m
+    int32_t n_elem;       // K
+    int32_t infeasible;   // .sol said Infeasible
+    int32_t bkp_cap;      // cells
+    int32_t path_cap;     // cells
+    int32_t out_cap;      // output junction records
+    int64_t seg_off;      // into seg_cn pool (doubles)
+    int64_t junc_off;     // into juncs pool (records)
+    int64_t elem_off;     // into elems pool (records)
+    int64_t res_off;      // byte offset of this unit's variable part inside the result blob
+    int64_t ideal_off;    // slot offset into the ideal-table pools
+    int32_t ideal_cap;    // power of two
+    int32_t has_components;   // .juncs components exist for this chromosome (localhap.cpp:158-164)
+};
+
+// fixed-size result header of one unit
+struct UnitOut {
+    int32_t status;          // ambi::Status
+    int32_t bias;            // localhap.cpp:141-146
+    int32_t K;
+    int32_t bkp_len;         // L of the first valid order after imperfectFBI
+    int32_t path_len;        // P  (getBFB result, LGM.cpp:3660-3671)
+    int32_t path_indel_len;  // P' after indelBFB
+    int32_t indel_printed;   // reference prints the indel caption + path (LGM.cpp:3835-3836)
+    int32_t n_out_junc;
+    int32_t first_forward;   // orientation of the first valid assembly: 1 forward seed, 0 reversed seed, -1 none
+    int32_t evaluated;       // number of order evaluations performed by the reference's sequential scan (E)
+    int64_t num_orders;      // R
+    int64_t first_valid;     // index of the first valid order or -1
+    int64_t order_off;       // byte offset of this unit's rows in the order-table arena (-1: not materialised)
+    double inv_cn_sum;       // localhap.cpp:150-153
+};
+
+// Variable part of a unit inside the result blob, in this order (each array padded to 8 bytes):
+//   junc_cn   f64  2*(n+1)
+//   seg_cn    f64  (n+1)         after getIndelBias
+//   target_cn i32  (n+1)
+//   inv_src   i16  (n+1)   inv_tgt i16 (n+1)   inv_junc i32 (n+1)
+//   bkp       i16  bkp_cap
+//   path      i32  path_cap      absolute signed ids (getBFB result)
+//   path_ind  i32  path_cap      after indelBFB
+//   out_junc  OutJunc out_cap
+AMBI_HD int64_t pad8(int64_t b) { return (b + 7) & ~int64_t(7); }
+struct UnitLayout {
+    int64_t junc_cn, seg_cn, target_cn, inv_src, inv_tgt, inv_junc, bkp, path, path_ind, out_junc, total;
+};
+AMBI_HD UnitLayout unit_layout(int n, int bkp_cap, int path_cap, int out_cap) {
+    UnitLayout L;
+    int64_t o = 0;
+    L.junc_cn = o; o += pad8(int64_t(16) * (n + 1));
+    L.seg_cn = o; o += pad8(int64_t(8) * (n + 1));
+    L.target_cn = o; o += pad8(int64_t(4) * (n + 1));
+    L.inv_src = o; o += pad8(int64_t(2) * (n + 1));
+    L.inv_tgt = o; o += pad8(int64_t(2) * (n + 1));
+    L.inv_junc = o; o += pad8(int64_t(4) * (n + 1));
+    L.bkp = o; o += pad8(int64_t(2) * bkp_cap);
+    L.path = o; o += pad8(int64_t(4) * path_cap);
+    L.path_ind = o; o += pad8(int64_t(4) * path_cap);
+    L.out_junc = o; o += pad8(int64_t(sizeof(OutJunc)) * out_cap);
+    L.total = o;
+    return L;
+}
+
+// kernel argument block (device pointers)
+struct BatchArgs {
+    int32_t n_units;
+    uint32_t flags;
+    int32_t first_budget;        // orders the first-valid kernel tries per orientation before declaring PENDING
+    int32_t tile_bytes;          // LDS bytes of one wave's order tile in the enumerate kernel
+    const UnitIn* units;
+    const double* seg_cn;
+    const Junction* juncs;
+    const Element* elems;
+    Dag* dags;                   // [U]
+    uint8_t* results;            // result blob; UnitOut[U] at the front
+    // ideal tables (pools indexed by UnitIn::ideal_off)
+    uint64_t* ideal_keys;
+    uint64_t* ideal_cnt;
+    int32_t* ideal_lvl;
+    int32_t* ideal_lvl_off;      // [U][kMaxNodes+2]
+    int32_t* ideal_counter;      // [U]
+    // order table
+    uint8_t* order_arena;
+    int64_t order_arena_bytes;
+    int64_t* blk_off;            // [U+1] enumerate work-block prefix
+    int32_t* rows_per_lane;      // [U]   T of the unit
+    int32_t* n_pending;          // [1]
+    int64_t* orders_needed;      // [1] bytes the order table of the whole batch needs (for arena sizing)
+    // scratch for indel grouping (per unit: sv[m], grp[2m+4] ints, taken[m] bytes)
+    int32_t* scratch_i32;
+    int64_t* scratch_off;        // [U] offset (ints) into scratch_i32
+};
+
+AMBI_HD UnitOut* unit_out(uint8_t* results, int u) { return reinterpret_cast<UnitOut*>(results) + u; }
+
+}  // namespace ambi

@@ -1,0 +1,343 @@
+// ambi_capi.cpp -- implementation of the C ABI declared in include/ambigram_hip.h on top of a Backend.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ambigram_hip.h"
+#include "ambi_backend.hpp"
+#include "ambi_pack.hpp"
+#include "lh_graph.hpp"
+
+using namespace ambi;
+
+struct ambi_graph { LhGraph g; };
+
+struct ambi_batch {
+    HostBatch hb;
+    EngineConfig cfg;
+    std::unique_ptr<Backend> be;
+    std::vector<uint8_t> blob;
+    bool uploaded = false, downloaded = false;
+};
+
+static int64_t copy_text(const std::string& s, char* buf, int64_t cap) {
+    if (buf && cap > 0) {
+        int64_t n = (int64_t)s.size() < cap - 1 ? (int64_t)s.size() : cap - 1;
+        memcpy(buf, s.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return (int64_t)s.size();
+}
+
+extern "C" {
+
+const char* ambi_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case AMBI_ST_SHORTCUT: return "no fold-back inversion (reference path)";
+        case AMBI_ST_INFEASIBLE: return "ILP is unsolvable";
+        case AMBI_ST_NO_VALID_ORDER: return "no valid BFB order";
+        case AMBI_ERR_TOO_MANY_NODES: return "more than 63 selected patterns/loops in one chromosome";
+        case AMBI_ERR_NO_ELEMENTS: return "ILP solution selects no pattern or loop";
+        case AMBI_ERR_REF_UB: return "reference behaviour undefined on this input (out-of-bounds read)";
+        case AMBI_ERR_BKP_CAPACITY: return "breakpoint path capacity exceeded";
+        case AMBI_ERR_PATH_CAPACITY: return "path capacity exceeded";
+        case AMBI_ERR_ORDERS_CAPACITY: return "topological-order table does not fit the arena";
+        case AMBI_ERR_IDEALS_CAPACITY: return "order-ideal table capacity exceeded";
+        case AMBI_ERR_BAD_INPUT: return "bad unit input";
+        case AMBI_ERR_OUTJUNC_CAPACITY: return "output junction capacity exceeded";
+        case AMBI_ERR_NO_DEVICE: return "no HIP device available (libambigram_hip has no CPU fallback)";
+        case AMBI_ERR_HIP: return "HIP runtime error";
+        case AMBI_ERR_STATE: return "call order violated";
+        case AMBI_ERR_ARG: return "bad argument";
+        default: return lh_error_string(code);
+    }
+}
+
+int ambi_abi_version(void) { return AMBI_ABI_VERSION; }
+
+const char* ambi_backend_name(void) {
+    static std::string nm;
+    if (nm.empty()) { std::unique_ptr<Backend> b(make_backend()); nm = b->name(); }
+    return nm.c_str();
+}
+int ambi_device_count(int* count) { std::unique_ptr<Backend> b(make_backend()); return b->device_count(count); }
+int ambi_set_device(int device) { std::unique_ptr<Backend> b(make_backend()); return b->set_device(device); }
+
+// ---- graph ----
+int ambi_graph_read_lh(const char* lh_path, ambi_graph_t** out) {
+    if (!lh_path || !out) return AMBI_ERR_ARG;
+    std::unique_ptr<ambi_graph> g(new ambi_graph());
+    int rc = read_lh(lh_path, g->g);
+    if (rc != LH_OK) return rc;
+    *out = g.release();
+    return 0;
+}
+void ambi_graph_destroy(ambi_graph_t* g) { delete g; }
+int ambi_graph_sizes(const ambi_graph_t* g, int32_t* n_seg, int32_t* n_junc, int32_t* n_chr) {
+    if (!g) return AMBI_ERR_ARG;
+    if (n_seg) *n_seg = g->g.n_seg();
+    if (n_junc) *n_junc = g->g.n_junc();
+    if (n_chr) *n_chr = g->g.n_chr();
+    return 0;
+}
+int ambi_graph_segments(const ambi_graph_t* g, int32_t* id, int32_t* chr_id, int32_t* start, int32_t* end, double* cov, double* cn) {
+    if (!g) return AMBI_ERR_ARG;
+    const LhGraph& G = g->g;
+    for (int i = 0; i < G.n_seg(); i++) {
+        if (id) id[i] = G.seg_id[i];
+        if (chr_id) chr_id[i] = G.seg_chr[i];
+        if (start) start[i] = G.seg_start[i];
+        if (end) end[i] = G.seg_end[i];
+        if (cov) cov[i] = G.seg_cov[i];
+        if (cn) cn[i] = G.seg_cn[i];
+    }
+    return 0;
+}
+int ambi_graph_junctions(const ambi_graph_t* g, int32_t* src, int8_t* sdir, int32_t* tgt, int8_t* tdir, double* cov,
+                         double* cn, uint8_t* inferred, uint8_t* bounded) {
+    if (!g) return AMBI_ERR_ARG;
+    const LhGraph& G = g->g;
+    for (int i = 0; i < G.n_junc(); i++) {
+        if (src) src[i] = G.j_src[i];
+        if (sdir) sdir[i] = G.j_sdir[i];
+        if (tgt) tgt[i] = G.j_tgt[i];
+        if (tdir) tdir[i] = G.j_tdir[i];
+        if (cov) cov[i] = G.j_cov[i];
+        if (cn) cn[i] = G.j_cn[i];
+        if (inferred) inferred[i] = G.j_inferred[i];
+        if (bounded) bounded[i] = G.j_bounded[i];
+    }
+    return 0;
+}
+int ambi_graph_chromosome(const ambi_graph_t* g, int32_t chr, int32_t* source_id, int32_t* sink_id) {
+    if (!g || chr < 0 || chr >= g->g.n_chr()) return AMBI_ERR_ARG;
+    if (source_id) *source_id = g->g.source_ids[chr];
+    if (sink_id) *sink_id = g->g.sink_ids[chr];
+    return 0;
+}
+int ambi_graph_read_juncs(ambi_graph_t* g, const char* juncs_path) {
+    if (!g) return AMBI_ERR_ARG;
+    return read_juncs(g->g, juncs_path ? juncs_path : "");
+}
+int64_t ambi_graph_log(const ambi_graph_t* g, char* buf, int64_t cap) {
+    if (!g) return AMBI_ERR_ARG;
+    std::string s;
+    for (auto& l : g->g.log) { s += l; s += '\n'; }
+    return copy_text(s, buf, cap);
+}
+int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode, char* main_chr, int64_t cap) {
+    if (!g) return AMBI_ERR_ARG;
+    if (ins_mode) *ins_mode = g->g.ins_mode;
+    if (con_mode) *con_mode = g->g.con_mode;
+    copy_text(g->g.main_chr, main_chr, cap);
+    return 0;
+}
+
+// ---- batch ----
+int ambi_batch_create(ambi_batch_t** out) {
+    if (!out) return AMBI_ERR_ARG;
+    ambi_batch* b = new ambi_batch();
+    b->be.reset(make_backend());
+    *out = b;
+    return 0;
+}
+void ambi_batch_destroy(ambi_batch_t* b) { delete b; }
+
+int ambi_batch_add_chromosome(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, int32_t n_cols, const int32_t* col,
+                              const int32_t* val, int32_t infeasible) {
+    if (!b || !g || b->uploaded) return b && b->uploaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    SolFile s;
+    s.infeasible = infeasible != 0;
+    for (int i = 0; i < n_cols; i++) { s.col.push_back(col[i]); s.val.push_back(val[i]); }
+    return b->hb.add_graph_chr(g->g, chr, &s);
+}
+int ambi_batch_add_chromosome_sol(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, const char* sol_path) {
+    if (!b || !g || !sol_path) return AMBI_ERR_ARG;
+    if (b->uploaded) return AMBI_ERR_STATE;
+    SolFile s;
+    int rc = read_sol(sol_path, s);
+    if (rc != LH_OK) return rc;
+    return b->hb.add_graph_chr(g->g, chr, &s);
+}
+int ambi_batch_add_unit(ambi_batch_t* b, int32_t n_seg, int32_t seg_base, const double* seg_cn, int32_t n_junc,
+                        const int32_t* j_src, const int32_t* j_tgt, const int8_t* j_sdir, const int8_t* j_tdir,
+                        const double* j_cn, int32_t n_elem, const int32_t* e_is_loop, const int32_t* e_a,
+                        const int32_t* e_b, const int32_t* e_cn, int32_t infeasible, int32_t has_components) {
+    if (!b) return AMBI_ERR_ARG;
+    if (b->uploaded) return AMBI_ERR_STATE;
+    return b->hb.add_unit(n_seg, seg_base, seg_cn, n_junc, j_src, j_tgt, j_sdir, j_tdir, j_cn, n_elem, e_is_loop, e_a, e_b,
+                          e_cn, infeasible, has_components);
+}
+int ambi_batch_size(const ambi_batch_t* b, int32_t* n_units) {
+    if (!b || !n_units) return AMBI_ERR_ARG;
+    *n_units = (int32_t)b->hb.units.size();
+    return 0;
+}
+int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t tile_bytes) {
+    if (!b) return AMBI_ERR_ARG;
+    if (b->uploaded) return AMBI_ERR_STATE;
+    if (order_arena_bytes >= 0) b->cfg.order_arena_bytes = order_arena_bytes;
+    if (ideal_cap > 0) {
+        int c = 2;
+        while (c < ideal_cap) c <<= 1;
+        b->hb.ideal_cap = c;
+    }
+    if (first_budget > 0) b->cfg.first_budget = first_budget;
+    if (tile_bytes >= 64) b->cfg.tile_bytes = tile_bytes;
+    return 0;
+}
+int ambi_batch_upload(ambi_batch_t* b) {
+    if (!b) return AMBI_ERR_ARG;
+    if (b->hb.units.empty()) return AMBI_ERR_STATE;
+    b->hb.finalize();
+    int rc = b->be->upload(b->hb, b->cfg);
+    if (rc == 0) b->uploaded = true;
+    return rc;
+}
+int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream) {
+    if (!b) return AMBI_ERR_ARG;
+    if (!b->uploaded) return AMBI_ERR_STATE;
+    b->downloaded = false;
+    return b->be->run(flags, hip_stream);
+}
+int ambi_batch_wait(ambi_batch_t* b) { return b ? b->be->wait() : AMBI_ERR_ARG; }
+int ambi_batch_download(ambi_batch_t* b) {
+    if (!b) return AMBI_ERR_ARG;
+    if (!b->uploaded) return AMBI_ERR_STATE;
+    int rc = b->be->download(b->blob);
+    if (rc == 0) b->downloaded = true;
+    return rc;
+}
+int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes) {
+    if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    return b->be->device_results(dev_ptr, bytes);
+}
+int ambi_batch_pack_paths(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap,
+                          int64_t* dev_total_cells, void* hip_stream) {
+    if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    return b->be->pack_paths(which, dev_lengths, dev_cells, cell_cap, dev_total_cells, hip_stream);
+}
+
+static const UnitOut* header(const ambi_batch_t* b, int unit) {
+    if (!b || !b->downloaded || unit < 0 || unit >= (int)b->hb.units.size()) return nullptr;
+    return reinterpret_cast<const UnitOut*>(b->blob.data()) + unit;
+}
+
+int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result_t* out) {
+    const UnitOut* h = header(b, unit);
+    if (!h || !out) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    out->status = h->status; out->bias = h->bias; out->n_nodes = h->K; out->bkp_len = h->bkp_len;
+    out->path_len = h->path_len; out->path_indel_len = h->path_indel_len; out->indel_printed = h->indel_printed;
+    out->n_out_junc = h->n_out_junc; out->first_forward = h->first_forward; out->evaluated = h->evaluated;
+    out->num_orders = h->num_orders; out->first_valid = h->first_valid; out->inv_cn_sum = h->inv_cn_sum;
+    return 0;
+}
+int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int32_t* out, int32_t cap) {
+    const UnitOut* h = header(b, unit);
+    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitIn& U = b->hb.units[unit];
+    UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const int32_t* src = reinterpret_cast<const int32_t*>(b->blob.data() + U.res_off + (which ? L.path_ind : L.path));
+    int len = which ? h->path_indel_len : h->path_len;
+    if (out) for (int i = 0; i < len && i < cap; i++) out[i] = src[i];
+    return len;
+}
+int ambi_batch_unit_bkp(const ambi_batch_t* b, int32_t unit, int32_t* out, int32_t cap) {
+    const UnitOut* h = header(b, unit);
+    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitIn& U = b->hb.units[unit];
+    UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const int16_t* src = reinterpret_cast<const int16_t*>(b->blob.data() + U.res_off + L.bkp);
+    if (out) for (int i = 0; i < h->bkp_len && i < cap; i++) { int v = src[i]; out[i] = v > 0 ? v + U.seg_base : v - U.seg_base; }
+    return h->bkp_len;
+}
+int ambi_batch_unit_prepare(const ambi_batch_t* b, int32_t unit, double* junc_cn, double* seg_cn, int32_t* target_cn,
+                            int32_t* inv_junc_global) {
+    const UnitOut* h = header(b, unit);
+    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitIn& U = b->hb.units[unit];
+    UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const uint8_t* r = b->blob.data() + U.res_off;
+    const int n = U.n_seg;
+    if (junc_cn) memcpy(junc_cn, r + L.junc_cn, sizeof(double) * 2 * (n + 1));
+    if (seg_cn) memcpy(seg_cn, r + L.seg_cn, sizeof(double) * (n + 1));
+    if (target_cn) memcpy(target_cn, r + L.target_cn, sizeof(int32_t) * (n + 1));
+    if (inv_junc_global) {
+        const int32_t* ij = reinterpret_cast<const int32_t*>(r + L.inv_junc);
+        const std::vector<int32_t>& map = b->hb.junc_global[unit];
+        for (int i = 0; i <= n; i++) inv_junc_global[i] = (ij[i] >= 0 && ij[i] < (int)map.size()) ? map[ij[i]] : ij[i];
+    }
+    return n + 1;
+}
+int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, int32_t* node2loop, uint64_t* succ) {
+    const UnitOut* h = header(b, unit);
+    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    Dag D;
+    int rc = b->be->copy_dag(unit, &D);
+    if (rc) return rc;
+    const int base = b->hb.units[unit].seg_base;
+    for (int i = 0; i < h->K; i++) {
+        for (int c = 0; c < 3; c++) {
+            if (node2pat) node2pat[3 * i + c] = D.pat[i][c] + ((c < 2 && D.pat[i][0] != 0) ? base : 0);
+            if (node2loop) node2loop[3 * i + c] = D.loop[i][c] + ((c < 2 && D.loop[i][0] != 0) ? base : 0);
+        }
+        if (succ) succ[i] = D.succ[i];
+    }
+    return h->K;
+}
+int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap) {
+    const UnitOut* h = header(b, unit);
+    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitIn& U = b->hb.units[unit];
+    UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const OutJunc* src = reinterpret_cast<const OutJunc*>(b->blob.data() + U.res_off + L.out_junc);
+    for (int i = 0; i < h->n_out_junc && i < cap; i++) {
+        if (u) u[i] = src[i].u;
+        if (v) v[i] = src[i].v;
+        if (count) count[i] = src[i].count;
+    }
+    return h->n_out_junc;
+}
+int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out) {
+    if (!b || !b->uploaded || !out) return AMBI_ERR_ARG;
+    return b->be->copy_orders(unit, first, count, out);
+}
+int ambi_batch_set_timing(ambi_batch_t* b, int32_t on) { if (!b) return AMBI_ERR_ARG; b->be->set_timing(on != 0); return 0; }
+int ambi_batch_kernel_count(const ambi_batch_t* b) { return b ? (int)b->be->kernel_times().size() : AMBI_ERR_ARG; }
+int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms) {
+    if (!b) return AMBI_ERR_ARG;
+    const auto& kt = b->be->kernel_times();
+    if (idx < 0 || idx >= (int)kt.size()) return AMBI_ERR_ARG;
+    if (name) *name = kt[idx].name;
+    if (ms) *ms = kt[idx].ms;
+    return 0;
+}
+int ambi_batch_traffic(const ambi_batch_t* b, int64_t* input_bytes, int64_t* order_bytes, int64_t* result_bytes) {
+    if (!b) return AMBI_ERR_ARG;
+    const HostBatch& hb = b->hb;
+    if (input_bytes) *input_bytes = (int64_t)(hb.seg_cn.size() * 8 + hb.juncs.size() * sizeof(Junction) + hb.elems.size() * sizeof(Element) + hb.units.size() * sizeof(UnitIn));
+    if (order_bytes) *order_bytes = b->be->order_bytes_written();
+    if (result_bytes) *result_bytes = hb.result_bytes;
+    return 0;
+}
+
+// ---- whole-sample helpers ----
+int64_t ambi_format_path(const ambi_graph_t* g, const int32_t* path, int32_t len, char* buf, int64_t cap) {
+    if (!g) return AMBI_ERR_ARG;
+    return copy_text(format_path(g->g, path, len), buf, cap);
+}
+int ambi_translocation_bfb(const ambi_graph_t* g, int32_t* paths, const int64_t* offsets, int32_t n_chr, int32_t* out, int32_t cap) {
+    if (!g || !paths || !offsets) return AMBI_ERR_ARG;
+    std::vector<std::vector<int32_t>> pp(n_chr);
+    for (int c = 0; c < n_chr; c++) pp[c].assign(paths + offsets[c], paths + offsets[c + 1]);
+    std::vector<int32_t> res;
+    translocation_bfb(g->g, pp, res);
+    for (int c = 0; c < n_chr; c++)   // the per-chromosome paths may have been reverse-complemented in place
+        for (size_t i = 0; i < pp[c].size(); i++) paths[offsets[c] + i] = pp[c][i];
+    if (out) for (size_t i = 0; i < res.size() && (int)i < cap; i++) out[i] = res[i];
+    return (int)res.size();
+}
+
+}  // extern "C"

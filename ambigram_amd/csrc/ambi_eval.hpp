@@ -1,0 +1,241 @@
+// ambi_eval.hpp -- assembly of one candidate order into a fold-back palindrome breakpoint path.
+//
+// Restates the per-order body of LocalGenomicMap::getBFB (LGM.cpp:3519-3658) and imperfectFBI (:3431-3512) as
+// SPMD code: the breakpoint path `bkp` (int16 signed local vertex ids) lives in the group's LDS; the reverse
+// std::find with its parity / nesting tests becomes a strided scan + group max-reduction, the vector::insert
+// of a loop's 4*cn breakpoints becomes a chunked LDS shift.  One wavefront evaluates one order.
+#pragma once
+#include "ambi_common.hpp"
+#include "ambi_group.hpp"
+
+namespace ambi {
+
+typedef int16_t cell_t;
+
+// fold-back map of the unit (getJuncCN's `inversions`): for local segment id i, the junction's two segment ids,
+// or src[i]==0 when the segment has no entry.
+struct InvMap {
+    const int16_t* src;
+    const int16_t* tgt;
+};
+
+template <class G>
+AMBI_HD int find_last_slot(const G& g, const cell_t* bkp, int L, int target, bool less) {
+    // LGM.cpp:3591-3602: last odd position f holding `target` that does not fail the nesting test
+    int best = -1;
+    for (int f = g.tid(); f < L; f += g.size()) {
+        if ((f & 1) && bkp[f] == target) {
+            bool skip = false;
+            if (f < L - 2) {
+                int x = iabs(bkp[f - 1]), y = iabs(bkp[f + 2]);
+                skip = less ? (x < y) : (x > y);
+            }
+            if (!skip && f > best) best = f;
+        }
+    }
+    return g.max_i32(best);
+}
+
+// open a gap of `count` cells at index `at` (cells [at,L) move up); group-cooperative, in place
+template <class G, class T>
+AMBI_HD void shift_up(const G& g, T* a, int L, int at, int count) {
+    int n = L - at;
+    for (int top = n; top > 0; top -= g.size()) {
+        int i = top - 1 - g.tid();
+        T v = 0;
+        if (i >= 0) v = a[at + i];
+        g.sync();
+        if (i >= 0) a[at + i + count] = v;
+        g.sync();
+    }
+}
+
+// close the gap [at, at+count): cells [at+count, L) move down
+template <class G, class T>
+AMBI_HD void shift_down(const G& g, T* a, int L, int at, int count) {
+    int n = L - (at + count);
+    for (int base = 0; base < n; base += g.size()) {
+        int i = base + g.tid();
+        T v = 0;
+        if (i < n) v = a[at + count + i];
+        g.sync();
+        if (i < n) a[at + i] = v;
+        g.sync();
+    }
+}
+
+// LGM.cpp:3431-3512.  Returns false when the reference would have read out of bounds.
+template <class G>
+AMBI_HD bool imperfect_fbi(const G& g, cell_t* bkp, int L, const InvMap& inv) {
+    int pos = 0;
+    while (pos < L) {
+        if (pos + 1 >= L) return false;
+        int r = L;
+        if (pos + 3 < L) {
+            int want = -bkp[pos];
+            int best = 0x7fffffff;
+            for (int q = pos + 3 + g.tid(); q < L; q += g.size())
+                if (bkp[q] == want) { best = q; break; }
+            best = g.min_i32(best);
+            if (best != 0x7fffffff) r = best;
+        }
+        int l = r - 1;
+        bool plain = (r == L) || (bkp[l] != -bkp[pos + 1]);
+        g.sync();
+        if (plain) {
+            if (g.tid() == 0) {
+                int id = iabs(bkp[pos + 1]);
+                if (inv.src[id] != 0) {
+                    int s = inv.src[id], t = inv.tgt[id];
+                    if (bkp[pos + 1] > 0) bkp[pos + 1] = (cell_t)((s < t) ? s : t);
+                    else bkp[pos + 1] = (cell_t)((s < t) ? -t : -s);
+                }
+                if (pos > 0) {
+                    id = iabs(bkp[pos]);
+                    if (inv.src[id] != 0 && iabs(bkp[pos - 1]) == id) {
+                        int other = (inv.src[id] == id) ? inv.tgt[id] : inv.src[id];
+                        bkp[pos] = (cell_t)(bkp[pos] > 0 ? other : -other);
+                    }
+                }
+                if (bkp[pos] > 0 && iabs(bkp[pos]) > iabs(bkp[pos + 1])) bkp[pos + 1] = bkp[pos];
+                if (bkp[pos] < 0 && iabs(bkp[pos]) < iabs(bkp[pos + 1])) bkp[pos + 1] = bkp[pos];
+            }
+            g.sync();
+            pos += 2;
+        } else {
+            int bad = 0;
+            if (g.tid() == 0) {
+                int p1 = pos + ((l - pos) / 2), p2 = p1 + 1;
+                while (p1 >= pos - 1 && p1 > 0) {
+                    int id = iabs(bkp[p1]);
+                    if (inv.src[id] != 0) {
+                        int s = inv.src[id], t = inv.tgt[id];
+                        if (p1 + 1 >= L) { bad = 1; break; }
+                        if (bkp[p1] > 0) {
+                            if (s < t) { bkp[p1] = (cell_t)s; bkp[p1 + 1] = (cell_t)-t; }
+                            else { bkp[p1] = (cell_t)t; bkp[p1 + 1] = (cell_t)-s; }
+                        } else {
+                            if (s < t) { bkp[p1] = (cell_t)-t; bkp[p1 + 1] = (cell_t)s; }
+                            else { bkp[p1] = (cell_t)-s; bkp[p1 + 1] = (cell_t)t; }
+                        }
+                        if (p2 != p1 + 1) {
+                            if (p1 > pos - 1) { if (p2 >= L) { bad = 1; break; } bkp[p2] = (cell_t)-bkp[p1]; }
+                            bkp[p2 - 1] = (cell_t)-bkp[p1 + 1];
+                        }
+                    }
+                    p1 -= 2; p2 += 2;
+                }
+            }
+            g.sync();
+            if (g.any(bad != 0)) return false;
+            pos = r + 1;
+        }
+    }
+    return true;
+}
+
+// Evaluate one order.  Returns 1 valid / 0 invalid / negative Status on error.  *L_out = bkp length.
+template <class G>
+AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forward, const InvMap& inv,
+                       cell_t* bkp, int cap, int* L_out) {
+    const int K = D.K;
+    int L = 0;
+    int x = ord[0];
+    bool isPat = D.pat[x][0] != 0, isLoop = D.loop[x][0] != 0;
+    if (!isPat && !isLoop) { *L_out = 0; return ST_ERR_REF_UB; }   // reference indexes an empty vector
+    {
+        int s = isPat ? D.pat[x][0] : D.loop[x][0], e = isPat ? D.pat[x][1] : D.loop[x][1];
+        int q0, q1, q2, q3, len;
+        if (forward) { q0 = s; q1 = e; q2 = -e; q3 = -s; } else { q0 = -e; q1 = -s; q2 = s; q3 = e; }
+        len = isPat ? 2 : 4 * D.loop[x][2];
+        if (len > cap) { *L_out = 0; return ST_ERR_BKP_CAPACITY; }
+        for (int i = g.tid(); i < len; i += g.size()) {
+            int w = i & 3;
+            bkp[i] = (cell_t)(w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3);
+        }
+        L = len;
+        g.sync();
+    }
+    int i;
+    for (i = 1; i < K; i++) {
+        x = ord[i];
+        if (D.pat[x][0] != 0) {   // LGM.cpp:3572-3585
+            int s = D.pat[x][0], e = D.pat[x][1];
+            if (L == 0) { *L_out = 0; return ST_ERR_REF_UB; }
+            int back = bkp[L - 1];
+            if (L + 2 > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
+            g.sync();
+            if (back == -s) { if (g.tid() == 0) { bkp[L] = (cell_t)s; bkp[L + 1] = (cell_t)e; } L += 2; }
+            else if (back == e) { if (g.tid() == 0) { bkp[L] = (cell_t)-e; bkp[L + 1] = (cell_t)-s; } L += 2; }
+            else break;
+            g.sync();
+        } else if (D.loop[x][0] != 0) {   // LGM.cpp:3586-3644
+            int s = D.loop[x][0], e = D.loop[x][1], cn = D.loop[x][2];
+            bool viaV1 = true;
+            int f = find_last_slot(g, bkp, L, -s, true);
+            if (f < 0) { f = find_last_slot(g, bkp, L, e, false); viaV1 = false; }
+            if (f < 0) break;
+            int cnt = 4 * cn;
+            if (L + cnt > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
+            bool hasNext = (f + 1 != L);
+            shift_up(g, bkp, L, f + 1, cnt);
+            int q0, q1, q2, q3, fix0, fix1;
+            if (viaV1) { q0 = s; q1 = e; q2 = -e; q3 = -s; fix0 = -s; fix1 = s; }
+            else { q0 = -e; q1 = -s; q2 = s; q3 = e; fix0 = e; fix1 = -e; }
+            for (int k = g.tid(); k < cnt; k += g.size()) {
+                int w = k & 3;
+                bkp[f + 1 + k] = (cell_t)(w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3);
+            }
+            if (g.tid() == 0) {
+                bkp[f] = (cell_t)fix0;                       // *temp (LGM.cpp:3627 / :3640)
+                if (hasNext) bkp[f + 1 + cnt] = (cell_t)fix1;   // *(temp+1), written before the insert shifts it
+            }
+            L += cnt;
+            g.sync();
+        }
+        // both slots empty (possible after the library sort for K > 16): nothing is placed, the loop goes on
+    }
+    bool ok = imperfect_fbi(g, bkp, L, inv);   // LGM.cpp:3656, before the validity test
+    *L_out = L;
+    if (!ok) return ST_ERR_REF_UB;
+    return (i == K) ? 1 : 0;
+}
+
+// LGM.cpp:3661-3670: breakpoint pairs -> per-segment path (int16 local signed ids).  `offs` = scratch of
+// L/2+1 ints.  Returns P or a negative Status.
+template <class G>
+AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int pcap, int32_t* offs) {
+    int np = L / 2;
+    int carry = 0;
+    for (int base = 0; base < np; base += g.size()) {
+        int j = base + g.tid();
+        int len = 0;
+        if (j < np) {
+            int a = bkp[2 * j], b = bkp[2 * j + 1];
+            if (a > 0) { len = iabs(b) - a + 1; } else { len = (-a) - iabs(b) + 1; }
+            if (len < 0) len = 0;
+        }
+        int tot;
+        int ex = g.exscan_i32(len, &tot);
+        if (j < np) offs[j] = carry + ex;
+        carry += tot;
+    }
+    const int P = carry;
+    if (g.tid() == 0) offs[np] = P;
+    g.sync();
+    if (P > pcap) return ST_ERR_PATH_CAPACITY;
+    for (int o = g.tid(); o < P; o += g.size()) {
+        int lo = 0, hi = np;   // last pair with offs[pair] <= o
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (offs[mid] <= o) lo = mid; else hi = mid; }
+        // pairs with zero length share an offset with their successor: take the last one that starts at <= o and
+        // actually covers o
+        while (lo + 1 < np && offs[lo + 1] <= o) lo++;
+        int a = bkp[2 * lo];
+        int k = o - offs[lo];
+        path[o] = (cell_t)(a > 0 ? a + k : a + k);   // '+' run counts up, '-' run: -(|a|-k) = a + k
+    }
+    g.sync();
+    return P;
+}
+
+}  // namespace ambi

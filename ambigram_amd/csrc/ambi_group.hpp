@@ -1,0 +1,115 @@
+// ambi_group.hpp -- thread-group policies for the SPMD algorithm headers.
+//
+// Every cooperative routine takes a group `g` and is written so that
+//   * all threads of the group execute it with identical (group-uniform) control flow,
+//   * per-element work is strided:  for (i = g.tid(); i < n; i += g.size()),
+//   * data handed between threads through the group's memory is separated by g.sync(),
+//   * decisions come from group reductions (g.min_i32 / g.max_i32 / g.any).
+// Policies:
+//   HostGroup   1 thread, reductions are identities        -> CPU host simulation (tests, sanitizers)
+//   WaveGroup   one 64-lane CDNA wavefront, DPP/shuffle reductions, no LDS scratch needed
+//   BlockGroup  one workgroup of up to 1024 threads (wave reduce + LDS exchange)
+#pragma once
+#include "ambi_common.hpp"
+
+namespace ambi {
+
+struct HostGroup {
+    AMBI_HD int tid() const { return 0; }
+    AMBI_HD int size() const { return 1; }
+    AMBI_HD void sync() const {}
+    AMBI_HD int min_i32(int v) const { return v; }
+    AMBI_HD int max_i32(int v) const { return v; }
+    AMBI_HD int sum_i32(int v) const { return v; }
+    AMBI_HD bool any(bool p) const { return p; }
+    AMBI_HD int bcast_i32(int v, int /*src*/) const { return v; }
+    // exclusive prefix sum over the group in thread order; total returned through *total
+    AMBI_HD int exscan_i32(int v, int* total) const { *total = v; return 0; }
+};
+
+#if defined(__HIPCC__)
+
+// One wavefront (64 lanes on gfx950). Lanes run in lockstep; sync() only has to order LDS traffic.
+struct WaveGroup {
+    __device__ inline int tid() const { return (int)(threadIdx.x & 63u); }
+    __device__ inline int size() const { return 64; }
+    __device__ inline void sync() const {
+        // Workgroup-scope fence: waits for this wave's outstanding LDS/global operations (all waves of a
+        // workgroup share one CU and its L1, so no cache maintenance is involved) and pins the compiler's ordering.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ inline int min_i32(int v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+        return v;
+    }
+    __device__ inline int max_i32(int v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+        return v;
+    }
+    __device__ inline int sum_i32(int v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ inline bool any(bool p) const { return __ballot(p) != 0ull; }
+    __device__ inline int bcast_i32(int v, int src) const { return __shfl(v, src, 64); }
+    __device__ inline int exscan_i32(int v, int* total) const {
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(x, o, 64); if (tid() >= o) x += t; }
+        *total = __shfl(x, 63, 64);
+        return x - v;
+    }
+};
+
+// One workgroup. `scratch` points at >= 40 ints of LDS reserved for the reductions.
+struct BlockGroup {
+    int* scratch;
+    __device__ inline explicit BlockGroup(int* s) : scratch(s) {}
+    __device__ inline int tid() const { return (int)threadIdx.x; }
+    __device__ inline int size() const { return (int)blockDim.x; }
+    __device__ inline void sync() const { __syncthreads(); }
+    __device__ inline int nwaves() const { return ((int)blockDim.x + 63) >> 6; }
+    template <class Op> __device__ inline int reduce(int v, Op op, int identity) const {
+        WaveGroup w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = op(v, t); }
+        __syncthreads();   // protect scratch against the previous reduction's readers
+        if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = v;
+        __syncthreads();
+        int r = identity;
+        int nw = nwaves();
+        for (int i = 0; i < nw; i++) r = op(r, scratch[i]);
+        (void)w;
+        return r;
+    }
+    __device__ inline int min_i32(int v) const { return reduce(v, [](int a, int b) { return a < b ? a : b; }, 0x7fffffff); }
+    __device__ inline int max_i32(int v) const { return reduce(v, [](int a, int b) { return a > b ? a : b; }, (int)0x80000000); }
+    __device__ inline int sum_i32(int v) const { return reduce(v, [](int a, int b) { return a + b; }, 0); }
+    __device__ inline bool any(bool p) const { return __syncthreads_or(p ? 1 : 0) != 0; }
+    __device__ inline int bcast_i32(int v, int src) const {
+        __syncthreads();
+        if ((int)threadIdx.x == src) scratch[32] = v;
+        __syncthreads();
+        return scratch[32];
+    }
+    __device__ inline int exscan_i32(int v, int* total) const {
+        WaveGroup w;
+        int wt;
+        int x = w.exscan_i32(v, &wt);
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 63u) scratch[threadIdx.x >> 6] = wt;
+        __syncthreads();
+        int base = 0, tot = 0, nw = nwaves(), me = (int)(threadIdx.x >> 6);
+        for (int i = 0; i < nw; i++) { int s = scratch[i]; if (i < me) base += s; tot += s; }
+        *total = tot;
+        return base + x;
+    }
+};
+
+#endif  // __HIPCC__
+
+}  // namespace ambi

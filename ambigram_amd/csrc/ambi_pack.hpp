@@ -1,0 +1,37 @@
+// ambi_pack.hpp -- host-side packing of units into the flat batch layout (ambi_batch.hpp).
+// Pure host C++ (no HIP): shared by the HIP engine (ambi_engine.hip) and the CPU host simulation.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "ambi_batch.hpp"
+#include "lh_graph.hpp"
+
+namespace ambi {
+
+constexpr int kPathCapLimit = 65536;   // cells; the finish kernel keeps the path in LDS as int16
+constexpr int kDefaultIdealCap = 4096; // slots per unit (holds up to 2048 order ideals)
+
+struct HostBatch {
+    std::vector<UnitIn> units;
+    std::vector<double> seg_cn;
+    std::vector<Junction> juncs;
+    std::vector<Element> elems;
+    std::vector<int64_t> scratch_off;       // per unit, ints
+    std::vector<std::vector<int32_t>> junc_global;   // per unit: local junction index -> index in the sample's graph
+    int64_t result_bytes = 0, ideal_slots = 0, scratch_ints = 0;
+    int max_n = 0, max_m = 0, max_k = 0, max_bkp = 0, max_path = 0, max_out = 0;
+    int ideal_cap = kDefaultIdealCap;
+
+    // Raw unit: local ids 1..n_seg, junctions already restricted to the unit.  Returns unit index or negative Status.
+    int add_unit(int n_seg, int seg_base, const double* cn_local /*[n_seg], id 1 first*/, int n_junc, const int32_t* j_src,
+                 const int32_t* j_tgt, const int8_t* j_sdir, const int8_t* j_tdir, const double* j_cn, int n_elem,
+                 const int32_t* e_is_loop, const int32_t* e_a, const int32_t* e_b, const int32_t* e_cn, int infeasible,
+                 int has_components);
+    // One chromosome of a parsed .lh plus the .sol columns of that chromosome (localhap.cpp:111-232).
+    int add_graph_chr(const LhGraph& g, int chr, const SolFile* sol);
+    void finalize();                          // computes result/ideal/scratch offsets
+    int64_t header_bytes() const { return int64_t(sizeof(UnitOut)) * (int64_t)units.size(); }
+};
+
+}  // namespace ambi

@@ -1,0 +1,380 @@
+// ambi_stages.hpp -- the per-unit stages of the reconstruction pipeline as SPMD functions over a thread group.
+// The HIP kernels (ambi_kernels.hip) are thin wrappers that carve the work areas out of LDS and call these;
+// the host simulation (tests/hostsim) calls the same functions with HostGroup and plain heap memory.
+//
+// Pipeline of one unit (reference: localhap.cpp:111-265):
+//   stage_prepare   getJuncCN, bias, getIndelBias, no-FBI shortcut, targetCN, constructDAG, ideal lattice + R
+//   (plan)          order-table offsets / work blocks over the whole batch
+//   stage_enumerate block of consecutive topological orders -> R x K uint8 table
+//   stage_first     sequential scan for the first valid order (forward pass, then the flipped orientation)
+//   stage_finish    bkp -> path, indelBFB, output junctions
+#pragma once
+#include "ambi_batch.hpp"
+#include "ambi_eval.hpp"
+#include "ambi_finish.hpp"
+#include "ambi_orders.hpp"
+#include "ambi_prepare.hpp"
+
+namespace ambi {
+
+// ---------------------------------------------------------------------------------------------
+// stage_prepare
+// ---------------------------------------------------------------------------------------------
+struct PrepareWork {      // group-local memory (LDS on the GPU)
+    Junction* juncs;      // [m]
+    double* seg_cn;       // [n+1]
+    double* junc_cn;      // [2(n+1)]
+    int32_t* inv_junc;    // [n+1]
+    int32_t* target_cn;   // [n+1]
+    Element* elems;       // [K]
+    Dag* dag;
+};
+AMBI_HD int64_t prepare_work_bytes(int n, int m, int K) {
+    return pad8(int64_t(sizeof(Junction)) * m) + pad8(8ll * (n + 1)) + pad8(16ll * (n + 1)) + pad8(4ll * (n + 1)) +
+           pad8(4ll * (n + 1)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(sizeof(Dag));
+}
+AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
+    PrepareWork W;
+    int64_t o = 0;
+    W.juncs = reinterpret_cast<Junction*>(base + o); o += pad8(int64_t(sizeof(Junction)) * m);
+    W.seg_cn = reinterpret_cast<double*>(base + o); o += pad8(8ll * (n + 1));
+    W.junc_cn = reinterpret_cast<double*>(base + o); o += pad8(16ll * (n + 1));
+    W.inv_junc = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
+    W.target_cn = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
+    W.elems = reinterpret_cast<Element*>(base + o); o += pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
+    W.dag = reinterpret_cast<Dag*>(base + o);
+    return W;
+}
+
+template <class G, class T>
+AMBI_HD void copy_words(const G& g, T* dst, const T* src, int64_t count) {
+    for (int64_t i = g.tid(); i < count; i += g.size()) dst[i] = src[i];
+}
+
+AMBI_HD IdealTable unit_ideal_table(const BatchArgs& A, int u) {
+    const UnitIn& U = A.units[u];
+    IdealTable T;
+    T.keys = A.ideal_keys + U.ideal_off;
+    T.cnt = A.ideal_cnt + U.ideal_off;
+    T.lvl = A.ideal_lvl + U.ideal_off / 2;
+    T.lvl_off = A.ideal_lvl_off + int64_t(u) * (kMaxNodes + 3);
+    T.counter = A.ideal_counter + u;
+    T.cap = U.ideal_cap;
+    return T;
+}
+
+template <class G>
+AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
+    PrepareWork W = carve_prepare(work, n, m, K);
+    uint8_t* res = A.results + U.res_off;
+    const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
+    UnitOut* out = unit_out(A.results, u);
+
+    // coalesced staging of the unit's records (as 32-bit words) into the group's memory
+    copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
+               int64_t(sizeof(Junction) / 4) * m);
+    copy_words(g, reinterpret_cast<uint32_t*>(W.seg_cn), reinterpret_cast<const uint32_t*>(A.seg_cn + U.seg_off),
+               2ll * (n + 1));
+    copy_words(g, reinterpret_cast<uint32_t*>(W.elems), reinterpret_cast<const uint32_t*>(A.elems + U.elem_off),
+               int64_t(sizeof(Element) / 4) * K);
+    for (int i = g.tid(); i <= n; i += g.size()) W.target_cn[i] = 0;
+    g.sync();
+
+    int status = ST_OK, bias = 1;
+    double inv_sum = 0;
+    if (g.tid() == 0) {
+        get_junc_cn(n, W.juncs, m, W.junc_cn, W.inv_junc);
+        bias = compute_bias(n, W.juncs, W.junc_cn, W.inv_junc);
+        int32_t* sv = A.scratch_i32 + A.scratch_off[u];
+        get_indel_bias(n, W.juncs, m, W.seg_cn, sv, sv + m);
+        inv_sum = inversion_cn_sum(n, W.junc_cn);
+        double a = inv_sum < 0 ? -inv_sum : inv_sum;
+        if (a < 0.000001 && !U.has_components) status = ST_SHORTCUT;   // localhap.cpp:164
+        else if (U.infeasible) status = ST_INFEASIBLE;               // localhap.cpp:213
+        else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
+        else {
+            add_target_cn(W.elems, K, n, W.target_cn);
+            status = construct_dag(W.elems, K, U.seg_base, *W.dag);
+        }
+    }
+    status = g.bcast_i32(status, 0);
+    g.sync();
+
+    uint64_t R = 0;
+    if (status == ST_OK) {
+        IdealTable T = unit_ideal_table(A, u);
+        int st = ideal_build_and_count(g, W.dag->pred, K, T, &R);
+        if (st != ST_OK) status = st;
+    }
+
+    // results: junc_cn, seg_cn (after indel bias), target_cn, fold-back map
+    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.junc_cn), reinterpret_cast<const uint32_t*>(W.junc_cn), 4ll * (n + 1));
+    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.seg_cn), reinterpret_cast<const uint32_t*>(W.seg_cn), 2ll * (n + 1));
+    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.target_cn), reinterpret_cast<const uint32_t*>(W.target_cn), int64_t(n + 1));
+    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.inv_junc), reinterpret_cast<const uint32_t*>(W.inv_junc), int64_t(n + 1));
+    {
+        int16_t* isrc = reinterpret_cast<int16_t*>(res + Lay.inv_src);
+        int16_t* itgt = reinterpret_cast<int16_t*>(res + Lay.inv_tgt);
+        for (int i = g.tid(); i <= n; i += g.size()) {
+            int ji = W.inv_junc[i];
+            isrc[i] = (int16_t)(ji >= 0 ? W.juncs[ji].src : 0);
+            itgt[i] = (int16_t)(ji >= 0 ? W.juncs[ji].tgt : 0);
+        }
+    }
+    if (status == ST_OK || status == ST_ERR_IDEALS_CAPACITY)
+        copy_words(g, reinterpret_cast<uint32_t*>(A.dags + u), reinterpret_cast<const uint32_t*>(W.dag), int64_t(sizeof(Dag) / 4));
+    if (g.tid() == 0) {
+        out->status = status;
+        out->bias = bias;
+        out->K = K;
+        out->bkp_len = 0; out->path_len = 0; out->path_indel_len = 0; out->indel_printed = 0; out->n_out_junc = 0;
+        out->first_forward = -1; out->evaluated = 0;
+        out->num_orders = (int64_t)R;
+        out->first_valid = -1;
+        out->order_off = -1;
+        out->inv_cn_sum = inv_sum;
+    }
+    g.sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan: order-table offsets + enumerate work blocks (one thread block for the whole batch)
+// ---------------------------------------------------------------------------------------------
+AMBI_HD int rows_per_lane_for(int K, int tile_bytes) {
+    int t = tile_bytes / (64 * (K > 0 ? K : 1));
+    if (t < 1) t = 1;
+    if (t > 64) t = 64;
+    return t;
+}
+
+// serial reference form (used by the host simulation and, with one thread, by the plan kernel's tail)
+AMBI_HD void plan_serial(const BatchArgs& A) {
+    int64_t off = 0, blk = 0;
+    for (int u = 0; u < A.n_units; u++) {
+        UnitOut* out = unit_out(A.results, u);
+        A.blk_off[u] = blk;
+        A.rows_per_lane[u] = 1;
+        if (out->status != ST_OK) continue;
+        const int K = out->K;
+        const int64_t R = out->num_orders;
+        int64_t bytes = (R * K + 15) & ~int64_t(15);
+        if (R >= (int64_t)kCountSat) { out->status = ST_ERR_ORDERS_CAPACITY; continue; }
+        // plain prefix sum: a unit that does not fit still advances the offset (so orders_needed is the true total)
+        if (off + bytes > A.order_arena_bytes) { out->status = ST_ERR_ORDERS_CAPACITY; off += bytes; continue; }
+        out->order_off = off;
+        off += bytes;
+        int T = rows_per_lane_for(K, A.tile_bytes);
+        A.rows_per_lane[u] = T;
+        blk += (R + 64ll * T - 1) / (64ll * T);
+    }
+    A.blk_off[A.n_units] = blk;
+    *A.orders_needed = off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage_enumerate: one work block = 64*T consecutive ranks of one unit, handled by one wave-sized group.
+// tile: [64*T*K] bytes of group memory laid out exactly like the destination rows; ord: [64][64] bytes;
+// pred: [64] masks.  `lane` / `nlanes`: the caller maps threads to lanes (HostGroup loops over all 64).
+// ---------------------------------------------------------------------------------------------
+AMBI_HD void enumerate_lane(const uint64_t* pred, int K, const IdealTable& T, int64_t R, int64_t first_rank, int rows,
+                            uint8_t* ord, int ord_stride, uint8_t* tile_rows) {
+    // rows consecutive orders starting at first_rank -> tile_rows[r*K + d]
+    if (first_rank >= R) return;
+    if (!order_unrank(pred, K, T, (uint64_t)first_rank, ord, ord_stride)) return;
+    for (int r = 0; r < rows; r++) {
+        if (first_rank + r >= R) break;
+        for (int d = 0; d < K; d++) tile_rows[r * K + d] = ord[d * ord_stride];
+        if (r + 1 < rows && first_rank + r + 1 < R) order_next(pred, K, ord, ord_stride);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage_first: sequential scan for the first valid order (LGM.cpp:3519-3696 control flow)
+// ---------------------------------------------------------------------------------------------
+struct FirstWork {
+    cell_t* bkp;        // [bkp_cap]
+    int16_t* inv_src;   // [n+1]
+    int16_t* inv_tgt;   // [n+1]
+    Dag* dag;
+    uint8_t* ord;       // [64]
+};
+AMBI_HD int64_t first_work_bytes(int n, int bkp_cap) {
+    return pad8(2ll * bkp_cap) + 2 * pad8(2ll * (n + 1)) + pad8(sizeof(Dag)) + 64;
+}
+AMBI_HD FirstWork carve_first(uint8_t* base, int n, int bkp_cap) {
+    FirstWork W;
+    int64_t o = 0;
+    W.bkp = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * bkp_cap);
+    W.inv_src = reinterpret_cast<int16_t*>(base + o); o += pad8(2ll * (n + 1));
+    W.inv_tgt = reinterpret_cast<int16_t*>(base + o); o += pad8(2ll * (n + 1));
+    W.dag = reinterpret_cast<Dag*>(base + o); o += pad8(sizeof(Dag));
+    W.ord = base + o;
+    return W;
+}
+
+template <class G>
+AMBI_HD void load_first_work(const G& g, const BatchArgs& A, int u, const FirstWork& W) {
+    const UnitIn& U = A.units[u];
+    const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    uint8_t* res = A.results + U.res_off;
+    copy_words(g, reinterpret_cast<uint32_t*>(W.dag), reinterpret_cast<const uint32_t*>(A.dags + u), int64_t(sizeof(Dag) / 4));
+    copy_words(g, W.inv_src, reinterpret_cast<const int16_t*>(res + Lay.inv_src), int64_t(U.n_seg + 1));
+    copy_words(g, W.inv_tgt, reinterpret_cast<const int16_t*>(res + Lay.inv_tgt), int64_t(U.n_seg + 1));
+    g.sync();
+}
+
+template <class G>
+AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    UnitOut* out = unit_out(A.results, u);
+    if (out->status != ST_OK) return;
+    const UnitIn U = A.units[u];
+    FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+    load_first_work(g, A, u, W);
+    const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    uint8_t* res = A.results + U.res_off;
+    const int K = out->K;
+    const int64_t R = out->num_orders;
+    const uint8_t* rows = A.order_arena + out->order_off;
+    InvMap inv{W.inv_src, W.inv_tgt};
+    const bool isReversed = (A.flags & FLAG_REVERSED) != 0;
+    bool forwardDir = !isReversed;
+    int status = ST_NO_VALID_ORDER;
+    int64_t found = -1;
+    int found_fwd = -1, L = 0;
+    int64_t evaluated = 0;
+    for (int pass = 0; pass < 2 && found < 0; pass++) {
+        int64_t lim = R < A.first_budget ? R : A.first_budget;
+        for (int64_t nidx = 0; nidx < lim; nidx++) {
+            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * K + d];
+            g.sync();
+            int Lo = 0;
+            int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo);
+            evaluated++;
+            if (v < 0) { status = v; found = -2; break; }
+            if (v == 1) { found = nidx; found_fwd = forwardDir ? 1 : 0; L = Lo; status = ST_OK; break; }
+        }
+        if (found == -2) break;
+        if (found < 0) {
+            if (lim < R) { status = ST_PENDING; break; }   // budget exhausted: parallel search takes over
+            forwardDir = !forwardDir;                       // LGM.cpp:3691-3695 (the last order was invalid)
+        }
+    }
+    if (status == ST_OK) {
+        cell_t* dst = reinterpret_cast<cell_t*>(res + Lay.bkp);
+        for (int i = g.tid(); i < L; i += g.size()) dst[i] = W.bkp[i];
+    }
+    if (g.tid() == 0) {
+        out->status = status;
+        if (status == ST_OK) {
+            out->first_valid = found; out->first_forward = found_fwd; out->bkp_len = L;
+        }
+        out->evaluated = (int32_t)evaluated;
+        if (status == ST_PENDING) atomic_add_i32(A.n_pending, 1);
+    }
+    g.sync();
+}
+
+// Parallel search support: evaluate ONE order of a unit; returns 1/0/negative.  `work` as in stage_first
+// (already loaded with load_first_work).
+template <class G>
+AMBI_HD int eval_indexed(const G& g, const BatchArgs& A, int u, const FirstWork& W, int64_t nidx, bool forwardDir, int* L) {
+    UnitOut* out = unit_out(A.results, u);
+    const UnitIn& U = A.units[u];
+    const int K = out->K;
+    const uint8_t* rows = A.order_arena + out->order_off;
+    for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * K + d];
+    g.sync();
+    InvMap inv{W.inv_src, W.inv_tgt};
+    return eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage_finish: bkp -> path (LGM.cpp:3661-3670), indelBFB (:3746-3837), output junctions (localhap.cpp:267-289)
+// ---------------------------------------------------------------------------------------------
+struct FinishWork {
+    cell_t* path;       // [path_cap]
+    cell_t* bkp;        // [bkp_cap]
+    int32_t* offs;      // [bkp_cap/2 + 2]
+    Junction* juncs;    // [m]
+    int32_t* sv;        // [m]
+    int32_t* grp;       // [2m+4]
+    int32_t* cand;      // [out_cap + bkp_cap]  candidate junction steps
+    uint8_t* taken;     // [m]
+};
+AMBI_HD int64_t finish_work_bytes(int m, int bkp_cap, int path_cap, int out_cap) {
+    return pad8(2ll * path_cap) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(Junction)) * m) +
+           pad8(4ll * m) + pad8(4ll * (2 * m + 4)) + pad8(4ll * (out_cap + bkp_cap)) + pad8(m);
+}
+AMBI_HD FinishWork carve_finish(uint8_t* base, int m, int bkp_cap, int path_cap, int out_cap) {
+    FinishWork W;
+    int64_t o = 0;
+    W.path = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * path_cap);
+    W.bkp = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * bkp_cap);
+    W.offs = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (bkp_cap / 2 + 2));
+    W.juncs = reinterpret_cast<Junction*>(base + o); o += pad8(int64_t(sizeof(Junction)) * m);
+    W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.grp = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * m + 4));
+    W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (out_cap + bkp_cap));
+    W.taken = base + o;
+    return W;
+}
+
+template <class G>
+AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    UnitOut* out = unit_out(A.results, u);
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc;
+    const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
+    uint8_t* res = A.results + U.res_off;
+    int32_t* gpath = reinterpret_cast<int32_t*>(res + Lay.path);
+    int32_t* gpath2 = reinterpret_cast<int32_t*>(res + Lay.path_ind);
+    OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
+    const int base = U.seg_base;
+    const int status = out->status;
+    if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
+        // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
+        int P = n <= U.path_cap ? n : U.path_cap;
+        for (int i = g.tid(); i < P; i += g.size()) { gpath[i] = i + 1 + base; gpath2[i] = i + 1 + base; }
+        if (g.tid() == 0) {
+            out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0;
+            if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
+        }
+        g.sync();
+        return;
+    }
+    if (status != ST_OK) return;
+    FinishWork W = carve_finish(work, m, U.bkp_cap, U.path_cap, U.out_cap);
+    const int L = out->bkp_len;
+    copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
+    copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
+               int64_t(sizeof(Junction) / 4) * m);
+    g.sync();
+    int P = expand_bkp(g, W.bkp, L, W.path, U.path_cap, W.offs);
+    if (P < 0) { if (g.tid() == 0) out->status = P; g.sync(); return; }
+    for (int i = g.tid(); i < P; i += g.size()) { int v = W.path[i]; gpath[i] = v > 0 ? v + base : v - base; }
+    int P2 = P;
+    IndelScratch S{W.sv, W.taken, W.grp};
+    int printed = indel_bfb(g, n, W.juncs, m, W.path, &P2, U.path_cap, S);
+    if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
+    for (int i = g.tid(); i < P2; i += g.size()) { int v = W.path[i]; gpath2[i] = v > 0 ? v + base : v - base; }
+    // output junctions of the final path; records are produced in LDS-free form straight into the blob
+    int nout = synth_out_juncs(g, W.path, P2, gout, U.out_cap, W.cand, U.out_cap + U.bkp_cap);
+    if (nout >= 0) {
+        g.sync();
+        for (int k = g.tid(); k < nout; k += g.size()) {
+            int a = gout[k].u, b = gout[k].v;
+            gout[k].u = a > 0 ? a + base : a - base;
+            gout[k].v = b > 0 ? b + base : b - base;
+        }
+    }
+    if (g.tid() == 0) {
+        out->path_len = P; out->path_indel_len = P2; out->indel_printed = printed;
+        out->n_out_junc = nout >= 0 ? nout : 0;
+        if (nout < 0) out->status = nout;
+    }
+    g.sync();
+}
+
+}  // namespace ambi

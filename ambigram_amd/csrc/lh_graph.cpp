@@ -1,0 +1,423 @@
+// lh_graph.cpp -- host-side readers/writers around the BFB path (see lh_graph.hpp).
+#include "lh_graph.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace ambi {
+
+const char* lh_error_string(int code) {
+    switch (code) {
+        case LH_OK: return "ok";
+        case LH_ERR_OPEN: return "Cannot open file";
+        case LH_ERR_MALFORMED: return "malformed .lh line (missing column)";
+        case LH_ERR_UNKNOWN_SEG: return "junction or SOURCE/SINK refers to an unknown segment";
+        case LH_ERR_SOURCE_SINK: return "SOURCE and SINK lists differ in length";
+        case LH_ERR_PLOIDY: return "input error: ploidy / purity information missing";
+        case LH_ERR_SEG_IDS: return "segment ids must be 1..N in file order";
+        case LH_ERR_SOL_OPEN: return "ILP error: cannot open file";
+        case LH_ERR_LINE_TOO_LONG: return "line longer than 8191 bytes";
+        case LH_ERR_UNSUPPORTED: return "TRX-BFB modes (PROP I1/C1) are not supported";
+        default: return "unknown error";
+    }
+}
+
+// ---- tokenizer with strtok's rules (skip leading delimiters, cut at the next one) but local state ----
+namespace {
+struct Cutter {
+    char* p;
+    explicit Cutter(char* s) : p(s) {}
+    char* next(const char* delims) {
+        if (!p) return nullptr;
+        while (*p && strchr(delims, *p)) p++;
+        if (!*p) { p = nullptr; return nullptr; }
+        char* tok = p;
+        while (*p && !strchr(delims, *p)) p++;
+        if (*p) { *p = '\0'; p++; } else p = nullptr;
+        return tok;
+    }
+};
+std::string dtoa(double v) { std::ostringstream o; o << v; return o.str(); }   // what `cout << double` prints
+bool same_edges(int s1, int sd1, int t1, int td1, int s2, int sd2, int t2, int td2) {
+    // Graph.cpp:489-499 compares the printed forms of edge A and edge B
+    int a1 = sd1 > 0 ? s1 : -s1, b1 = td1 > 0 ? t1 : -t1;
+    int a2 = sd2 > 0 ? s2 : -s2, b2 = td2 > 0 ? t2 : -t2;
+    return (a1 == a2 && b1 == b2) || (a1 == -b2 && b1 == -a2);
+}
+}  // namespace
+
+int LhGraph::find_junction(int src, int sdir, int tgt, int tdir) const {
+    for (int i = 0; i < n_junc(); i++)
+        if (same_edges(j_src[i], j_sdir[i], j_tgt[i], j_tdir[i], src, sdir, tgt, tdir)) return i;
+    return -1;
+}
+
+bool LhGraph::add_junction(int src, int sdir, int tgt, int tdir, double cov, double cn, bool inferred, bool bounded) {
+    bool hs = false, ht = false;
+    for (int id : seg_id) { hs |= (id == src); ht |= (id == tgt); }
+    if (!hs || !ht) return false;
+    if (find_junction(src, sdir, tgt, tdir) >= 0) return true;   // duplicate: ignored (Graph.cpp:592-595)
+    j_src.push_back(src); j_tgt.push_back(tgt); j_sdir.push_back((int8_t)sdir); j_tdir.push_back((int8_t)tdir);
+    j_cov.push_back(cov); j_cn.push_back(cn); j_inferred.push_back(inferred); j_bounded.push_back(bounded);
+    return true;
+}
+
+static int hap_depth(LhGraph& g) {   // Graph.cpp:312-367
+    if (g.avg_ploidy < 0) {
+        if (g.avg_tumor_ploidy < 0 || g.purity < 0) return LH_ERR_PLOIDY;
+        g.avg_ploidy = g.purity * g.avg_tumor_ploidy + (1 - g.purity) * 2;
+    } else if (g.avg_tumor_ploidy >= 0) {
+        if (g.purity < 0) g.log.push_back("WARN: no purity information provided, use the given AVG_PLOIDY");
+        else {
+            double pt = g.purity * g.avg_tumor_ploidy;
+            g.ratio = 1 - pt / (pt + (1 - g.purity) * 2);
+            g.ratio_set = true;
+            double ap = g.purity * g.avg_tumor_ploidy + (1 - g.purity) * 2;
+            if (!(std::abs(g.avg_ploidy - ap) <= 0.1)) g.avg_ploidy = ap;
+        }
+    } else {
+        g.log.push_back("WARN: only AVG_PLOIDY is given, use that");
+    }
+    g.haploid_depth = g.avg_cov_raw * g.purity / g.avg_ploidy;
+    g.avg_coverage = g.avg_ploidy * g.haploid_depth;
+    g.avg_cov_junc = g.avg_ploidy * g.haploid_depth;
+    return LH_OK;
+}
+
+static void copy_num(LhGraph& g) {   // Graph.cpp:369-405: only entries with CN <= 0 are (re)computed
+    for (int i = 0; i < g.n_seg(); i++) {
+        if (g.seg_cn[i] > 0) continue;
+        double c;
+        if (g.seg_id[i] >= g.virus_seg_start) c = g.seg_cov[i] / g.avg_cov_raw * 2;
+        else c = (g.seg_cov[i] - g.avg_cov_raw * g.ratio) / g.haploid_depth;
+        g.seg_cn[i] = std::max(c, 0.0);
+        g.log.push_back("SEG" + std::to_string(g.seg_id[i]) + " " + dtoa(g.seg_cov[i]) + " " + dtoa(g.seg_cn[i]));
+    }
+    for (int i = 0; i < g.n_junc(); i++) {
+        if (g.j_cn[i] > 0) continue;
+        if (g.j_inferred[i]) g.log.push_back(dtoa(g.haploid_depth));
+        g.j_cn[i] = std::max((g.j_cov[i] - g.avg_cov_raw * g.ratio) / g.haploid_depth, 0.0);
+    }
+}
+
+static void read_props(const std::string& path, LhGraph& g) {   // LGM.cpp:3941-3987
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream ss(line);
+        std::string w;
+        if (!(ss >> w) || w != "PROP") continue;
+        while (ss >> w) {
+            auto fields = [&](size_t from, std::vector<std::string>& out) {
+                size_t last = from;
+                while (true) {
+                    size_t pos = w.find(':', last);
+                    out.push_back(w.substr(last, pos == std::string::npos ? std::string::npos : pos - last));
+                    if (pos == std::string::npos) break;
+                    last = pos + 1;
+                }
+            };
+            if (w[0] == 'M') g.main_chr = w.size() > 2 ? w.substr(2) : "";
+            else if (w[0] == 'I') {
+                size_t from = 2;
+                if (w.size() > 1 && w[1] != ':') { g.ins_mode = w[1] - '0'; from = 3; } else g.ins_mode = 2;
+                fields(from, g.ins_chr);
+            } else if (w[0] == 'C') {
+                size_t from = 2;
+                if (w.size() > 1 && w[1] != ':') { g.con_mode = w[1] - '0'; from = 3; } else g.con_mode = 2;
+                fields(from, g.con_chr);
+            } else if (w[0] == 'S') {
+                std::vector<std::string> t;
+                fields(2, t);
+                for (auto& x : t) g.start_segs.push_back(atoi(x.c_str()));
+            }
+        }
+    }
+}
+
+int read_lh(const std::string& path, LhGraph& g) {
+    std::ifstream f(path);
+    if (!f) return LH_ERR_OPEN;
+    g.log.push_back("Reading graph...");
+    std::string raw;
+    bool more = true;
+    while (more) {
+        // the reference loops `while(!eof) getline(buf, 8192)`: a final line without '\n' is still processed,
+        // and a trailing '\n' yields one last empty line
+        if (!std::getline(f, raw)) { more = false; if (f.eof() && raw.empty()) { /* one empty line */ } }
+        if (raw.size() > 8191) return LH_ERR_LINE_TOO_LONG;
+        std::vector<char> buf(raw.begin(), raw.end());
+        buf.push_back('\0');
+        raw.clear();
+        char* line = buf.data();
+        const char* q = line;
+        while (*q == ' ' || *q == '\t') q++;
+        if (*q == '#') continue;
+        Cutter c(line);
+        char* key = c.next(" \t");
+        if (!key) continue;
+        auto need = [&](const char* d) -> char* { return c.next(d); };
+        if (!strcmp(key, "SAMPLE_NAME")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.sample_name = t; }
+        else if (!strcmp(key, "AVG_CHR_SEG_DP")) {
+            char* t = need(" ");
+            if (t) { Cutter s(t); while (char* x = s.next(",")) g.avg_coverages.push_back(atof(x)); }
+        }
+        else if (!strcmp(key, "AVG_WHOLE_HOST_DP")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.avg_cov_raw = atof(t); }
+        else if (!strcmp(key, "AVG_VIRUS_SEG_DP")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.avg_virus_dp = atof(t); }
+        else if (!strcmp(key, "VIRUS_START")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.virus_seg_start = atoi(t); g.virus_seg_start_set = true; }
+        else if (!strcmp(key, "AVG_JUNC_DP")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.avg_cov_junc = atof(t); }
+        else if (!strcmp(key, "PURITY")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.purity = atof(t); }
+        else if (!strcmp(key, "AVG_TUMOR_PLOIDY")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.avg_tumor_ploidy = atof(t); }
+        else if (!strcmp(key, "AVG_PLOIDY")) { char* t = need(" "); if (!t) return LH_ERR_MALFORMED; g.avg_ploidy = atof(t); }
+        else if (!strcmp(key, "PLOIDY")) {
+            char* t = need(" "); if (!t) return LH_ERR_MALFORMED;
+            g.ploidy = t;
+            Cutter s(t); char* x = s.next("m"); if (!x) return LH_ERR_MALFORMED;
+            g.expected_ploidy = atoi(x);
+        }
+        else if (!strcmp(key, "SOURCE") || !strcmp(key, "SINK")) {
+            std::vector<int32_t>& dst = key[1] == 'O' ? g.source_ids : g.sink_ids;
+            char* t = need(" ");
+            if (t) { Cutter s(t); while (char* x = s.next(",")) dst.push_back(atoi(x)); }
+        }
+        else if (!strcmp(key, "SEG")) {
+            char* node = need(" "); char* cov = need(" "); char* cn = need(" ");
+            if (!node || !cov || !cn) return LH_ERR_MALFORMED;
+            Cutter s(node);
+            char* h = s.next(":"); char* id = s.next(":"); char* chrom = s.next(":"); char* st = s.next(":"); char* en = s.next(":");
+            if (!h || !id || !chrom || !st || !en) return LH_ERR_MALFORMED;
+            int sid = atoi(id);
+            int chr = -1;   // uninitialised in the reference when no SOURCE/SINK range matches
+            for (size_t i = 0; i < g.source_ids.size() && i < g.sink_ids.size(); i++)
+                if (g.source_ids[i] <= sid && sid <= g.sink_ids[i]) chr = (int)i;
+            g.seg_id.push_back(sid); g.seg_chr.push_back(chr); g.seg_chrom.push_back(chrom);
+            g.seg_start.push_back(atoi(st)); g.seg_end.push_back(atoi(en));
+            g.seg_cov.push_back(std::max(atof(cov), 0.0)); g.seg_cn.push_back(atof(cn));
+            g.seg_partition.push_back(0);
+        }
+        else if (!strcmp(key, "JUNC")) {
+            char* sn = need(" "); char* tn = need(" "); char* cov = need(" "); char* cn = need(" ");
+            char* inf = need(" "); char* bnd = need(" ");
+            if (!sn || !tn || !cov || !cn || !inf || !bnd) return LH_ERR_MALFORMED;
+            double jc = atof(cov), jn = atof(cn);
+            if (jc <= 0 && jn <= 0) continue;   // Graph.cpp:211
+            Cutter a(sn); char* h1 = a.next(":"); char* sid = a.next(":"); char* sd = a.next(":");
+            Cutter b(tn); char* h2 = b.next(":"); char* tid = b.next(":"); char* td = b.next(":");
+            if (!h1 || !sid || !sd || !h2 || !tid || !td) return LH_ERR_MALFORMED;
+            if (!g.add_junction(atoi(sid), sd[0] == '+' ? 1 : -1, atoi(tid), td[0] == '+' ? 1 : -1, jc, jn, inf[0] == 'I', bnd[0] == 'B'))
+                return LH_ERR_UNKNOWN_SEG;
+        }
+    }
+    if (g.source_ids.size() != g.sink_ids.size()) return LH_ERR_SOURCE_SINK;
+    for (int i = 0; i < g.n_seg(); i++) if (g.seg_id[i] != i + 1) return LH_ERR_SEG_IDS;
+    for (size_t i = 0; i < g.source_ids.size(); i++) {
+        if (g.source_ids[i] < 1 || g.source_ids[i] > g.n_seg() || g.sink_ids[i] < 1 || g.sink_ids[i] > g.n_seg()) return LH_ERR_UNKNOWN_SEG;
+    }
+    int rc = hap_depth(g);
+    if (rc != LH_OK) return rc;
+    copy_num(g);
+    read_props(path, g);
+    if (g.ins_mode == 1 || g.con_mode == 1) return LH_ERR_UNSUPPORTED;
+    set_partitions(g);
+    return LH_OK;
+}
+
+void set_partitions(LhGraph& g) {   // localhap.cpp:94-98
+    for (int c = 0; c < g.n_chr(); c++)
+        for (int j = g.source_ids[c]; j <= g.sink_ids[c]; j++)
+            if (j >= 1 && j <= g.n_seg()) g.seg_partition[j - 1] = c;
+}
+
+int read_juncs(LhGraph& g, const std::string& path) {   // LGM.cpp:5096-5156
+    if (path.empty()) return LH_OK;
+    std::ifstream f(path);
+    std::string line;
+    auto& res = g.components;
+    while (std::getline(f, line)) {
+        std::istringstream iss(line);
+        std::vector<int> ids; std::vector<char> sg; std::string w;
+        while (iss >> w) { ids.push_back(atoi(w.substr(0, w.size() - 1).c_str())); sg.push_back(w.back()); }
+        for (int id : ids) if (id < 1 || id > g.n_seg()) return LH_ERR_UNKNOWN_SEG;
+        size_t last = 0;
+        for (size_t i = 1; i < ids.size(); i++) {
+            if (g.seg_partition[ids[last] - 1] != g.seg_partition[ids[i] - 1] || sg[i - 1] != sg[i]) {
+                if (i - last >= 2) {
+                    std::vector<int32_t> sub(ids.begin() + last, ids.begin() + i);
+                    std::sort(sub.begin(), sub.end());
+                    res.push_back(sub);
+                }
+                int s = ids[i - 1], t = ids[i];
+                g.log.push_back(std::to_string(s) + sg[i - 1] + " -> " + std::to_string(t) + sg[i]);
+                int sd = sg[i - 1] == '+' ? 1 : -1, td = sg[i] == '+' ? 1 : -1;
+                int j = g.find_junction(s, sd, t, td);
+                if (j < 0) g.add_junction(s, sd, t, td, g.avg_coverage, 1, false, true);
+                else if (g.j_cn[j] < 2) g.j_cn[j] = 2;
+                last = i;
+            }
+        }
+        if (ids.size() >= last + 2) {
+            std::vector<int32_t> sub(ids.begin() + last, ids.end());
+            std::sort(sub.begin(), sub.end());
+            res.push_back(sub);
+        }
+    }
+    std::sort(res.begin(), res.end());
+    res.erase(std::unique(res.begin(), res.end()), res.end());
+    return LH_OK;
+}
+
+int read_sol(const std::string& path, SolFile& s) {   // localhap.cpp:184-212
+    std::ifstream f(path);
+    if (!f) return LH_ERR_SOL_OPEN;
+    std::string w, v;
+    while (f >> w) {
+        if (w == "Infeasible") { s.infeasible = true; break; }
+        if (w == "value") { double t = 0; f >> t; s.objective += t; }
+        if (w[0] == 'x') {
+            int x = atoi(w.c_str() + 1);
+            // the reference consumes the next token only for x < numComp; epsilon columns come after all element
+            // columns in CBC's listing and their value token never starts with 'x', so reading it here is equivalent
+            if (!(f >> v)) break;
+            s.col.push_back(x); s.val.push_back(atoi(v.c_str()));
+        }
+    }
+    return LH_OK;
+}
+
+std::string format_path(const LhGraph& g, const int32_t* path, int len) {   // LGM.cpp:3411-3429
+    std::string s;
+    auto tok = [](int v) { return std::to_string(v < 0 ? -v : v) + (v > 0 ? "+" : "-"); };
+    auto chr = [&](int v) { int id = v < 0 ? -v : v; return (id >= 1 && id <= g.n_seg()) ? g.seg_chr[id - 1] : -2; };
+    for (int i = 1; i < len; i++) {
+        s += tok(path[i - 1]);
+        if (chr(path[i - 1]) != chr(path[i])) s += "||";
+        else if ((path[i - 1] > 0) != (path[i] > 0)) s += "|";
+    }
+    if (len > 0) s += tok(path[len - 1]);
+    return s;
+}
+
+bool column_to_element(int col, int start_id, int end_id, int* is_loop, int* a, int* b) {
+    const int n = end_id - start_id + 1;
+    const int num_pat = n * (n + 1) / 2;
+    if (col < 0 || col >= 2 * num_pat) return false;
+    *is_loop = col >= num_pat;
+    int r = col % num_pat;
+    int da = 0;
+    while (r >= n - da) { r -= n - da; da++; }   // rows of the (a,b) triangle have n, n-1, ... entries
+    *a = start_id + da;
+    *b = *a + r;
+    return true;
+}
+
+void merge_out_junctions(std::vector<OutJunction>& out, const int32_t* p, int len, bool increase) {
+    for (int i = 0; i + 1 < len; i++) {
+        int u = p[i], v = p[i + 1];
+        int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+        int d = au - av; if (d < 0) d = -d;
+        if (d == 1 && ((u > 0) == (v > 0))) continue;
+        bool has = false;
+        for (auto& j : out)
+            if ((j.u == u && j.v == v) || (j.u == -v && j.v == -u)) { has = true; if (increase) j.count += 1; }
+        if (!has) out.push_back({u, v, 1});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BFB-TRX (PROP I2 / C2): stitch the per-chromosome paths along the inter-chromosomal junctions.
+// LGM.cpp:4052-4193.  Positions are plain indices; an index equal to the container size plays the role of end().
+// ------------------------------------------------------------------------------------------------------
+void translocation_bfb(const LhGraph& g, std::vector<std::vector<int32_t>>& paths, std::vector<int32_t>& res) {
+    auto chr_of = [&](int v) { return g.seg_chr[(v < 0 ? -v : v) - 1]; };
+    auto chrom_of = [&](int v) -> const std::string& { return g.seg_chrom[(v < 0 ? -v : v) - 1]; };
+    auto vsrc = [&](int j) { return g.j_sdir[j] > 0 ? g.j_src[j] : -g.j_src[j]; };   // edge A source / target
+    auto vtgt = [&](int j) { return g.j_tdir[j] > 0 ? g.j_tgt[j] : -g.j_tgt[j]; };
+    auto revcomp = [](std::vector<int32_t>& v) { std::reverse(v.begin(), v.end()); for (auto& x : v) x = -x; };
+    auto first_of = [](const std::vector<int32_t>& v, long from, int val) -> long {
+        for (long i = from < 0 ? 0 : from; i < (long)v.size(); i++) if (v[i] == val) return i;
+        return (long)v.size();
+    };
+    auto last_of = [](const std::vector<int32_t>& v, int val) -> long {
+        for (long i = (long)v.size() - 1; i >= 0; i--) if (v[i] == val) return i;
+        return -1;
+    };
+    std::vector<int> sv;
+    for (int j = 0; j < g.n_junc(); j++) if (chr_of(g.j_src[j]) != chr_of(g.j_tgt[j])) sv.push_back(j);
+    for (auto& p : paths) if (!p.empty() && chrom_of(p[0]) == g.main_chr) res.insert(res.end(), p.begin(), p.end());
+    long start_pos = 0;
+    while (!sv.empty()) {
+        std::vector<int32_t> grp;
+        for (size_t i = 0; i < sv.size(); i++) {
+            int j = sv[i];
+            if (chrom_of(g.j_src[j]) == g.main_chr) { grp = {vsrc(j), vtgt(j)}; sv.erase(sv.begin() + i); break; }
+            if (chrom_of(g.j_tgt[j]) == g.main_chr) { grp = {-vtgt(j), -vsrc(j)}; sv.erase(sv.begin() + i); break; }
+        }
+        if (grp.empty()) break;
+        for (long i = 0; i < (long)sv.size(); i++) {
+            int j = sv[i];
+            if (chr_of(grp.back()) == chr_of(vsrc(j))) { grp.push_back(vsrc(j)); grp.push_back(vtgt(j)); }
+            else if (chr_of(grp.back()) == chr_of(-vtgt(j))) { grp.push_back(-vtgt(j)); grp.push_back(-vsrc(j)); }
+            else continue;
+            sv.erase(sv.begin() + i);
+            i = -1;
+            if (chrom_of(grp.back()) == g.main_chr) break;
+        }
+        if (grp.size() == 2) {   // concatenation
+            long p1 = last_of(res, grp[0]);
+            if (p1 < 0) { revcomp(grp); p1 = last_of(res, grp[0]); }
+            if (p1 < 0) continue;
+            res.resize(p1 + 1);
+            int c = chr_of(grp[1]);
+            if (c < 0 || c >= (int)paths.size()) continue;
+            std::vector<int32_t>& pp = paths[c];
+            long p2 = first_of(pp, 0, grp[1]);
+            if (p2 == (long)pp.size()) { revcomp(pp); p2 = first_of(pp, 0, grp[1]); }
+            if (p2 == (long)pp.size()) continue;
+            res.insert(res.end(), pp.begin() + p2, pp.end());
+            start_pos = 0;
+        } else {   // insertion
+            if (std::abs(grp.front()) > std::abs(grp.back())) revcomp(grp);
+            struct Pos { int where; long idx; };   // where: -1 = res, else chromosome index
+            std::vector<Pos> pos;
+            auto locate = [&]() {
+                pos.clear();
+                long flag = first_of(res, start_pos, grp[0]);
+                pos.push_back({-1, flag});
+                if (flag != (long)res.size()) {
+                    for (size_t i = 1; i + 1 < grp.size(); i += 2) {
+                        int c = chr_of(grp[i]);
+                        std::vector<int32_t>& pp = paths[c];
+                        long a = first_of(pp, 0, grp[i]);
+                        if (a == (long)pp.size()) { revcomp(pp); a = first_of(pp, 0, grp[i]); }
+                        if (a == (long)pp.size()) break;
+                        pos.push_back({c, a});
+                        long b = last_of(pp, grp[i + 1]);
+                        if (b < 0 || a > b + 1) { revcomp(pp); b = last_of(pp, grp[i + 1]); }
+                        if (b < 0 || a > b + 1) break;
+                        pos.push_back({c, b});
+                    }
+                }
+                pos.push_back({-1, first_of(res, flag + 1, grp.back())});
+            };
+            locate();
+            if (pos.size() < grp.size() || pos.back().idx == (long)res.size()) { revcomp(grp); locate(); }
+            if (pos.size() < grp.size() || pos.back().idx == (long)res.size()) continue;
+            std::vector<int32_t> ins;
+            for (size_t i = 1; i + 1 < pos.size(); i += 2) {
+                const std::vector<int32_t>& pp = paths[pos[i].where];
+                if (pos[i].idx <= pos[i + 1].idx) ins.insert(ins.end(), pp.begin() + pos[i].idx, pp.begin() + pos[i + 1].idx + 1);
+            }
+            if (ins.empty()) continue;
+            long a = pos.front().idx + 1, b = pos.back().idx;
+            if (a <= b) res.erase(res.begin() + a, res.begin() + b);
+            res.insert(res.begin() + a, ins.begin(), ins.end());
+            start_pos = first_of(res, 0, ins.back());
+        }
+    }
+}
+
+}  // namespace ambi

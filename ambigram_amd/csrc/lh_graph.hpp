@@ -1,0 +1,91 @@
+// lh_graph.hpp -- host-side flat breakpoint-graph model and the text formats around the BFB path.
+//
+// Replaces the pointer graph of the reference (Graph/Segment/Vertex/Edge/Junction/Weight)
+// with SoA vectors: a vertex is a signed segment id, a junction is (src, sdir, tgt, tdir, cn) and its two
+// complementary edges are derived on the fly.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace ambi {
+
+struct LhGraph {
+    // header keys (Graph.cpp:140-167)
+    std::string sample_name, ploidy;
+    std::vector<double> avg_coverages;
+    double avg_cov_raw = -1, avg_virus_dp = -1, avg_cov_junc = 0, purity = -1;
+    double avg_tumor_ploidy = -1, avg_ploidy = 0;      // defaults of Graph::Graph(const char*) Graph.cpp:36-41
+    int virus_seg_start = 0; bool virus_seg_start_set = false;
+    int expected_ploidy = 0;
+    double ratio = 0; bool ratio_set = false;
+    double haploid_depth = 0, avg_coverage = 0;
+    // segments (file order; ids must be 1..N in file order, localhap.cpp:96 / LGM.cpp:3734 rely on it)
+    std::vector<int32_t> seg_id, seg_chr, seg_start, seg_end, seg_partition;
+    std::vector<std::string> seg_chrom;
+    std::vector<double> seg_cov, seg_cn;
+    // junctions (file order, duplicates dropped as Graph.cpp:592-595 does)
+    std::vector<int32_t> j_src, j_tgt;
+    std::vector<int8_t> j_sdir, j_tdir;     // +1 / -1
+    std::vector<double> j_cov, j_cn;
+    std::vector<uint8_t> j_inferred, j_bounded;
+    // chromosomes
+    std::vector<int32_t> source_ids, sink_ids;
+    // PROP line (LGM.cpp:3941-3987)
+    std::string main_chr;
+    int ins_mode = 0, con_mode = 0;
+    std::vector<std::string> ins_chr, con_chr;
+    std::vector<int32_t> start_segs;
+    // .juncs components (LGM.cpp:5096-5156)
+    std::vector<std::vector<int32_t>> components;
+    // lines the reference prints to stdout while loading (progress, SEG echoes, WARNs, .juncs breakpoints)
+    std::vector<std::string> log;
+
+    int n_seg() const { return (int)seg_id.size(); }
+    int n_junc() const { return (int)j_src.size(); }
+    int n_chr() const { return (int)source_ids.size(); }
+    int find_junction(int src, int sdir, int tgt, int tdir) const;   // Graph.cpp:501-511, -1 if absent
+    bool add_junction(int src, int sdir, int tgt, int tdir, double cov, double cn, bool inferred, bool bounded);
+};
+
+// Error codes of the host layer (negative; 0 = ok).  Text via lh_error_string().
+enum LhError {
+    LH_OK = 0,
+    LH_ERR_OPEN = -1,          // reference: "Cannot open file" + exit(1)          (Graph.cpp:111-114)
+    LH_ERR_MALFORMED = -2,     // reference dereferences a NULL strtok result (segfault)
+    LH_ERR_UNKNOWN_SEG = -3,   // reference: uncaught SegmentDoesNotExistException  (Graph.cpp:519)
+    LH_ERR_SOURCE_SINK = -4,   // reference: assert sourceIds.size()==sinkIds.size() (Graph.cpp:227)
+    LH_ERR_PLOIDY = -5,        // reference: "input error: ..." + exit(1)           (Graph.cpp:318-330)
+    LH_ERR_SEG_IDS = -6,       // ids not 1..N in file order (reference indexes segs[id-1])
+    LH_ERR_SOL_OPEN = -7,      // reference: "ILP error: cannot open file" + exit(1) (localhap.cpp:187-190)
+    LH_ERR_LINE_TOO_LONG = -8, // > 8191 bytes: the reference's getline(line, 8192) never terminates
+    LH_ERR_UNSUPPORTED = -9,   // TRX-BFB modes I1/C1 (reference path is UB)
+};
+const char* lh_error_string(int code);
+
+int read_lh(const std::string& path, LhGraph& g);                 // Graph.cpp:109-237 + calculateHapDepth/CopyNum + PROP
+int read_juncs(LhGraph& g, const std::string& path);              // LGM.cpp:5096-5156 (needs partitions set)
+void set_partitions(LhGraph& g);                                   // localhap.cpp:94-98
+
+struct SolFile {                                                   // localhap.cpp:192-212
+    bool infeasible = false;
+    double objective = 0;
+    std::vector<int32_t> col, val;                                 // in file order (a later line overrides an earlier one)
+};
+int read_sol(const std::string& path, SolFile& s);
+
+// printBFB (LGM.cpp:3411-3429): "1+2+|2-1-" with "||" between chromosomes
+std::string format_path(const LhGraph& g, const int32_t* path, int len);
+
+// column index <-> element (localhap.cpp:117-133): columns [0,numPat) are patterns in lexicographic (a,b) order,
+// [numPat, 2 numPat) the loops.
+bool column_to_element(int col, int start_id, int end_id, int* is_loop, int* a, int* b);
+
+// BFB-TRX stitching (LGM.cpp:4052-4193); paths[chr] may be reverse-complemented in place, as in the reference.
+void translocation_bfb(const LhGraph& g, std::vector<std::vector<int32_t>>& paths, std::vector<int32_t>& res);
+
+struct OutJunction { int32_t u, v, count; };
+// localhap.cpp:267-316: merge the junction steps of `path` into `out` (increase=false for the TRX pass)
+void merge_out_junctions(std::vector<OutJunction>& out, const int32_t* path, int len, bool increase);
+
+}  // namespace ambi

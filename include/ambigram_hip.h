@@ -1,0 +1,177 @@
+/* ambigram_hip.h -- C ABI of libambigram_hip.so, the MI355X-native BFB path-reconstruction engine.
+ *
+ * Drop-in boundary for the `--op bfb` path of deepomicslab/Ambigram.  The reference has no plugin/FFI interface
+ * (SURVEY.md 8b): the path is reached through C++ member calls on pointer-graph objects from main()
+ * (localhap.cpp:49-388).  Each entry point below names the reference call(s) it replaces; INTEGRATION.md shows
+ * the binding a maintainer adds to localhap.cpp and the ctypes stub used by ambigram_amd/.
+ *
+ * Conventions: plain pointers and sizes, caller-owned arrays, int32 unless noted; return 0 on success or a negative
+ * code (ambi_error_string); no exceptions cross the boundary; a handle is not thread-safe, different handles are.
+ * Vertices are signed ABSOLUTE segment ids: +id = (id,'+'), -id = (id,'-').
+ */
+#ifndef AMBIGRAM_HIP_H
+#define AMBIGRAM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMBI_ABI_VERSION 1
+
+/* run flags */
+#define AMBI_FLAG_REVERSED 1u /* --reversed (localhap.cpp:37,55) */
+#define AMBI_FLAG_ALL 2u      /* --all      (localhap.cpp:38,56) */
+
+/* per-unit status (ambi_unit_result_t.status); negative values are errors */
+#define AMBI_ST_OK 0
+#define AMBI_ST_SHORTCUT 1        /* no fold-back inversion: path 1+..n+ (localhap.cpp:164-170) */
+#define AMBI_ST_INFEASIBLE 2      /* .sol Infeasible: path 1+..n+ + "ILP is unsolvable." (localhap.cpp:213-220) */
+#define AMBI_ST_NO_VALID_ORDER 3  /* no order assembles in either orientation (reference leaves the path empty) */
+#define AMBI_ERR_TOO_MANY_NODES (-10)
+#define AMBI_ERR_NO_ELEMENTS (-11)
+#define AMBI_ERR_REF_UB (-12)     /* the reference reads out of bounds on this input; refused instead of guessed */
+#define AMBI_ERR_BKP_CAPACITY (-13)
+#define AMBI_ERR_PATH_CAPACITY (-14)
+#define AMBI_ERR_ORDERS_CAPACITY (-15)
+#define AMBI_ERR_IDEALS_CAPACITY (-16)
+#define AMBI_ERR_BAD_INPUT (-17)
+#define AMBI_ERR_OUTJUNC_CAPACITY (-18)
+/* host / runtime errors */
+#define AMBI_ERR_OPEN (-1)
+#define AMBI_ERR_MALFORMED (-2)
+#define AMBI_ERR_UNKNOWN_SEG (-3)
+#define AMBI_ERR_SOURCE_SINK (-4)
+#define AMBI_ERR_PLOIDY (-5)
+#define AMBI_ERR_SEG_IDS (-6)
+#define AMBI_ERR_SOL_OPEN (-7)
+#define AMBI_ERR_LINE_TOO_LONG (-8)
+#define AMBI_ERR_UNSUPPORTED (-9)
+#define AMBI_ERR_NO_DEVICE (-30)  /* no HIP device: the engine has NO CPU fallback */
+#define AMBI_ERR_HIP (-31)
+#define AMBI_ERR_STATE (-32)      /* call order violated (e.g. run before upload) */
+#define AMBI_ERR_ARG (-33)
+
+const char* ambi_error_string(int code);
+int ambi_abi_version(void);
+/* "hip" for libambigram_hip.so.  (The test-only host simulation built under tests/hostsim reports "hostsim".) */
+const char* ambi_backend_name(void);
+int ambi_device_count(int* count);
+int ambi_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph: replaces `new Graph(lh)` + calculateHapDepth + calculateCopyNum + readBFBProps
+ * (localhap.cpp:65-75; Graph.cpp:36-49,109-237,312-405; LocalGenomicMap.cpp:3941-3987).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ambi_graph ambi_graph_t;
+int ambi_graph_read_lh(const char* lh_path, ambi_graph_t** out);
+void ambi_graph_destroy(ambi_graph_t* g);
+int ambi_graph_sizes(const ambi_graph_t* g, int32_t* n_seg, int32_t* n_junc, int32_t* n_chr);
+/* any output pointer may be NULL */
+int ambi_graph_segments(const ambi_graph_t* g, int32_t* id, int32_t* chr_id, int32_t* start, int32_t* end, double* cov, double* cn);
+int ambi_graph_junctions(const ambi_graph_t* g, int32_t* src, int8_t* sdir, int32_t* tgt, int8_t* tdir, double* cov,
+                         double* cn, uint8_t* inferred, uint8_t* bounded);
+int ambi_graph_chromosome(const ambi_graph_t* g, int32_t chr, int32_t* source_id, int32_t* sink_id);
+/* replaces LocalGenomicMap::readComponents (LocalGenomicMap.cpp:5096-5156, localhap.cpp:102); may add junctions */
+int ambi_graph_read_juncs(ambi_graph_t* g, const char* juncs_path);
+/* stdout lines the reference prints while loading (progress, SEG echoes, .juncs breakpoints), '\n' separated.
+ * Returns the number of bytes needed (excluding the terminator); copies at most cap-1 bytes. */
+int64_t ambi_graph_log(const ambi_graph_t* g, char* buf, int64_t cap);
+/* PROP line: ins_mode / con_mode as in localhap.cpp:72-75, main chromosome name copied into main_chr[cap] */
+int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode, char* main_chr, int64_t cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch of units.  A unit = one chromosome of one sample = one iteration of the loop localhap.cpp:111-265:
+ *   getJuncCN (:136-139), bias (:141-146), getIndelBias (:147), no-FBI shortcut (:164-170), [ILP + cbc on the host],
+ *   targetCN (:222-232), constructDAG (:236), allTopologicalOrders (:254), getBFB (:261), indelBFB (:262)
+ * plus the unit's share of the output-junction loop (:267-289).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ambi_batch ambi_batch_t;
+int ambi_batch_create(ambi_batch_t** out);
+void ambi_batch_destroy(ambi_batch_t* b);
+
+/* Adds chromosome `chr` of `g` with the ILP solution of that chromosome: n_cols (column index, value) pairs as read
+ * from `<prefix>.sol` (column numbering of localhap.cpp:122-133; epsilon/bias columns and non-positive values are
+ * ignored), or infeasible != 0.  Returns the unit index (>= 0) or a negative code. */
+int ambi_batch_add_chromosome(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, int32_t n_cols, const int32_t* col,
+                              const int32_t* val, int32_t infeasible);
+/* Same, reading the .sol text (localhap.cpp:184-212).  A missing file returns AMBI_ERR_SOL_OPEN. */
+int ambi_batch_add_chromosome_sol(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, const char* sol_path);
+/* Raw unit: LOCAL segment ids 1..n_seg (absolute id = local + seg_base), junctions with both ends inside the unit,
+ * elements (is_loop, a, b, cn) of the decomposition. */
+int ambi_batch_add_unit(ambi_batch_t* b, int32_t n_seg, int32_t seg_base, const double* seg_cn, int32_t n_junc,
+                        const int32_t* j_src, const int32_t* j_tgt, const int8_t* j_sdir, const int8_t* j_tdir,
+                        const double* j_cn, int32_t n_elem, const int32_t* e_is_loop, const int32_t* e_a,
+                        const int32_t* e_b, const int32_t* e_cn, int32_t infeasible, int32_t has_components);
+int ambi_batch_size(const ambi_batch_t* b, int32_t* n_units);
+
+/* Tunables (before upload): order-table arena bytes (0 = size it from the first run), ideal-table slots per unit,
+ * first-valid scan budget, LDS tile bytes of the enumerate kernel. */
+int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t tile_bytes);
+
+/* Packs the units and copies the inputs to HBM on the current device (inputs stay resident across runs). */
+int ambi_batch_upload(ambi_batch_t* b);
+/* Enqueues one pass of the whole pipeline over the batch on `hip_stream` (a hipStream_t; NULL = default stream).
+ * Asynchronous unless the order arena has to grow. */
+int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream);
+int ambi_batch_wait(ambi_batch_t* b);
+/* Copies the result blob to the host (implies wait).  After this the getters below are valid. */
+int ambi_batch_download(ambi_batch_t* b);
+
+/* Device-side view for collectives: the result blob (header [n_units] + per-unit arrays) lives in device memory. */
+int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes);
+/* Packs the final paths of all units into caller-provided DEVICE buffers: lengths[n_units] (int32) and the
+ * concatenation of the paths (int32, absolute signed ids) -- the payload of the end-of-batch RCCL gather.
+ * which: 0 = getBFB path, 1 = path after indelBFB.  total_cells receives the number of cells written (device int64). */
+int ambi_batch_pack_paths(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap,
+                          int64_t* dev_total_cells, void* hip_stream);
+
+typedef struct {
+    int32_t status;
+    int32_t bias;             /* localhap.cpp:141-146 */
+    int32_t n_nodes;          /* K */
+    int32_t bkp_len;
+    int32_t path_len;         /* getBFB result */
+    int32_t path_indel_len;   /* after indelBFB */
+    int32_t indel_printed;    /* reference prints the indel caption + path */
+    int32_t n_out_junc;
+    int32_t first_forward;    /* 1 forward seed / 0 reversed seed / -1 */
+    int32_t evaluated;        /* order evaluations of the reference's sequential scan */
+    int64_t num_orders;       /* R */
+    int64_t first_valid;      /* index of the first valid order, -1 if none */
+    double inv_cn_sum;        /* localhap.cpp:150-153 */
+} ambi_unit_result_t;
+int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result_t* out);
+/* which: 0 = getBFB path (LocalGenomicMap.cpp:3660-3671), 1 = after indelBFB (:3746-3837). Returns length or <0. */
+int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int32_t* out, int32_t cap);
+int ambi_batch_unit_bkp(const ambi_batch_t* b, int32_t unit, int32_t* out, int32_t cap);
+/* per local segment id 0..n (slot 0 unused): junction CN (2 per id), CN after getIndelBias, targetCN, fold-back map */
+int ambi_batch_unit_prepare(const ambi_batch_t* b, int32_t unit, double* junc_cn, double* seg_cn, int32_t* target_cn,
+                            int32_t* inv_junc_global);
+/* DAG of the unit: node2pat / node2loop as [K][3] (absolute ids; a==0 empty), successor bit masks [K] */
+int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, int32_t* node2loop, uint64_t* succ);
+int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap);
+/* Copies rows [first,first+count) of the unit's order table (count x K uint8) from the device. */
+int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out);
+
+/* Per-kernel timing of the LAST run (HIP events on the run's stream, milliseconds); names are static strings.
+ * Enable with ambi_batch_set_timing(b, 1) before run. */
+int ambi_batch_set_timing(ambi_batch_t* b, int32_t on);
+int ambi_batch_kernel_count(const ambi_batch_t* b);
+int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms);
+/* bytes: inputs resident in HBM, order-table bytes written by the last run, result blob bytes */
+int ambi_batch_traffic(const ambi_batch_t* b, int64_t* input_bytes, int64_t* order_bytes, int64_t* result_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-sample helpers used by the CLI (host side, tiny): path text (printBFB, LocalGenomicMap.cpp:3411-3429),
+ * BFB-TRX stitching (translocationBFB, :4052-4193), output-junction merge (localhap.cpp:267-316).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ambi_format_path(const ambi_graph_t* g, const int32_t* path, int32_t len, char* buf, int64_t cap);
+/* paths: concatenated per-chromosome paths with offsets[n_chr+1]; result written to out (cap cells). Returns length. */
+int ambi_translocation_bfb(const ambi_graph_t* g, int32_t* paths, const int64_t* offsets, int32_t n_chr, int32_t* out, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMBIGRAM_HIP_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (ambigram_amd/) never does.  See oracle/bfb_oracle.hpp for what the oracle restates and how it is pinned.
+"""
+import ctypes
+import json
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FLAG_REVERSED = 1
+FLAG_ALL = 2
+FLAG_JUNC_INFO = 4
+FLAG_KEEP_ORDERS = 8
+
+
+def build(ref=True):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    targets = ["all"] + (["ref"] if ref else [])
+    subprocess.check_call(["make", "-s", "-C", _HERE] + targets)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = ctypes.CDLL(path)
+        L.oracle_run_bfb.restype = ctypes.c_void_p
+        L.oracle_run_bfb.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int,
+                                     ctypes.c_longlong, ctypes.POINTER(ctypes.c_double)]
+        L.oracle_graph_dump.restype = ctypes.c_void_p
+        L.oracle_graph_dump.argtypes = [ctypes.c_char_p]
+        L.oracle_free.argtypes = [ctypes.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _take(ptr):
+    s = ctypes.string_at(ptr).decode()
+    lib().oracle_free(ptr)
+    return json.loads(s)
+
+
+def run_bfb(lh, sols, juncs="", reversed_=False, all_=False, junc_info=False, keep_orders=False, max_orders=0):
+    """Whole `--op bfb` flow on the CPU oracle. `sols`: list of .sol paths, one per chromosome reaching the ILP."""
+    flags = (FLAG_REVERSED if reversed_ else 0) | (FLAG_ALL if all_ else 0) | \
+            (FLAG_JUNC_INFO if junc_info else 0) | (FLAG_KEEP_ORDERS if keep_orders else 0)
+    sec = ctypes.c_double(0)
+    p = lib().oracle_run_bfb(lh.encode(), juncs.encode(), ",".join(sols).encode(), flags, max_orders,
+                             ctypes.byref(sec))
+    out = _take(p)
+    out["seconds"] = sec.value
+    return out
+
+
+def graph_dump(lh):
+    return _take(lib().oracle_graph_dump(lh.encode()))
+
+
+def ref_graph_dump(lh):
+    """Parsed graph from the REAL reference graph model (oracle/_ref, container-only). None if unavailable."""
+    exe = os.path.join(_HERE, "_ref", "ref_graph_dump")
+    if not os.path.exists(exe):
+        return None
+    out = subprocess.run([exe, lh], capture_output=True, text=True)
+    if out.returncode != 0:
+        return {"ok": False, "err": "reference exited %d" % out.returncode}
+    return json.loads(out.stdout.strip().splitlines()[-1])

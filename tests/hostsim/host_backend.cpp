@@ -1,0 +1,180 @@
+// tests/hostsim/host_backend.cpp -- TEST INFRASTRUCTURE ONLY.
+// A Backend that executes the engine's SPMD stage code (ambigram_amd/csrc/ambi_stages.hpp -- the very source the
+// HIP kernels instantiate) with the 1-thread HostGroup on heap memory.  It lets `pytest -m "not gpu"` check the
+// stage logic, the packing, the result-blob layout and the C ABI against the oracle without a GPU, and lets the
+// sanitizers run over the kernel code on the CPU.  It is built into tests/hostsim/libambigram_hostsim.so only;
+// the product library libambigram_hip.so does not contain it and nothing in ambigram_amd/ loads it by default.
+#include <cstring>
+#include <vector>
+
+#include "../../ambigram_amd/csrc/ambi_backend.hpp"
+#include "../../ambigram_amd/csrc/ambi_stages.hpp"
+
+namespace ambi {
+
+class HostSimBackend : public Backend {
+    HostBatch hb_;
+    EngineConfig cfg_;
+    std::vector<UnitIn> units_;
+    std::vector<Dag> dags_;
+    std::vector<uint8_t> results_, arena_;
+    std::vector<uint64_t> ikeys_, icnt_;
+    std::vector<int32_t> ilvl_, ilvl_off_, icounter_, rows_per_lane_, scratch_;
+    std::vector<int64_t> blk_off_;
+    int32_t n_pending_ = 0;
+    int64_t orders_needed_ = 0;
+    std::vector<KernelTime> times_;
+    BatchArgs A_{};
+
+  public:
+    const char* name() const override { return "hostsim"; }
+    int device_count(int* n) override { if (n) *n = 0; return 0; }
+    int set_device(int) override { return 0; }
+
+    int upload(const HostBatch& hb, const EngineConfig& cfg) override {
+        hb_ = hb; cfg_ = cfg;
+        units_ = hb.units;
+        const size_t U = units_.size();
+        dags_.assign(U, Dag{});
+        results_.assign((size_t)hb.result_bytes, 0);
+        ikeys_.assign((size_t)hb.ideal_slots, 0); icnt_.assign((size_t)hb.ideal_slots, 0);
+        ilvl_.assign((size_t)hb.ideal_slots / 2 + 1, 0);
+        ilvl_off_.assign(U * (kMaxNodes + 3), 0); icounter_.assign(U, 0);
+        rows_per_lane_.assign(U, 1); blk_off_.assign(U + 1, 0);
+        scratch_.assign((size_t)hb.scratch_ints + 8, 0);
+        arena_.assign((size_t)(cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : 0), 0);
+        return 0;
+    }
+
+    void bind(uint32_t flags) {
+        A_.n_units = (int32_t)units_.size();
+        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.tile_bytes = cfg_.tile_bytes;
+        A_.units = units_.data(); A_.seg_cn = hb_.seg_cn.data(); A_.juncs = hb_.juncs.data(); A_.elems = hb_.elems.data();
+        A_.dags = dags_.data(); A_.results = results_.data();
+        A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_lvl = ilvl_.data();
+        A_.ideal_lvl_off = ilvl_off_.data(); A_.ideal_counter = icounter_.data();
+        A_.order_arena = arena_.data(); A_.order_arena_bytes = (int64_t)arena_.size();
+        A_.blk_off = blk_off_.data(); A_.rows_per_lane = rows_per_lane_.data();
+        A_.n_pending = &n_pending_; A_.orders_needed = &orders_needed_;
+        A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data();
+    }
+
+    void enumerate_all() {
+        HostGroup g;
+        const int64_t total = blk_off_[units_.size()];
+        std::vector<uint8_t> tile((size_t)A_.tile_bytes + 64 * 64);
+        for (int64_t b = 0; b < total; b++) {
+            int lo = 0, hi = (int)units_.size();
+            while (hi - lo > 1) { int mid = (lo + hi) / 2; if (blk_off_[mid] <= b) lo = mid; else hi = mid; }
+            const int u = lo;
+            UnitOut* out = unit_out(A_.results, u);
+            const int K = out->K, T = rows_per_lane_[u];
+            const int64_t R = out->num_orders, base_rank = (b - blk_off_[u]) * 64ll * T;
+            IdealTable tbl = unit_ideal_table(A_, u);
+            uint8_t ord[64];
+            for (int lane = 0; lane < 64; lane++)
+                enumerate_lane(dags_[u].pred, K, tbl, R, base_rank + (int64_t)lane * T, T, ord, 1, tile.data() + (size_t)lane * T * K);
+            int64_t rows = R - base_rank < 64ll * T ? R - base_rank : 64ll * T;
+            memcpy(A_.order_arena + out->order_off + base_rank * K, tile.data(), (size_t)(rows * K));
+        }
+        (void)g;
+    }
+
+    // slow path of the first-valid search: all orders, forward pass then flipped pass (LGM.cpp:3519-3696)
+    void search_pending() {
+        HostGroup g;
+        for (size_t u = 0; u < units_.size(); u++) {
+            UnitOut* out = unit_out(A_.results, (int)u);
+            if (out->status != ST_PENDING) continue;
+            const UnitIn& U = units_[u];
+            std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
+            FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+            load_first_work(g, A_, (int)u, W);
+            const int64_t R = out->num_orders;
+            bool fwd = !(A_.flags & FLAG_REVERSED);
+            int status = ST_NO_VALID_ORDER; int64_t found = -1; int L = 0; int64_t evaluated = 0; int found_fwd = -1;
+            for (int pass = 0; pass < 2 && found < 0; pass++) {
+                for (int64_t n = 0; n < R; n++) {
+                    int Lo = 0;
+                    int v = eval_indexed(g, A_, (int)u, W, n, fwd, &Lo);
+                    evaluated++;
+                    if (v < 0) { status = v; found = -2; break; }
+                    if (v == 1) { found = n; found_fwd = fwd ? 1 : 0; L = Lo; status = ST_OK; break; }
+                }
+                if (found == -2) break;
+                if (found < 0) fwd = !fwd;
+            }
+            out->status = status; out->evaluated = (int32_t)evaluated;
+            if (status == ST_OK) {
+                UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+                memcpy(A_.results + U.res_off + Lay.bkp, W.bkp, (size_t)L * 2);
+                out->first_valid = found; out->first_forward = found_fwd; out->bkp_len = L;
+            }
+        }
+    }
+
+    int run(uint32_t flags, void*) override {
+        HostGroup g;
+        bind(flags);
+        n_pending_ = 0;
+        const int Un = (int)units_.size();
+        for (int attempt = 0; attempt < 2; attempt++) {
+            for (int u = 0; u < Un; u++) {
+                std::vector<uint8_t> work((size_t)prepare_work_bytes(units_[u].n_seg, units_[u].n_junc, units_[u].n_elem));
+                stage_prepare(g, A_, u, work.data());
+            }
+            plan_serial(A_);
+            if (orders_needed_ <= (int64_t)arena_.size()) break;
+            arena_.assign((size_t)orders_needed_, 0);   // grow the arena and redo (first run only)
+            bind(flags);
+        }
+        enumerate_all();
+        for (int u = 0; u < Un; u++) {
+            std::vector<uint8_t> work((size_t)first_work_bytes(units_[u].n_seg, units_[u].bkp_cap));
+            stage_first(g, A_, u, work.data());
+        }
+        if (n_pending_ > 0) search_pending();
+        for (int u = 0; u < Un; u++) {
+            const UnitIn& U = units_[u];
+            std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_junc, U.bkp_cap, U.path_cap, U.out_cap));
+            stage_finish(g, A_, u, work.data());
+        }
+        return 0;
+    }
+    int wait() override { return 0; }
+    int download(std::vector<uint8_t>& blob) override { blob = results_; return 0; }
+    int device_results(void** ptr, int64_t* bytes) override {
+        if (ptr) *ptr = results_.data();
+        if (bytes) *bytes = (int64_t)results_.size();
+        return 0;
+    }
+    int pack_paths(int which, int32_t* lengths, int32_t* cells, int64_t cap, int64_t* total, void*) override {
+        int64_t off = 0;
+        for (size_t u = 0; u < units_.size(); u++) {
+            const UnitOut* h = unit_out(results_.data(), (int)u);
+            const UnitIn& U = units_[u];
+            UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+            int len = which ? h->path_indel_len : h->path_len;
+            const int32_t* src = reinterpret_cast<const int32_t*>(results_.data() + U.res_off + (which ? L.path_ind : L.path));
+            lengths[u] = len;
+            for (int i = 0; i < len && off + i < cap; i++) cells[off + i] = src[i];
+            off += len;
+        }
+        if (total) *total = off;
+        return 0;
+    }
+    int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
+        const UnitOut* h = unit_out(results_.data(), unit);
+        if (h->order_off < 0 || first < 0 || first + count > h->num_orders) return ST_ERR_BAD_INPUT;
+        memcpy(out, arena_.data() + h->order_off + first * h->K, (size_t)(count * h->K));
+        return 0;
+    }
+    int copy_dag(int unit, Dag* out) override { *out = dags_[unit]; return 0; }
+    void set_timing(bool) override {}
+    const std::vector<KernelTime>& kernel_times() override { return times_; }
+    int64_t order_bytes_written() const override { return orders_needed_; }
+};
+
+Backend* make_backend() { return new HostSimBackend(); }
+
+}  // namespace ambi
