@@ -1,0 +1,526 @@
+// ambi_engine.hip -- the HIP (gfx950 / MI355X) backend: kernels + stream orchestration.
+//
+// Kernels (all integer / index work, no MFMA; bound by HBM traffic of the order table and by LDS latency):
+//   ambi_prepare_kernel    1 wave  / unit   junction records staged into LDS by coalesced loads; getJuncCN, bias,
+//                                           getIndelBias, targetCN, constructDAG; order-ideal lattice by
+//                                           level-synchronous frontier expansion; R
+//   ambi_plan_kernel       1 block / batch  64-bit scans: order-table offsets, enumerate work blocks
+//   ambi_enumerate_kernel  1 wave  / block of 64*T ranks: unrank + lexicographic successor per lane, rows staged in an
+//                                           LDS tile, written to HBM with 16-byte coalesced stores   <- HBM-bound
+//   ambi_first_kernel      1 wave  / unit   getBFB scan for the first valid order, bkp in LDS
+//   ambi_search_kernel     1 wave  / chunk of orders (only for units whose scan budget ran out)
+//   ambi_finish_kernel     1 block / unit   bkp -> path (LDS int16), indelBFB, output junctions
+//   ambi_pack_*            end-of-batch packing of the paths for the RCCL gather
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ambi_backend.hpp"
+#include "ambi_stages.hpp"
+
+namespace ambi {
+
+#define HIP_CK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) {                                                                     \
+            fprintf(stderr, "ambigram_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -31;                                                                             \
+        }                                                                                           \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+extern __shared__ __align__(16) uint8_t ambi_lds[];
+
+__global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
+    WaveGroup g;
+    stage_prepare(g, A, (int)blockIdx.x, ambi_lds);
+}
+
+__device__ inline int64_t wave_incl_scan_i64(int64_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int64_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one int64 per thread (blockDim.x <= 1024); *total = sum
+__device__ inline int64_t block_exscan_i64(int64_t v, int64_t* total, int64_t* sh /*[17]*/) {
+    int64_t inc = wave_incl_scan_i64(v);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+    for (int i = 0; i < nw; i++) { int64_t s = sh[i]; if (i < w) base += s; tot += s; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// Parallel form of plan_serial (ambi_stages.hpp): same prefix-sum semantics.
+__global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
+    __shared__ int64_t sh[17];
+    int64_t off_carry = 0, blk_carry = 0;
+    for (int base = 0; base < A.n_units; base += blockDim.x) {
+        const int u = base + (int)threadIdx.x;
+        int64_t bytes = 0, blocks = 0;
+        int T = 1;
+        bool live = false, toobig = false;
+        UnitOut* out = nullptr;
+        if (u < A.n_units) {
+            out = unit_out(A.results, u);
+            if (out->status == ST_OK) {
+                const int K = out->K;
+                const int64_t R = out->num_orders;
+                if (R >= (int64_t)kCountSat) toobig = true;
+                else {
+                    live = true;
+                    bytes = (R * K + 15) & ~int64_t(15);
+                    T = rows_per_lane_for(K, A.tile_bytes);
+                    blocks = (R + 64ll * T - 1) / (64ll * T);
+                }
+            }
+        }
+        int64_t tot_b, tot_k;
+        int64_t off = off_carry + block_exscan_i64(bytes, &tot_b, sh);
+        // a unit that does not fit contributes no work blocks
+        bool fits = live && (off + bytes <= A.order_arena_bytes);
+        int64_t blk = blk_carry + block_exscan_i64(fits ? blocks : 0, &tot_k, sh);
+        if (u < A.n_units) {
+            A.blk_off[u] = blk;
+            A.rows_per_lane[u] = T;
+            if (toobig) out->status = ST_ERR_ORDERS_CAPACITY;
+            else if (live) {
+                if (fits) out->order_off = off;
+                else out->status = ST_ERR_ORDERS_CAPACITY;
+            }
+        }
+        off_carry += tot_b;
+        blk_carry += tot_k;
+    }
+    if (threadIdx.x == 0) {
+        A.blk_off[A.n_units] = blk_carry;
+        *A.orders_needed = off_carry;
+    }
+}
+
+// LDS per wave: [tile_bytes] rows | [64*64] per-lane current order, transposed (ord[d*64 + lane]) | [64] pred masks
+__global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int wave_bytes = A.tile_bytes + 64 * 64 + 64 * 8;
+    uint8_t* wbase = ambi_lds + (size_t)wave * wave_bytes;
+    uint8_t* tile = wbase;
+    uint8_t* ord = wbase + A.tile_bytes;
+    uint64_t* pred = reinterpret_cast<uint64_t*>(wbase + A.tile_bytes + 64 * 64);
+    WaveGroup g;
+    const int64_t total = A.blk_off[A.n_units];
+    for (int64_t b = (int64_t)blockIdx.x * wpb + wave; b < total; b += (int64_t)gridDim.x * wpb) {
+        int lo = 0, hi = A.n_units;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
+        const int u = lo;
+        const UnitOut* out = unit_out(A.results, u);
+        const int K = out->K, T = A.rows_per_lane[u];
+        const int64_t R = out->num_orders;
+        const int64_t base_rank = (b - A.blk_off[u]) * 64ll * T;
+        if (lane < K) pred[lane] = A.dags[u].pred[lane];
+        g.sync();
+        IdealTable tbl = unit_ideal_table(A, u);
+        enumerate_lane(pred, K, tbl, R, base_rank + (int64_t)lane * T, T, ord + lane, 64, tile + (size_t)lane * T * K);
+        g.sync();
+        int64_t rows = R - base_rank;
+        if (rows > 64ll * T) rows = 64ll * T;
+        const int64_t nbytes = rows * K;
+        uint8_t* dst = A.order_arena + out->order_off + base_rank * K;   // 16-byte aligned: order_off%16==0, 64*T*K%16==0
+        const int64_t nvec = nbytes >> 4;
+        const uint4* src4 = reinterpret_cast<const uint4*>(tile);
+        uint4* dst4 = reinterpret_cast<uint4*>(dst);
+        for (int64_t i = lane; i < nvec; i += 64) dst4[i] = src4[i];
+        for (int64_t i = (nvec << 4) + lane; i < nbytes; i += 64) dst[i] = tile[i];
+        g.sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void ambi_first_kernel(BatchArgs A) {
+    WaveGroup g;
+    stage_first(g, A, (int)blockIdx.x, ambi_lds);
+}
+
+// Slow path: units whose first-valid scan ran out of budget.  One wave per chunk of `chunk` consecutive orders.
+struct SearchArgs {
+    const int32_t* pending;      // [np] unit indices
+    const int64_t* chunk_off;    // [np+1] prefix of chunk counts
+    int64_t* found;              // [np] min valid order index (init INT64_MAX)
+    int32_t* err;                // [np] negative status seen
+    int32_t np, chunk, forward, wave_lds;
+};
+__global__ __launch_bounds__(256) void ambi_search_kernel(BatchArgs A, SearchArgs S) {
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint8_t* work = ambi_lds + (size_t)wave * S.wave_lds;
+    WaveGroup g;
+    const int64_t total = S.chunk_off[S.np];
+    for (int64_t c = (int64_t)blockIdx.x * wpb + wave; c < total; c += (int64_t)gridDim.x * wpb) {
+        int lo = 0, hi = S.np;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (S.chunk_off[mid] <= c) lo = mid; else hi = mid; }
+        const int p = lo, u = S.pending[p];
+        const UnitIn& U = A.units[u];
+        if (unit_out(A.results, u)->status != ST_PENDING) continue;   // resolved by the previous pass
+        const int64_t R = unit_out(A.results, u)->num_orders;
+        const int64_t first = (c - S.chunk_off[p]) * S.chunk;
+        if (first >= *(volatile int64_t*)&S.found[p]) continue;   // an earlier valid order is already known
+        FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+        load_first_work(g, A, u, W);
+        for (int64_t n = first; n < first + S.chunk && n < R; n++) {
+            if (n >= *(volatile int64_t*)&S.found[p]) break;
+            int L = 0;
+            int v = eval_indexed(g, A, u, W, n, S.forward != 0, &L);
+            if (v < 0) { if (g.tid() == 0) atomicMin(&S.err[p], v); break; }
+            if (v == 1) { if (g.tid() == 0) atomicMin((unsigned long long*)&S.found[p], (unsigned long long)n); break; }
+        }
+        g.sync();
+    }
+}
+// after a search pass: re-evaluate the winning order to materialise its bkp and fill the header
+__global__ __launch_bounds__(64) void ambi_resolve_kernel(BatchArgs A, SearchArgs S, int pass) {
+    WaveGroup g;
+    const int p = blockIdx.x, u = S.pending[p];
+    UnitOut* out = unit_out(A.results, u);
+    if (out->status != ST_PENDING) return;
+    const UnitIn& U = A.units[u];
+    const int64_t R = out->num_orders;
+    const int64_t f = S.found[p];
+    if (S.err[p] < 0) { if (g.tid() == 0) out->status = S.err[p]; return; }
+    if (f == 0x7fffffffffffffffll) {
+        if (pass == 1 && g.tid() == 0) { out->status = ST_NO_VALID_ORDER; out->evaluated = (int32_t)(2 * R); }
+        return;
+    }
+    FirstWork W = carve_first(ambi_lds, U.n_seg, U.bkp_cap);
+    load_first_work(g, A, u, W);
+    int L = 0;
+    int v = eval_indexed(g, A, u, W, f, S.forward != 0, &L);
+    const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    cell_t* dst = reinterpret_cast<cell_t*>(A.results + U.res_off + Lay.bkp);
+    for (int i = g.tid(); i < L; i += g.size()) dst[i] = W.bkp[i];
+    if (g.tid() == 0) {
+        out->status = (v == 1) ? ST_OK : ST_ERR_REF_UB;
+        out->first_valid = f; out->first_forward = S.forward; out->bkp_len = L;
+        out->evaluated = (int32_t)(pass * R + f + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    const int u = unit_list ? unit_list[blockIdx.x] : (int)blockIdx.x;
+    stage_finish(g, A, u, ambi_lds);
+}
+
+__global__ __launch_bounds__(1024) void ambi_pack_scan_kernel(BatchArgs A, int which, int32_t* lengths, int64_t* pack_off, int64_t* total) {
+    __shared__ int64_t sh[17];
+    int64_t carry = 0;
+    for (int base = 0; base < A.n_units; base += blockDim.x) {
+        const int u = base + (int)threadIdx.x;
+        int64_t len = 0;
+        if (u < A.n_units) {
+            const UnitOut* h = unit_out(A.results, u);
+            len = which ? h->path_indel_len : h->path_len;
+            lengths[u] = (int32_t)len;
+        }
+        int64_t tot;
+        int64_t ex = block_exscan_i64(len, &tot, sh);
+        if (u < A.n_units) pack_off[u] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { pack_off[A.n_units] = carry; if (total) *total = carry; }
+}
+__global__ __launch_bounds__(256) void ambi_pack_copy_kernel(BatchArgs A, int which, const int64_t* pack_off, int32_t* cells, int64_t cap) {
+    const int u = blockIdx.x;
+    const UnitIn& U = A.units[u];
+    const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const int32_t* src = reinterpret_cast<const int32_t*>(A.results + U.res_off + (which ? L.path_ind : L.path));
+    const int64_t off = pack_off[u], len = pack_off[u + 1] - off;
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x)
+        if (off + i < cap) cells[off + i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// backend
+// ------------------------------------------------------------------------------------------------
+class HipBackend : public Backend {
+    HostBatch hb_;
+    EngineConfig cfg_;
+    bool uploaded_ = false, timing_ = false, arena_checked_ = false, ran_ = false;
+    hipStream_t stream_ = nullptr;
+    // device buffers
+    UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; Element* d_elems_ = nullptr;
+    Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
+    uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; int32_t* d_ilvl_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
+    uint8_t* d_arena_ = nullptr; int64_t arena_bytes_ = 0;
+    int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
+    int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
+    int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned
+    BatchArgs A_{};
+    int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_enum_ = 0;
+    std::vector<KernelTime> times_;
+    struct Ev { const char* name; hipEvent_t a, b; };
+    std::vector<Ev> evs_;
+    int64_t last_needed_ = 0;
+
+    void free_all() {
+        void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilvl_, d_ilvl_off_,
+                        d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (h_npending_) (void)hipHostFree(h_npending_);
+        if (h_needed_) (void)hipHostFree(h_needed_);
+        for (auto& e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        evs_.clear();
+    }
+
+  public:
+    ~HipBackend() override { free_all(); }
+    const char* name() const override { return "hip"; }
+    int device_count(int* n) override {
+        int c = 0;
+        hipError_t e = hipGetDeviceCount(&c);
+        if (e != hipSuccess) c = 0;
+        if (n) *n = c;
+        return 0;
+    }
+    int set_device(int d) override { HIP_CK(hipSetDevice(d)); return 0; }
+
+    template <class T> int dalloc(T** p, size_t count) {
+        HIP_CK(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
+        return 0;
+    }
+
+    int upload(const HostBatch& hb, const EngineConfig& cfg) override {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
+        hb_ = hb; cfg_ = cfg;
+        const size_t U = hb.units.size();
+        int rc;
+        if ((rc = dalloc(&d_units_, U))) return rc;
+        if ((rc = dalloc(&d_seg_cn_, hb.seg_cn.size()))) return rc;
+        if ((rc = dalloc(&d_juncs_, hb.juncs.size()))) return rc;
+        if ((rc = dalloc(&d_elems_, hb.elems.size()))) return rc;
+        if ((rc = dalloc(&d_dags_, U))) return rc;
+        if ((rc = dalloc(&d_results_, (size_t)hb.result_bytes))) return rc;
+        if ((rc = dalloc(&d_ikeys_, (size_t)hb.ideal_slots))) return rc;
+        if ((rc = dalloc(&d_icnt_, (size_t)hb.ideal_slots))) return rc;
+        if ((rc = dalloc(&d_ilvl_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
+        if ((rc = dalloc(&d_ilvl_off_, U * (kMaxNodes + 3)))) return rc;
+        if ((rc = dalloc(&d_icounter_, U))) return rc;
+        if ((rc = dalloc(&d_blk_off_, U + 1))) return rc;
+        if ((rc = dalloc(&d_rows_, U))) return rc;
+        if ((rc = dalloc(&d_npending_, 1))) return rc;
+        if ((rc = dalloc(&d_needed_, 1))) return rc;
+        if ((rc = dalloc(&d_scratch_, (size_t)hb.scratch_ints + 8))) return rc;
+        if ((rc = dalloc(&d_scratch_off_, U))) return rc;
+        if ((rc = dalloc(&d_pack_off_, U + 1))) return rc;
+        HIP_CK(hipHostMalloc((void**)&h_npending_, sizeof(int32_t)));
+        HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t)));
+        arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
+        HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
+        HIP_CK(hipMemcpy(d_units_, hb.units.data(), U * sizeof(UnitIn), hipMemcpyHostToDevice));
+        HIP_CK(hipMemcpy(d_seg_cn_, hb.seg_cn.data(), hb.seg_cn.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (!hb.juncs.empty()) HIP_CK(hipMemcpy(d_juncs_, hb.juncs.data(), hb.juncs.size() * sizeof(Junction), hipMemcpyHostToDevice));
+        if (!hb.elems.empty()) HIP_CK(hipMemcpy(d_elems_, hb.elems.data(), hb.elems.size() * sizeof(Element), hipMemcpyHostToDevice));
+        HIP_CK(hipMemcpy(d_scratch_off_, hb.scratch_off.data(), U * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_CK(hipMemset(d_results_, 0, (size_t)hb.result_bytes));
+        // LDS budgets (dynamic shared memory), sized for the largest unit of the batch
+        lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
+        lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
+        lds_finish_ = (int)finish_work_bytes(hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
+        lds_enum_ = 4 * (cfg.tile_bytes + 64 * 64 + 64 * 8);
+        const int kLdsLimit = 160 * 1024 - 1024;
+        if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit) {
+            fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
+                    lds_prepare_, lds_first_, lds_finish_);
+            return ST_ERR_BAD_INPUT;
+        }
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_prepare_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
+        uploaded_ = true; arena_checked_ = false;
+        return 0;
+    }
+
+    void bind(uint32_t flags) {
+        A_.n_units = (int32_t)hb_.units.size();
+        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.tile_bytes = cfg_.tile_bytes;
+        A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
+        A_.dags = d_dags_; A_.results = d_results_;
+        A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_lvl = d_ilvl_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
+        A_.order_arena = d_arena_; A_.order_arena_bytes = arena_bytes_;
+        A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
+        A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_;
+    }
+
+    void tick(const char* name, size_t idx, bool begin) {
+        if (!timing_) return;
+        if (idx >= evs_.size()) {
+            Ev e{name, nullptr, nullptr};
+            (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+            evs_.push_back(e);
+        }
+        (void)hipEventRecord(begin ? evs_[idx].a : evs_[idx].b, stream_);
+    }
+
+    int launch_front() {   // prepare + plan
+        const int U = A_.n_units;
+        tick("ambi_prepare_kernel", 0, true);
+        hipLaunchKernelGGL(ambi_prepare_kernel, dim3(U), dim3(64), lds_prepare_, stream_, A_);
+        tick("ambi_prepare_kernel", 0, false);
+        tick("ambi_plan_kernel", 1, true);
+        hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, stream_, A_);
+        tick("ambi_plan_kernel", 1, false);
+        HIP_CK(hipGetLastError());
+        return 0;
+    }
+
+    int run(uint32_t flags, void* stream) override {
+        if (!uploaded_) return -32;
+        stream_ = (hipStream_t)stream;
+        bind(flags);
+        HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
+        int rc = launch_front();
+        if (rc) return rc;
+        if (!arena_checked_) {
+            // first run of this batch: make sure the order table fits, growing the arena once if needed
+            HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+            HIP_CK(hipStreamSynchronize(stream_));
+            if (*h_needed_ > arena_bytes_) {
+                HIP_CK(hipFree(d_arena_));
+                d_arena_ = nullptr;
+                arena_bytes_ = *h_needed_ + (*h_needed_ >> 3) + 4096;
+                HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
+                bind(flags);
+                if ((rc = launch_front())) return rc;
+            }
+            arena_checked_ = true;
+        }
+        const int U = A_.n_units;
+        tick("ambi_enumerate_kernel", 2, true);
+        hipLaunchKernelGGL(ambi_enumerate_kernel, dim3(2048), dim3(256), lds_enum_, stream_, A_);
+        tick("ambi_enumerate_kernel", 2, false);
+        tick("ambi_first_kernel", 3, true);
+        hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, stream_, A_);
+        tick("ambi_first_kernel", 3, false);
+        tick("ambi_finish_kernel", 4, true);
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, stream_, A_, (const int32_t*)nullptr);
+        tick("ambi_finish_kernel", 4, false);
+        HIP_CK(hipGetLastError());
+        HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+        ran_ = true;
+        return 0;
+    }
+
+    // parallel search for units whose sequential scan ran out of budget (rare)
+    int slow_path() {
+        const int U = A_.n_units;
+        std::vector<UnitOut> hdr(U);
+        HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));
+        std::vector<int32_t> pend;
+        for (int u = 0; u < U; u++) if (hdr[u].status == ST_PENDING) pend.push_back(u);
+        if (pend.empty()) return 0;
+        const int np = (int)pend.size(), chunk = 16;
+        std::vector<int64_t> coff(np + 1, 0);
+        for (int p = 0; p < np; p++) coff[p + 1] = coff[p] + (hdr[pend[p]].num_orders + chunk - 1) / chunk;
+        int32_t* d_pend; int64_t* d_coff; int64_t* d_found; int32_t* d_err;
+        HIP_CK(hipMalloc((void**)&d_pend, np * sizeof(int32_t)));
+        HIP_CK(hipMalloc((void**)&d_coff, (np + 1) * sizeof(int64_t)));
+        HIP_CK(hipMalloc((void**)&d_found, np * sizeof(int64_t)));
+        HIP_CK(hipMalloc((void**)&d_err, np * sizeof(int32_t)));
+        HIP_CK(hipMemcpy(d_pend, pend.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CK(hipMemcpy(d_coff, coff.data(), (np + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1;
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, waves * lds_first_));
+        bool fwd = !(A_.flags & FLAG_REVERSED);
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<int64_t> init(np, 0x7fffffffffffffffll);
+            HIP_CK(hipMemcpy(d_found, init.data(), np * sizeof(int64_t), hipMemcpyHostToDevice));
+            HIP_CK(hipMemset(d_err, 0, np * sizeof(int32_t)));
+            SearchArgs S{d_pend, d_coff, d_found, d_err, np, chunk, fwd ? 1 : 0, lds_first_};
+            int64_t nblk = (coff[np] + waves - 1) / waves;
+            if (nblk > 65535 * 16) nblk = 65535 * 16;
+            if (nblk < 1) nblk = 1;
+            hipLaunchKernelGGL(ambi_search_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * lds_first_, stream_, A_, S);
+            hipLaunchKernelGGL(ambi_resolve_kernel, dim3(np), dim3(64), lds_first_, stream_, A_, S, pass);
+            HIP_CK(hipGetLastError());
+            HIP_CK(hipStreamSynchronize(stream_));
+            fwd = !fwd;
+        }
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(np), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend);
+        HIP_CK(hipGetLastError());
+        HIP_CK(hipStreamSynchronize(stream_));
+        (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_found); (void)hipFree(d_err);
+        return 0;
+    }
+
+    int wait() override {
+        if (!ran_) return 0;
+        HIP_CK(hipStreamSynchronize(stream_));
+        last_needed_ = *h_needed_;
+        if (*h_npending_ > 0) {
+            int rc = slow_path();
+            if (rc) return rc;
+            *h_npending_ = 0;
+        }
+        if (timing_) {
+            times_.clear();
+            for (auto& e : evs_) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) ms = -1;
+                times_.push_back({e.name, ms});
+            }
+        }
+        return 0;
+    }
+    int download(std::vector<uint8_t>& blob) override {
+        int rc = wait();
+        if (rc) return rc;
+        blob.resize((size_t)hb_.result_bytes);
+        HIP_CK(hipMemcpy(blob.data(), d_results_, (size_t)hb_.result_bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    int device_results(void** ptr, int64_t* bytes) override {
+        if (ptr) *ptr = d_results_;
+        if (bytes) *bytes = hb_.result_bytes;
+        return 0;
+    }
+    int pack_paths(int which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap, int64_t* dev_total, void* stream) override {
+        hipStream_t s = (hipStream_t)stream;
+        bind(A_.flags);
+        hipLaunchKernelGGL(ambi_pack_scan_kernel, dim3(1), dim3(1024), 0, s, A_, which, dev_lengths, d_pack_off_, dev_total);
+        hipLaunchKernelGGL(ambi_pack_copy_kernel, dim3(A_.n_units), dim3(256), 0, s, A_, which, (const int64_t*)d_pack_off_, dev_cells, cell_cap);
+        HIP_CK(hipGetLastError());
+        return 0;
+    }
+    int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
+        UnitOut h;
+        HIP_CK(hipMemcpy(&h, d_results_ + sizeof(UnitOut) * (size_t)unit, sizeof(UnitOut), hipMemcpyDeviceToHost));
+        if (h.order_off < 0 || first < 0 || first + count > h.num_orders) return ST_ERR_BAD_INPUT;
+        HIP_CK(hipMemcpy(out, d_arena_ + h.order_off + first * h.K, (size_t)(count * h.K), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    int copy_dag(int unit, Dag* out) override {
+        HIP_CK(hipMemcpy(out, d_dags_ + unit, sizeof(Dag), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    void set_timing(bool on) override { timing_ = on; }
+    const std::vector<KernelTime>& kernel_times() override { return times_; }
+    int64_t order_bytes_written() const override { return last_needed_; }
+};
+
+Backend* make_backend() { return new HipBackend(); }
+
+}  // namespace ambi

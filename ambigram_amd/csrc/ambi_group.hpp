@@ -10,6 +10,9 @@
 //   WaveGroup   one 64-lane CDNA wavefront, DPP/shuffle reductions, no LDS scratch needed
 //   BlockGroup  one workgroup of up to 1024 threads (wave reduce + LDS exchange)
 #pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
 #include "ambi_common.hpp"
 
 namespace ambi {

@@ -1,0 +1,143 @@
+"""Parity checks shared by the CPU host-simulation tests and the GPU tests (same assertions, different library)."""
+import numpy as np
+
+import cases
+import parity
+from ambigram_amd import api
+
+
+def check_fixed_and_synthetic(lib, oracle, workdir, small_only):
+    bad = {}
+    for name, lh, sols in cases.fixed_cases() + cases.synthetic_cases(workdir, small_only=small_only):
+        d = parity.compare(lib, oracle, lh, sols)
+        if d:
+            bad[name] = d
+        d = parity.compare(lib, oracle, lh, sols, reversed_=True, keep_orders=False)
+        if d:
+            bad[name + "/reversed"] = d
+    assert not bad, bad
+
+
+def check_search_budget(lib, oracle, workdir):
+    """first_budget=1 forces the parallel search path whenever the first order is not the valid one."""
+    bad = {}
+    for name, lh, sols in cases.synthetic_cases(workdir, small_only=True)[:6]:
+        d = parity.compare(lib, oracle, lh, sols, first_budget=1, keep_orders=False)
+        if d:
+            bad[name] = d
+    assert not bad, bad
+
+
+def check_random_decompositions(lib, oracle, workdir, seeds, budget=0):
+    stats = dict(valid=0, none=0, deep=0, reversed_pass=0, refused=0)
+    for seed in seeds:
+        lh, sols = cases.random_decomposition(workdir, seed)
+        for rev in (False, True):
+            o = oracle.run_bfb(lh, sols, reversed_=rev, keep_orders=True)
+            assert o["ok"], o["err"]
+            oc = o["chr"][0]
+            if oc["shortcut"]:
+                continue
+            g = api.Graph(lib, lh)
+            b = api.Batch(lib)
+            if budget:
+                b.configure(first_budget=budget)
+            b.add_chromosome_sol(g, 0, sols[0])
+            b.upload(); b.run(api.FLAG_REVERSED if rev else 0); b.download()
+            r = b.unit_result(0)
+            if oc["ub"]:
+                # the reference itself reads out of bounds here; the engine must refuse, not guess
+                assert r["status"] in (-12, 3, 0), (seed, r)
+                stats["refused"] += 1
+                continue
+            assert r["num_orders"] == oc["num_orders"], (seed, rev)
+            K = r["n_nodes"]
+            if oc["num_orders"] and oc["num_orders"] <= 20000:
+                assert b.unit_orders(0, 0, r["num_orders"], K).tolist() == oc["orders"], (seed, rev)
+            if oc["first_valid"] < 0:
+                assert r["status"] == api.ST_NO_VALID_ORDER, (seed, rev, r)
+                assert r["evaluated"] == oc["evaluated"], (seed, rev, r["evaluated"], oc["evaluated"])
+                stats["none"] += 1
+            else:
+                assert r["status"] == 0, (seed, rev, r)
+                assert (r["first_valid"], r["first_forward"], r["evaluated"]) == (oc["first_valid"], oc["first_forward"], oc["evaluated"]), (seed, rev)
+                assert b.unit_bkp(0).tolist() == oc["bkp"], (seed, rev)
+                assert b.unit_path(0, 0).tolist() == oc["path"], (seed, rev)
+                assert b.unit_path(0, 1).tolist() == oc["path_indel"], (seed, rev)
+                stats["valid"] += 1
+                if oc["first_valid"] > 0:
+                    stats["deep"] += 1
+                if oc["first_forward"] == (1 if rev else 0):
+                    stats["reversed_pass"] += 1
+            b.close(); g.close()
+    return stats
+
+
+def check_edge_cases(lib, oracle, workdir):
+    import os
+    # (1) chromosome without any fold-back inversion -> shortcut path 1+..n+ (localhap.cpp:164-170)
+    lh = os.path.join(workdir, "nofbi.lh")
+    with open(lh, "w") as f:
+        f.write("SAMPLE_NAME nofbi\nAVG_CHR_SEG_DP 30\nAVG_WHOLE_HOST_DP 30\nAVG_JUNC_DP 30\nPURITY 1\nAVG_TUMOR_PLOIDY 2\n"
+                "PLOIDY 2m1\nVIRUS_START 5\nSOURCE 1\nSINK 4\n"
+                "SEG H:1:chr1:1:10 30.0 1.0\nSEG H:2:chr1:11:20 30.0 1.0\nSEG H:3:chr1:21:30 30.0 1.0\nSEG H:4:chr1:31:40 30.0 1.0\n"
+                "JUNC H:1:+ H:2:+ 30.0 1.0 U B\nJUNC H:2:+ H:3:+ 30.0 1.0 U B\nJUNC H:1:+ H:4:+ 30.0 1.0 U B\n")
+    assert parity.compare(lib, oracle, lh, []) == []
+    # (2) infeasible ILP -> reference path + "ILP is unsolvable." (localhap.cpp:213-220)
+    sol = os.path.join(workdir, "infeasible.sol")
+    with open(sol, "w") as f:
+        f.write("Infeasible - objective value 0.00000000\n")
+    assert parity.compare(lib, oracle, os.path.join(cases.DATA, "readme6.lh"), [sol]) == []
+    # (3) a .sol that selects nothing -> the reference indexes an empty order; the engine refuses
+    sol0 = os.path.join(workdir, "empty.sol")
+    with open(sol0, "w") as f:
+        f.write("Optimal - objective value 0.00000000\n")
+    g = api.Graph(lib, os.path.join(cases.DATA, "readme6.lh"))
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sol0)
+    b.upload(); b.run(0); b.download()
+    assert b.unit_result(0)["status"] == -11
+    # (4) missing .sol / missing .lh error codes (localhap.cpp:187-190, Graph.cpp:111-114)
+    import pytest
+    with pytest.raises(api.AmbiError) as e:
+        b2 = api.Batch(lib); b2.add_chromosome_sol(g, 0, os.path.join(workdir, "nope.sol"))
+    assert e.value.code == -7
+    with pytest.raises(api.AmbiError) as e:
+        api.Graph(lib, os.path.join(workdir, "nope.lh"))
+    assert e.value.code == -1
+
+
+def check_juncs_file(lib, oracle, workdir):
+    """.juncs components (readComponents, LGM.cpp:5096-5156): adds junctions / bumps CN before getJuncCN."""
+    import os
+    j = os.path.join(workdir, "readme6.juncs")
+    with open(j, "w") as f:
+        f.write("6+ 6- 5- 4- 3- 2- 2+\n2- 2+ 3+ 4+ 5+ 6+ 6-\n6+ 6- 5- 4- 3-\n")   # README.md:173-177
+    lh = os.path.join(cases.DATA, "readme6.lh")
+    assert parity.compare(lib, oracle, lh, [os.path.join(cases.DATA, "readme6.sol")], juncs=j) == []
+
+
+def check_batch_many_units(lib, oracle, workdir, n_samples):
+    """Many independent samples in ONE batch == each sample alone (units do not interact)."""
+    from ambigram_amd import synth
+    graphs, b = [], api.Batch(lib)
+    expect = []
+    for i in range(n_samples):
+        tier, K = [("chain", 7), ("wide", 7), ("mixed", 7)][i % 3]
+        s = synth.make_sample(48, 100, tier, K, seed=5000 + i, imperfect=i % 2, n_del=i % 2)
+        lh, sols = s.write(workdir, "b%d" % i)
+        g = api.Graph(lib, lh)
+        graphs.append(g)
+        b.add_chromosome_sol(g, 0, sols[0])
+        expect.append(oracle.run_bfb(lh, sols)["chr"][0])
+    b.upload(); b.run(0); b.download()
+    for i, oc in enumerate(expect):
+        r = b.unit_result(i)
+        assert r["status"] == 0 and r["num_orders"] == oc["num_orders"], i
+        assert b.unit_path(i, 0).tolist() == oc["path"], i
+        assert b.unit_path(i, 1).tolist() == oc["path_indel"], i
+    # a second run over the resident batch gives the same answer (idempotence)
+    b.run(0); b.download()
+    for i, oc in enumerate(expect):
+        assert b.unit_path(i, 1).tolist() == oc["path_indel"], i
+    return b, graphs, expect

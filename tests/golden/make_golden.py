@@ -1,0 +1,43 @@
+"""Generates tests/golden/graph_*.json from the REAL reference graph model (oracle/_ref/ref_graph_dump, built from
+/root/reference/src/{Graph,Segment,Vertex,Edge,Junction,Weight,Exceptions}.cpp by `make -C oracle ref`).
+Container-only: the GPU box has no /root/reference; it uses the committed JSON files.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle_py  # noqa: E402
+from ambigram_amd import synth  # noqa: E402
+
+CASES = {
+    "readme6": os.path.join(ROOT, "tests", "data", "readme6.lh"),
+    "trx_c2": os.path.join(ROOT, "tests", "data", "trx_c2.lh"),
+    "quirks": os.path.join(ROOT, "tests", "data", "quirks.lh"),
+}
+
+
+def main():
+    oracle_py.build(ref=True)
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    tmp = os.path.join(out_dir, "_tmp")
+    os.makedirs(tmp, exist_ok=True)
+    s = synth.make_sample(24, 48, "chain", 5, seed=7, imperfect=1, n_del=1, n_dup=1)
+    lh, _ = s.write(tmp, "syn24")
+    cases = dict(CASES)
+    cases["syn24"] = lh
+    with open(os.path.join(out_dir, "syn24.lh"), "w") as f:
+        f.write(s.lh_text)
+    for name, path in cases.items():
+        d = oracle_py.ref_graph_dump(path)
+        assert d and d["ok"], (name, d)
+        with open(os.path.join(out_dir, "graph_%s.json" % name), "w") as f:
+            json.dump(d, f, indent=0, sort_keys=True)
+        print("wrote graph_%s.json: %d segs, %d juncs" % (name, len(d["segs"]), len(d["juncs"])))
+
+
+if __name__ == "__main__":
+    main()

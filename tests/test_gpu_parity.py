@@ -1,0 +1,133 @@
+"""GPU parity tests: the HIP engine (libambigram_hip.so, through the C ABI) against the CPU oracle on the same
+seeded inputs, plus size-independent properties at BASELINE.json's full sizes.  Bit-exact: integer/index work."""
+import numpy as np
+import pytest
+
+import engine_checks as ec
+from ambigram_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_backend_is_hip(hip_lib):
+    assert hip_lib.ambi_backend_name() == b"hip"
+
+
+def test_fixed_and_synthetic(hip_lib, oracle, workdir):
+    ec.check_fixed_and_synthetic(hip_lib, oracle, workdir, small_only=False)
+
+
+def test_search_budget(hip_lib, oracle, workdir):
+    ec.check_search_budget(hip_lib, oracle, workdir)
+
+
+def test_random_decompositions(hip_lib, oracle, workdir):
+    st = ec.check_random_decompositions(hip_lib, oracle, workdir, range(120), budget=2)
+    assert st["valid"] > 10 and st["none"] > 10, st
+
+
+def test_random_decompositions_default_budget(hip_lib, oracle, workdir):
+    ec.check_random_decompositions(hip_lib, oracle, workdir, range(200, 260))
+
+
+def test_edge_cases(hip_lib, oracle, workdir):
+    ec.check_edge_cases(hip_lib, oracle, workdir)
+
+
+def test_juncs_file(hip_lib, oracle, workdir):
+    ec.check_juncs_file(hip_lib, oracle, workdir)
+
+
+def test_batch_many_units(hip_lib, oracle, workdir):
+    ec.check_batch_many_units(hip_lib, oracle, workdir, 48)
+
+
+def test_config2_full_size_properties(hip_lib, oracle, workdir):
+    """BASELINE config 2 (256 seg / 512 junc), wide tier K=19: R = C(18,9) = 48 620 orders.
+    Properties that do not need the oracle at full size + one full oracle comparison."""
+    s = synth.make_sample(256, 512, "wide", 19, seed=2000)
+    lh, sols = s.write(workdir, "c2")
+    g = api.Graph(hip_lib, lh)
+    b = api.Batch(hip_lib)
+    b.add_chromosome_sol(g, 0, sols[0])
+    b.upload(); b.run(0); b.download()
+    r = b.unit_result(0)
+    assert r["status"] == 0 and r["num_orders"] == 48620 and r["n_nodes"] == 19
+    K = 19
+    orders = b.unit_orders(0, 0, r["num_orders"], K)
+    # every row is a permutation of 0..K-1
+    assert np.array_equal(np.sort(orders, axis=1), np.tile(np.arange(K, dtype=np.uint8), (len(orders), 1)))
+    # rows are strictly increasing in lexicographic order (the reference's DFS emits them that way)
+    a, bb = orders[:-1].astype(np.int16), orders[1:].astype(np.int16)
+    neq = a != bb
+    first = neq.argmax(axis=1)
+    assert neq.any(axis=1).all()
+    idx = np.arange(len(a))
+    assert (a[idx, first] < bb[idx, first]).all()
+    # every row respects the DAG (predecessors first)
+    pat, loop, succ = b.unit_dag(0, K)
+    pos = np.argsort(orders, axis=1)
+    for i in range(K):
+        for j in range(K):
+            if (int(succ[i]) >> j) & 1:
+                assert (pos[:, i] < pos[:, j]).all()
+    # path: copy-number profile of the path == targetCN of the planted decomposition (localhap.cpp:222-232)
+    path = b.unit_path(0, 0)
+    prep = b.unit_prepare(0, 256)
+    counts = np.bincount(np.abs(path), minlength=257)[1:257]
+    assert np.array_equal(counts, prep["target_cn"][1:])
+    # consecutive path vertices are reference adjacencies or fold-backs on one segment (perfect FBIs here)
+    d = np.abs(np.abs(path[1:]) - np.abs(path[:-1]))
+    same_strand = (path[1:] > 0) == (path[:-1] > 0)
+    assert ((d == 1) & same_strand | (d == 0) & ~same_strand).all()
+    # and the whole thing equals the oracle
+    oc = oracle.run_bfb(lh, sols, keep_orders=True)["chr"][0]
+    assert orders.tolist() == oc["orders"]
+    assert path.tolist() == oc["path"] and b.unit_path(0, 1).tolist() == oc["path_indel"]
+
+
+def test_config3_batch_1024x64(hip_lib, oracle, workdir):
+    """BASELINE config 3: 1024 independent 64-seg samples in one batch; oracle spot-check on a subset."""
+    graphs, b, samples = [], api.Batch(hip_lib), []
+    for i in range(1024):
+        s = synth.config_sample(3, i, tier=("chain", "wide", "mixed")[i % 3], K=(9, 9, 7)[i % 3])
+        lh, sols = s.write(workdir, "c3_%d" % i)
+        g = api.Graph(hip_lib, lh)
+        graphs.append(g)
+        b.add_chromosome_sol(g, 0, sols[0])
+        samples.append((lh, sols))
+    b.upload(); b.run(0); b.download()
+    for i in range(1024):
+        r = b.unit_result(i)
+        assert r["status"] == 0, (i, r)
+        p = b.unit_path(i, 0)
+        prep = b.unit_prepare(i, 64)
+        assert np.array_equal(np.bincount(np.abs(p), minlength=65)[1:65], prep["target_cn"][1:]), i
+    for i in range(0, 1024, 37):
+        oc = oracle.run_bfb(*samples[i])["chr"][0]
+        assert b.unit_path(i, 0).tolist() == oc["path"] and b.unit_path(i, 1).tolist() == oc["path_indel"], i
+        assert b.unit_out_juncs(i) == [tuple(x) for x in oracle.run_bfb(*samples[i])["out_juncs"]], i
+
+
+def test_config4_multichr_1024(hip_lib, oracle, workdir):
+    """BASELINE config 4: 1024 seg / 2048 junc, 8 chromosomes, translocation + PROP C2 (BFB-TRX)."""
+    import parity
+    s = synth.config_sample(4, 0, tier="chain", K=7)
+    lh, sols = s.write(workdir, "c4")
+    assert parity.compare(hip_lib, oracle, lh, sols) == []
+
+
+def test_pack_paths_matches_download(hip_lib, oracle, workdir):
+    import torch
+    b, graphs, expect = ec.check_batch_many_units(hip_lib, oracle, workdir, 9)
+    n = b.size()
+    lengths = torch.zeros(n, dtype=torch.int32, device="cuda")
+    cap = sum(len(e["path_indel"]) for e in expect) + 8
+    cells = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    b.pack_paths(1, lengths.data_ptr(), cells.data_ptr(), cap, total.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert lengths.cpu().tolist() == [len(e["path_indel"]) for e in expect]
+    flat = [v for e in expect for v in e["path_indel"]]
+    assert int(total.item()) == len(flat)
+    assert cells.cpu().tolist()[:len(flat)] == flat

@@ -1,0 +1,32 @@
+"""CPU-only: the engine's SPMD stage code (the source the HIP kernels instantiate), the packing, the result-blob
+layout and the C ABI, executed on the 1-thread host group, against the oracle."""
+import engine_checks as ec
+
+
+def test_backend_name(hostsim_lib):
+    assert hostsim_lib.ambi_backend_name() == b"hostsim"
+
+
+def test_fixed_and_synthetic(hostsim_lib, oracle, workdir):
+    ec.check_fixed_and_synthetic(hostsim_lib, oracle, workdir, small_only=False)
+
+
+def test_search_budget(hostsim_lib, oracle, workdir):
+    ec.check_search_budget(hostsim_lib, oracle, workdir)
+
+
+def test_random_decompositions(hostsim_lib, oracle, workdir):
+    st = ec.check_random_decompositions(hostsim_lib, oracle, workdir, range(120), budget=2)
+    assert st["valid"] > 10 and st["none"] > 10, st
+
+
+def test_edge_cases(hostsim_lib, oracle, workdir):
+    ec.check_edge_cases(hostsim_lib, oracle, workdir)
+
+
+def test_juncs_file(hostsim_lib, oracle, workdir):
+    ec.check_juncs_file(hostsim_lib, oracle, workdir)
+
+
+def test_batch_many_units(hostsim_lib, oracle, workdir):
+    ec.check_batch_many_units(hostsim_lib, oracle, workdir, 12)
