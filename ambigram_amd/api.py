@@ -91,6 +91,26 @@ def _declare(L):
 
 _LIBS = {}
 EXPORTS = []
+_RUNTIME = []
+
+
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7); if the engine pulled in the system copy first, a later `import torch` would load the bundled
+    copy as a second runtime and lose the GPU.  So when a torch wheel is installed, its runtime is loaded first and
+    the engine binds to it by SONAME; without torch the system ROCm runtime is used."""
+    if _RUNTIME:
+        return
+    _RUNTIME.append(None)
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                _RUNTIME[0] = C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        _RUNTIME[0] = None
 
 
 def load(path=None):
@@ -100,6 +120,8 @@ def load(path=None):
         if not os.path.exists(path):
             raise RuntimeError("ambigram_amd: %s not found -- build the HIP extension first "
                                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % path)
+        if os.path.basename(path) == os.path.basename(DEFAULT_LIB):
+            _preload_hip_runtime()
         L = C.CDLL(path)
         names = _declare(L)
         if not EXPORTS:

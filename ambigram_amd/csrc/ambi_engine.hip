@@ -271,6 +271,7 @@ class HipBackend : public Backend {
     struct Ev { const char* name; hipEvent_t a, b; };
     std::vector<Ev> evs_;
     int64_t last_needed_ = 0;
+    long timed_runs_ = 0;
 
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilvl_, d_ilvl_off_,
@@ -364,14 +365,20 @@ class HipBackend : public Backend {
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_;
     }
 
+    // Per-kernel HIP events on the run's stream.  A ring of kTimingSlots event sets lets a timed region of many runs be
+    // averaged without a host sync per run: run r records into slot r % kTimingSlots.
+    static constexpr int kTimingSlots = 64, kTimedKernels = 5;
     void tick(const char* name, size_t idx, bool begin) {
         if (!timing_) return;
-        if (idx >= evs_.size()) {
+        const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
+        const size_t at = slot * kTimedKernels + idx;
+        while (evs_.size() <= at) {
             Ev e{name, nullptr, nullptr};
             (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
             evs_.push_back(e);
         }
-        (void)hipEventRecord(begin ? evs_[idx].a : evs_[idx].b, stream_);
+        evs_[at].name = name;
+        (void)hipEventRecord(begin ? evs_[at].a : evs_[at].b, stream_);
     }
 
     int launch_front() {   // prepare + plan
@@ -421,6 +428,7 @@ class HipBackend : public Backend {
         HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
         ran_ = true;
+        if (timing_) timed_runs_++;
         return 0;
     }
 
@@ -475,12 +483,19 @@ class HipBackend : public Backend {
             if (rc) return rc;
             *h_npending_ = 0;
         }
-        if (timing_) {
+        if (timing_ && timed_runs_ > 0) {
+            // average per kernel over the slots filled since timing was switched on
+            const long filled = timed_runs_ < kTimingSlots ? timed_runs_ : kTimingSlots;
             times_.clear();
-            for (auto& e : evs_) {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) ms = -1;
-                times_.push_back({e.name, ms});
+            for (int k = 0; k < kTimedKernels; k++) {
+                double sum = 0; int cnt = 0; const char* nm = "";
+                for (long s = 0; s < filled; s++) {
+                    size_t at = (size_t)s * kTimedKernels + k;
+                    if (at >= evs_.size()) continue;
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, evs_[at].a, evs_[at].b) == hipSuccess) { sum += ms; cnt++; nm = evs_[at].name; }
+                }
+                times_.push_back({nm, cnt ? (float)(sum / cnt) : -1.0f});
             }
         }
         return 0;
@@ -516,7 +531,7 @@ class HipBackend : public Backend {
         HIP_CK(hipMemcpy(out, d_dags_ + unit, sizeof(Dag), hipMemcpyDeviceToHost));
         return 0;
     }
-    void set_timing(bool on) override { timing_ = on; }
+    void set_timing(bool on) override { timing_ = on; timed_runs_ = 0; }
     const std::vector<KernelTime>& kernel_times() override { return times_; }
     int64_t order_bytes_written() const override { return last_needed_; }
 };

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- BFB reconstructions/sec on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole post-.sol reconstruction pipeline (SURVEY.md 8a #7,#8,#11-#16,#20: getJuncCN,
+bias, getIndelBias, targetCN, constructDAG, allTopologicalOrders, getBFB+imperfectFBI, indelBFB, output junctions)
+over one batch of synthetic units that is already resident in HBM, followed by the end-of-batch packing of the paths
+and -- for N > 1 -- the single RCCL gather of path lengths + paths to rank 0.
+
+Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted on: synthetic
+256-segment / 512-junction .lh samples, wide DAG tier K=19 (R = C(18,9) = 48 620 topological orders per sample),
+default CLI mode (first valid order).  Every rank holds its own batch of `--batch` samples (weak scaling); the ILP
+solve is replaced by the planted .sol exactly as SURVEY.md 8c/8d prescribes.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="samples (units) per GPU")
+    ap.add_argument("--segs", type=int, default=256)
+    ap.add_argument("--juncs", type=int, default=512)
+    ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])
+    ap.add_argument("--K", type=int, default=19)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
+    ap.add_argument("--tile-bytes", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from ambigram_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib = api.load()                       # the HIP engine; raises if it has not been built (no CPU fallback)
+    lib.ambi_set_device(local_rank)
+
+    # ---- workload: B samples per rank, seeds as SURVEY.md 8d (seed = 1000*config + sample index) ----
+    B = args.batch
+    tmp = tempfile.mkdtemp(prefix="ambi_bench_")
+    graphs, files = [], []
+    batch = api.Batch(lib)
+    batch.configure(tile_bytes=args.tile_bytes)
+    for i in range(B):
+        s = synth.make_sample(args.segs, args.juncs, args.tier, args.K, seed=1000 * 2 + rank * B + i)
+        lh, sols = s.write(tmp, "s%d" % i)
+        g = api.Graph(lib, lh)
+        graphs.append(g)
+        batch.add_chromosome_sol(g, 0, sols[0])
+        files.append((lh, sols))
+    batch.upload()                         # inputs now resident in HBM
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # one untimed pass to size the order arena and the gather buffers
+    batch.run(0, stream); batch.wait(); batch.download()
+    res = [batch.unit_result(u) for u in range(B)]
+    bad = [r for r in res if r["status"] != 0]
+    if bad:
+        raise SystemExit("bench: %d units did not reconstruct: %r" % (len(bad), bad[0]))
+    total_cells = sum(r["path_indel_len"] for r in res)
+    cell_cap = total_cells
+    if world > 1:
+        t = torch.tensor([cell_cap], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cell_cap = int(t.item())
+    lengths = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cells = torch.zeros(max(cell_cap, 1), dtype=torch.int32, device="cuda")
+    tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    if world > 1:
+        lengths_all = torch.zeros(B * world, dtype=torch.int32, device="cuda")
+        gather_list = [torch.zeros_like(cells) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        batch.run(0, stream)
+        batch.pack_paths(1, lengths.data_ptr(), cells.data_ptr(), cell_cap, tot.data_ptr(), stream)
+        if world > 1:   # the single end-of-batch exchange: path lengths, then the concatenated int32 paths
+            dist.all_gather_into_tensor(lengths_all, lengths)
+            dist.gather(cells, gather_list, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    batch.wait()
+    torch.cuda.synchronize()
+    batch.set_timing(True)                 # HIP events around every kernel, on the stream the kernels run on
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    batch.wait()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ktimes = batch.kernel_times()
+    batch.set_timing(False)
+
+    # sanity: the packed payload of the last step equals the downloaded paths
+    batch.download()
+    assert int(tot.item()) == total_cells
+    l_host = lengths.cpu().tolist()
+    assert l_host == [batch.unit_result(u)["path_indel_len"] for u in range(B)]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    units_total = B * world
+    value = units_total * args.steps / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- algorithmic bytes: B = 8n + 24m + 16K + 2RK + 4EL + 4P per unit, split per kernel ----
+    n, m = args.segs, None
+    per_kernel = {"ambi_prepare_kernel": 0, "ambi_plan_kernel": 0, "ambi_enumerate_kernel": 0, "ambi_first_kernel": 0, "ambi_finish_kernel": 0}
+    formula = 0
+    for u, r in enumerate(res):
+        mj = graphs[u].n_junc
+        K, R, E, L, P, P2 = r["n_nodes"], r["num_orders"], r["evaluated"], r["bkp_len"], r["path_len"], r["path_indel_len"]
+        per_kernel["ambi_prepare_kernel"] += 8 * n + 24 * mj + 16 * K
+        per_kernel["ambi_plan_kernel"] += 64
+        per_kernel["ambi_enumerate_kernel"] += R * K                 # every order written once
+        per_kernel["ambi_first_kernel"] += E * K + 2 * E * L         # orders read until the first valid one, bkp written
+        per_kernel["ambi_finish_kernel"] += 2 * L + 4 * P + 4 * P2   # bkp read, path + edited path written
+        formula += 8 * n + 24 * mj + 16 * K + 2 * R * K + 4 * E * L + 4 * P
+    dom = max(ktimes, key=lambda k: ktimes[k]) if ktimes else "ambi_enumerate_kernel"
+    dom_ms = ktimes.get(dom, float("nan"))
+    achieved = per_kernel.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("workload") == "%d/%d/%s/K%d" % (args.segs, args.juncs, args.tier, args.K):
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                "algorithmic_bytes_per_launch": per_kernel.get(dom, 0), "kernel_ms": dom_ms,
+                "all_kernels_ms": ktimes,
+                "pipeline_bytes_per_step": formula,
+                "pipeline_GBps": formula / (dt / args.steps) / 1e9}
+
+    # ---- CPU baseline: the oracle (a single-thread port of the reference path) on this box's host cores ----
+    cpu = None
+    if args.cpu_seconds > 0:
+        from oracle import oracle_py
+        oracle_py.build(ref=False)
+        spent, recon, whole, cnt = 0.0, 0.0, 0.0, 0
+        t_start = time.perf_counter()
+        for (lh, sols) in files:
+            r = oracle_py.run_bfb(lh, sols)
+            assert r["ok"]
+            # the oracle doubles as a last parity check on the benchmarked inputs
+            assert r["chr"][0]["path_indel"] == batch.unit_path(cnt, 1).tolist(), "parity lost on bench sample %d" % cnt
+            recon += r["recon_seconds"]; whole += r["seconds"]; cnt += 1
+            spent = time.perf_counter() - t_start
+            if spent > args.cpu_seconds:
+                break
+        cpu = {"value": cnt / recon if recon > 0 else None, "unit": "reconstructions/s", "cores": 1, "kind": "port",
+               "sample": "%d of the %d benchmarked samples, stages #7,#8,#11-#16,#20 only (%.2f s); whole oracle run incl. .lh "
+                         "parse and the variableIdx map: %.1f /s" % (cnt, B, recon, cnt / whole if whole > 0 else 0),
+               "host_cores_available": os.cpu_count()}
+
+    out = {
+        "metric": "BFB reconstructions/sec (synthetic .lh, 256 seg) at 1/2/4/8 MI355X",
+        "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/int16 (order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
+        "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, default CLI mode; %d samples per GPU resident in HBM"
+                               % (args.segs, args.juncs, args.tier, args.K, B),
+                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), one RCCL gather per step" % world},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,7 @@
 #include "bfb_oracle.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -613,7 +614,12 @@ void expandBkp(const std::vector<int>& bkp, std::vector<int>& path) {   // LGM.c
 std::string formatPath(const Graph& g, const std::vector<int>& path) {   // LGM.cpp:3411-3429
     std::string s;
     auto info = [](int v) { return std::to_string(std::abs(v)) + (v > 0 ? "+" : "-"); };
-    auto chr = [&](int v) { for (auto& sg : g.segs) if (sg.id == std::abs(v)) return sg.chrId; return -2; };
+    auto chr = [&](int v) {   // ids are 1..N in file order on every supported input; fall back to the scan otherwise
+        int id = std::abs(v);
+        if (id >= 1 && id <= (int)g.segs.size() && g.segs[id - 1].id == id) return g.segs[id - 1].chrId;
+        for (auto& sg : g.segs) if (sg.id == id) return sg.chrId;
+        return -2;
+    };
     for (size_t i = 1; i < path.size(); i++) {
         s += info(path[i - 1]);
         if (chr(path[i - 1]) != chr(path[i])) s += "||";
@@ -906,11 +912,13 @@ RunResult runBfb(const RunOptions& opt) {
         int numPat = 0;
         std::map<std::string, int> variableIdx = makeVariableIdx(startID, endID, &numPat);
         int numComp = (int)variableIdx.size();
+        auto tA = std::chrono::steady_clock::now();
         Inversions inversions;
         getJuncCN(g, startID, endID, inversions, st.juncCN);
         R.numInv += (int)inversions.size();
         st.bias = computeBias(g, startID, endID, inversions, st.juncCN);
         getIndelBias(g, startID, endID);
+        R.reconSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tA).count();
         for (auto& s : g.segs) st.segCNAfterIndelBias.push_back(s.cn);
         {
             std::vector<std::pair<int, int>> iv(inversions.begin(), inversions.end());
@@ -950,6 +958,7 @@ RunResult runBfb(const RunOptions& opt) {
             R.chr.push_back(st);
             continue;
         }
+        auto tB = std::chrono::steady_clock::now();
         for (auto iter = variableIdx.begin(); iter != variableIdx.end(); iter++) {   // localhap.cpp:222-232
             if (elementCN[iter->second] > 0) {
                 const std::string& key = iter->first;
@@ -968,11 +977,16 @@ RunResult runBfb(const RunOptions& opt) {
         if (opt.keepOrders) st.orders = orders;
         std::vector<int> path = st.bfb.path;
         st.indelPrinted = indelBFB(g, path, startID, endID, R.log);
+        R.reconSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count();
         st.pathAfterIndel = path;
         R.paths.push_back(path);
         R.chr.push_back(st);
     }
-    for (auto& p : R.paths) { R.pathLen += (int)p.size(); synthesizeOutputJuncs(p, R.outJuncs, true); }
+    {
+        auto tC = std::chrono::steady_clock::now();
+        for (auto& p : R.paths) { R.pathLen += (int)p.size(); synthesizeOutputJuncs(p, R.outJuncs, true); }
+        R.reconSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tC).count();
+    }
     for (auto& s : g.segs) {   // localhap.cpp:290-293 (int accumulators fed with doubles)
         R.cnSum += s.cn;
         R.maxCN = (R.maxCN > s.cn) ? R.maxCN : s.cn;

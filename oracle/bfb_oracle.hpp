@@ -176,6 +176,7 @@ struct RunResult {
     std::vector<int> targetCN;
     int pathLen = 0, cnSum = 0, maxCN = 0, numInv = 0;
     double ilpError = 0;
+    double reconSeconds = 0;   // wall time of stages #7,#8,#11-#16,#20 only (the region the GPU step covers)
 };
 RunResult runBfb(const RunOptions& opt);
 

@@ -71,7 +71,7 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
     o << "],\"paths\":"; jarr2(o, R.paths);
     o << ",\"trx_run\":" << (R.trxRun ? "true" : "false") << ",\"trx_path\":"; jarr(o, R.trxPath);
     o << ",\"target_cn\":"; jarr(o, R.targetCN);
-    o << ",\"path_len\":" << R.pathLen << ",\"cn_sum\":" << R.cnSum << ",\"max_cn\":" << R.maxCN << ",\"num_inv\":" << R.numInv;
+    o << ",\"recon_seconds\":" << R.reconSeconds << ",\"path_len\":" << R.pathLen << ",\"cn_sum\":" << R.cnSum << ",\"max_cn\":" << R.maxCN << ",\"num_inv\":" << R.numInv;
     o << ",\"out_juncs\":[";
     for (size_t i = 0; i < R.outJuncs.size(); i++) { if (i) o << ','; o << '[' << R.outJuncs[i].u << ',' << R.outJuncs[i].v << ',' << R.outJuncs[i].count << ']'; }
     o << "],\"chr\":[";
