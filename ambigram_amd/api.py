@@ -281,8 +281,8 @@ class Batch:
         self.lib.ambi_batch_size(self.h, C.byref(n))
         return n.value
 
-    def configure(self, order_arena_bytes=-1, ideal_cap=0, first_budget=0, tile_bytes=0):
-        self._ck(self.lib.ambi_batch_configure(self.h, order_arena_bytes, ideal_cap, first_budget, tile_bytes), "configure")
+    def configure(self, order_arena_bytes=-1, ideal_cap=0, first_budget=0, target_lanes=0):
+        self._ck(self.lib.ambi_batch_configure(self.h, order_arena_bytes, ideal_cap, first_budget, target_lanes), "configure")
 
     def upload(self):
         self._ck(self.lib.ambi_batch_upload(self.h), "upload")
@@ -402,7 +402,7 @@ def merge_out_juncs(acc, unit_list, increase=True):
 
 
 def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, first_budget=0, order_arena_bytes=-1,
-                       tile_bytes=0, keep_orders=False):
+                       target_lanes=0, keep_orders=False):
     """Host-side mirror of `Ambigram --op bfb` (localhap.cpp:49-388) with the external `cbc` call replaced by the given
     .sol files (one per chromosome that reaches the ILP, in order).  Returns a dict shaped like the oracle's dump."""
     g = Graph(lib, lh)
@@ -412,7 +412,7 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
         g.read_juncs(juncs)
         log += g.log()[n_log0:]
     b = Batch(lib)
-    b.configure(order_arena_bytes=order_arena_bytes, first_budget=first_budget, tile_bytes=tile_bytes)
+    b.configure(order_arena_bytes=order_arena_bytes, first_budget=first_budget, target_lanes=target_lanes)
     # a chromosome reaches the ILP unless it has no fold-back inversion; the engine decides (status SHORTCUT), so the
     # caller hands a .sol to every chromosome for which one exists, consuming them in order for non-shortcut units.
     # To know which chromosomes are shortcuts before assigning .sol files, run a solution-less probe batch first.

@@ -86,19 +86,26 @@ struct BatchArgs {
     int32_t n_units;
     uint32_t flags;
     int32_t first_budget;        // orders the first-valid kernel tries per orientation before declaring PENDING
-    int32_t tile_bytes;          // LDS bytes of one wave's order tile in the enumerate kernel
+    int32_t target_lanes;        // enumerate kernel: lanes to spread the rows of the batch over (sets rows per lane)
+    int32_t enum_stack_lds;      // enumerate kernel: LDS bytes per wave for the per-lane DFS stacks
+    int32_t enum_auto_lds;       // enumerate kernel: LDS bytes per wave for the compact automaton copy
     const UnitIn* units;
     const double* seg_cn;
     const Junction* juncs;
     const Element* elems;
     Dag* dags;                   // [U]
     uint8_t* results;            // result blob; UnitOut[U] at the front
-    // ideal tables (pools indexed by UnitIn::ideal_off)
-    uint64_t* ideal_keys;
-    uint64_t* ideal_cnt;
-    int32_t* ideal_lvl;
-    int32_t* ideal_lvl_off;      // [U][kMaxNodes+2]
-    int32_t* ideal_counter;      // [U]
+    // ideal tables (pools indexed by UnitIn::ideal_off; cap = UnitIn::ideal_cap slots per unit)
+    uint64_t* ideal_keys;        // [slots]
+    uint64_t* ideal_cnt;         // [slots]
+    int32_t* ideal_pos;          // [slots]
+    int32_t* ideal_lvl;          // [slots/2]
+    int32_t* ideal_lvl_off;      // [U][kMaxNodes+3]
+    int32_t* ideal_counter;      // [U][2]
+    uint64_t* auto_avail;        // [slots/2]
+    uint64_t* auto_cnt;          // [slots/2]
+    int32_t* auto_cbase;         // [slots/2 + U]
+    uint16_t* auto_child;        // [U * 4 * ideal_cap]
     // order table
     uint8_t* order_arena;
     int64_t order_arena_bytes;

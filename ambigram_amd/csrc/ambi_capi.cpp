@@ -175,7 +175,7 @@ int ambi_batch_size(const ambi_batch_t* b, int32_t* n_units) {
     *n_units = (int32_t)b->hb.units.size();
     return 0;
 }
-int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t tile_bytes) {
+int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t target_lanes) {
     if (!b) return AMBI_ERR_ARG;
     if (b->uploaded) return AMBI_ERR_STATE;
     if (order_arena_bytes >= 0) b->cfg.order_arena_bytes = order_arena_bytes;
@@ -185,7 +185,7 @@ int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ide
         b->hb.ideal_cap = c;
     }
     if (first_budget > 0) b->cfg.first_budget = first_budget;
-    if (tile_bytes >= 64) b->cfg.tile_bytes = tile_bytes;
+    if (target_lanes >= 64) b->cfg.target_lanes = target_lanes;
     return 0;
 }
 int ambi_batch_upload(ambi_batch_t* b) {

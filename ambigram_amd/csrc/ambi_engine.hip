@@ -67,11 +67,20 @@ __device__ inline int64_t block_exscan_i64(int64_t v, int64_t* total, int64_t* s
 // Parallel form of plan_serial (ambi_stages.hpp): same prefix-sum semantics.
 __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     __shared__ int64_t sh[17];
+    // pass 1: rows of the whole batch -> rows per lane of the enumerate kernel
+    int64_t my_rows = 0;
+    for (int u = threadIdx.x; u < A.n_units; u += blockDim.x) {
+        const UnitOut* o = unit_out(A.results, u);
+        if (o->status == ST_OK && o->num_orders < (int64_t)kCountSat) my_rows += o->num_orders;
+    }
+    int64_t total_rows;
+    (void)block_exscan_i64(my_rows, &total_rows, sh);
+    const int TL = rows_per_lane_for(total_rows, A.target_lanes);
     int64_t off_carry = 0, blk_carry = 0;
     for (int base = 0; base < A.n_units; base += blockDim.x) {
         const int u = base + (int)threadIdx.x;
         int64_t bytes = 0, blocks = 0;
-        int T = 1;
+        const int T = TL;
         bool live = false, toobig = false;
         UnitOut* out = nullptr;
         if (u < A.n_units) {
@@ -82,8 +91,7 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
                 if (R >= (int64_t)kCountSat) toobig = true;
                 else {
                     live = true;
-                    bytes = (R * K + 15) & ~int64_t(15);
-                    T = rows_per_lane_for(K, A.tile_bytes);
+                    bytes = order_bytes(R, K);
                     blocks = (R + 64ll * T - 1) / (64ll * T);
                 }
             }
@@ -111,16 +119,20 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     }
 }
 
-// LDS per wave: [tile_bytes] rows | [64*64] per-lane current order, transposed (ord[d*64 + lane]) | [64] pred masks
+// One wavefront per work block of 64*T consecutive ranks of one unit.  Lane l unranks rank base + l*T from the
+// automaton and walks T lexicographic successors; rows leave the registers as 16-byte stores (4 rows per group), so
+// every byte of the table is written exactly once and nothing is staged through an LDS tile.
+// LDS per wave: [enum_stack_lds] per-lane DFS stacks (depth-major) | [enum_auto_lds] compact copy of the unit's
+// automaton (avail masks, child bases, child links) when it fits, else the automaton is read through L2.
 __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    const int wave_bytes = A.tile_bytes + 64 * 64 + 64 * 8;
-    uint8_t* wbase = ambi_lds + (size_t)wave * wave_bytes;
-    uint8_t* tile = wbase;
-    uint8_t* ord = wbase + A.tile_bytes;
-    uint64_t* pred = reinterpret_cast<uint64_t*>(wbase + A.tile_bytes + 64 * 64);
+    const int wave_bytes = A.enum_stack_lds + A.enum_auto_lds;
+    uint8_t* stacks = ambi_lds + (size_t)wave * wave_bytes;
+    uint8_t* amem = stacks + A.enum_stack_lds;
     WaveGroup g;
     const int64_t total = A.blk_off[A.n_units];
+    int staged_unit = -1;
+    bool in_lds = false;
     for (int64_t b = (int64_t)blockIdx.x * wpb + wave; b < total; b += (int64_t)gridDim.x * wpb) {
         int lo = 0, hi = A.n_units;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
@@ -129,21 +141,39 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
         const int K = out->K, T = A.rows_per_lane[u];
         const int64_t R = out->num_orders;
         const int64_t base_rank = (b - A.blk_off[u]) * 64ll * T;
-        if (lane < K) pred[lane] = A.dags[u].pred[lane];
-        g.sync();
-        IdealTable tbl = unit_ideal_table(A, u);
-        enumerate_lane(pred, K, tbl, R, base_rank + (int64_t)lane * T, T, ord + lane, 64, tile + (size_t)lane * T * K);
-        g.sync();
-        int64_t rows = R - base_rank;
-        if (rows > 64ll * T) rows = 64ll * T;
-        const int64_t nbytes = rows * K;
-        uint8_t* dst = A.order_arena + out->order_off + base_rank * K;   // 16-byte aligned: order_off%16==0, 64*T*K%16==0
-        const int64_t nvec = nbytes >> 4;
-        const uint4* src4 = reinterpret_cast<const uint4*>(tile);
-        uint4* dst4 = reinterpret_cast<uint4*>(dst);
-        for (int64_t i = lane; i < nvec; i += 64) dst4[i] = src4[i];
-        for (int64_t i = (nvec << 4) + lane; i < nbytes; i += 64) dst[i] = tile[i];
-        g.sync();
+        const IdealTable tbl = unit_ideal_table(A, u);
+        const AutoView V = auto_view(tbl);
+        const int nI = V.nI, nC = tbl.counter[1];
+        const bool wide = K > 32;
+        const int msz = wide ? 8 : 4;
+        uint8_t* av_l = amem;
+        uint16_t* cb_l = reinterpret_cast<uint16_t*>(amem + (size_t)nI * msz);
+        uint16_t* ch_l = cb_l + nI;
+        if (u != staged_unit) {
+            g.sync();
+            const int64_t need = (int64_t)nI * (msz + 2) + 2ll * nC + 16;
+            in_lds = need <= A.enum_auto_lds && nC < 65536;
+            if (in_lds) {
+                for (int i = lane; i < nI; i += 64) {
+                    if (wide) reinterpret_cast<uint64_t*>(av_l)[i] = V.avail[i];
+                    else reinterpret_cast<uint32_t*>(av_l)[i] = (uint32_t)V.avail[i];
+                    cb_l[i] = (uint16_t)V.cbase[i];
+                }
+                for (int i = lane; i < nC; i += 64) ch_l[i] = V.child[i];
+            }
+            staged_unit = u;
+            g.sync();
+        }
+        uint8_t* rows = A.order_arena + out->order_off;   // 16-byte aligned; lane ranges start at multiples of 4 rows
+        const int64_t first = base_rank + (int64_t)lane * T;
+        if (in_lds) {
+            LdsAuto<uint32_t> a32{reinterpret_cast<const uint32_t*>(av_l), cb_l, ch_l};
+            LdsAuto<uint64_t> a64{reinterpret_cast<const uint64_t*>(av_l), cb_l, ch_l};
+            enumerate_lane_dispatch(a32, a64, V, K, R, first, T, stacks, lane, 64, rows);
+        } else {
+            GlobalAuto ga{V};
+            enumerate_lane_dispatch(ga, ga, V, K, R, first, T, stacks, lane, 64, rows);
+        }
     }
 }
 
@@ -261,6 +291,8 @@ class HipBackend : public Backend {
     UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; Element* d_elems_ = nullptr;
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; int32_t* d_ilvl_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
+    int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
+    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096;
     uint8_t* d_arena_ = nullptr; int64_t arena_bytes_ = 0;
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
@@ -275,7 +307,8 @@ class HipBackend : public Backend {
 
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilvl_, d_ilvl_off_,
-                        d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_};
+                        d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_,
+                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
@@ -316,7 +349,12 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_icnt_, (size_t)hb.ideal_slots))) return rc;
         if ((rc = dalloc(&d_ilvl_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
         if ((rc = dalloc(&d_ilvl_off_, U * (kMaxNodes + 3)))) return rc;
-        if ((rc = dalloc(&d_icounter_, U))) return rc;
+        if ((rc = dalloc(&d_icounter_, 2 * U))) return rc;
+        if ((rc = dalloc(&d_ipos_, (size_t)hb.ideal_slots))) return rc;
+        if ((rc = dalloc(&d_aavail_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
+        if ((rc = dalloc(&d_acnt_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
+        if ((rc = dalloc(&d_acbase_, (size_t)hb.ideal_slots / 2 + U + 1))) return rc;
+        if ((rc = dalloc(&d_achild_, (size_t)hb.ideal_slots * 4 + 8))) return rc;
         if ((rc = dalloc(&d_blk_off_, U + 1))) return rc;
         if ((rc = dalloc(&d_rows_, U))) return rc;
         if ((rc = dalloc(&d_npending_, 1))) return rc;
@@ -338,7 +376,8 @@ class HipBackend : public Backend {
         lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
         lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
         lds_finish_ = (int)finish_work_bytes(hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
-        lds_enum_ = 4 * (cfg.tile_bytes + 64 * 64 + 64 * 8);
+        enum_stack_lds_ = (int)(hb.max_k > 32 ? enum_stack_bytes<uint64_t>(hb.max_k) : enum_stack_bytes<uint32_t>(hb.max_k > 0 ? hb.max_k : 1));
+        lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         const int kLdsLimit = 160 * 1024 - 1024;
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
@@ -356,7 +395,9 @@ class HipBackend : public Backend {
 
     void bind(uint32_t flags) {
         A_.n_units = (int32_t)hb_.units.size();
-        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.tile_bytes = cfg_.tile_bytes;
+        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
+        A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
+        A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
         A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_lvl = d_ilvl_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
@@ -524,7 +565,11 @@ class HipBackend : public Backend {
         UnitOut h;
         HIP_CK(hipMemcpy(&h, d_results_ + sizeof(UnitOut) * (size_t)unit, sizeof(UnitOut), hipMemcpyDeviceToHost));
         if (h.order_off < 0 || first < 0 || first + count > h.num_orders) return ST_ERR_BAD_INPUT;
-        HIP_CK(hipMemcpy(out, d_arena_ + h.order_off + first * h.K, (size_t)(count * h.K), hipMemcpyDeviceToHost));
+        // rows are Kpad bytes apart on the device; the caller gets count x K
+        const int stride = row_stride(h.K);
+        std::vector<uint8_t> tmp((size_t)(count * stride));
+        HIP_CK(hipMemcpy(tmp.data(), d_arena_ + h.order_off + first * stride, tmp.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < count; r++) memcpy(out + r * h.K, tmp.data() + r * stride, (size_t)h.K);
         return 0;
     }
     int copy_dag(int unit, Dag* out) override {

@@ -5,12 +5,16 @@
 // of the DAG in LEXICOGRAPHIC order of their node sequences and stores all R of them (R x K ints).
 //
 // MI355X design: instead of one serial DFS the engine
-//   1. builds the lattice of order ideals (down-sets) of the DAG by level-synchronous frontier expansion and
-//      counts, for every ideal I, the number cnt[I] of ways to complete it  (ideal_build / ideal_count),
-//   2. gives every lane a contiguous block of ranks: the lane UNRANKS its first order from the counts
-//      (order_unrank) and then steps through its block with the lexicographic successor (order_next),
-//   3. stages rows through LDS and writes the R x K uint8 table with coalesced stores (kernel side).
-// The table is byte-identical to the reference's `orders` vector (row r = r-th order the reference pushes).
+//   1. builds the lattice of order ideals (down-sets) of the DAG by level-synchronous frontier expansion (hash set
+//      with atomicCAS, one frontier per level) and counts, for every ideal I, the number cnt[I] of ways to complete
+//      it; the lattice is then frozen into a small AUTOMATON: per ideal index its available-node mask, its
+//      completion count and the indices of its children  (ideal_build_and_count),
+//   2. gives every lane a contiguous block of ranks: the lane UNRANKS its first order by walking the automaton
+//      (order_unrank) and then steps through its block with the lexicographic successor, keeping the current row
+//      packed in registers and per-depth (ideal, avail, node) stacks in LDS  (enumerate_rows),
+//   3. writes the R x Kpad uint8 table with 16-byte stores straight from registers (4 rows per store group).
+// Row r of the table = r-th order the reference pushes; columns K..Kpad-1 are 0xFF padding (Kpad = K rounded up
+// to a multiple of 4 so that rows are dword aligned).
 #pragma once
 #include "ambi_common.hpp"
 #include "ambi_group.hpp"
@@ -19,6 +23,10 @@ namespace ambi {
 
 constexpr uint64_t kEmptyKey = ~0ull;     // K <= 63, so no ideal mask equals this
 constexpr uint64_t kCountSat = 1ull << 62;
+
+// Kpad: bytes per row of the order table (a multiple of 4; coarser buckets above 32 nodes keep the number of
+// enumerate-kernel instantiations small)
+AMBI_HD int row_stride(int K) { return K <= 32 ? ((K + 3) & ~3) : (K <= 48 ? 48 : 64); }
 
 // ---- atomics usable from both builds ----
 AMBI_HD uint64_t atomic_cas_u64(uint64_t* p, uint64_t expected, uint64_t desired) {
@@ -38,12 +46,15 @@ AMBI_HD int atomic_add_i32(int* p, int v) {
 #endif
 }
 
+AMBI_HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+AMBI_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
+
 // nodes that may be appended to the ideal I: not in I, all predecessors in I
 AMBI_HD uint64_t avail_mask(const uint64_t* pred, int K, uint64_t I) {
     uint64_t rem = ~I & (K >= 64 ? ~0ull : ((1ull << K) - 1));
     uint64_t out = 0;
     while (rem) {
-        int v = __builtin_ctzll(rem);
+        int v = ctz64(rem);
         rem &= rem - 1;
         if ((pred[v] & ~I) == 0) out |= (1ull << v);
     }
@@ -55,15 +66,31 @@ AMBI_HD uint32_t hash_mask(uint64_t k) {
     return (uint32_t)k;
 }
 
-// Ideal table of one unit: open addressing, capacity `cap` (power of two).
+// Ideal table of one unit (global memory).  Hash part: open addressing, capacity `cap` (power of two).
+// Automaton part: ideals numbered 0..nI-1 in discovery (level) order, 0 = empty ideal.
 struct IdealTable {
-    uint64_t* keys;    // [cap]   ideal masks, kEmptyKey = free
-    uint64_t* cnt;     // [cap]   completions of the ideal
-    int32_t* lvl;      // [cap/2] slots in discovery order, level by level
-    int32_t* lvl_off;  // [kMaxNodes + 2]
-    int32_t* counter;  // [1] number of discovered ideals
-    int cap;
+    uint64_t* keys;      // [cap]    ideal masks, kEmptyKey = free
+    uint64_t* cnt;       // [cap]    completions of the ideal (by hash slot)
+    int32_t* pos;        // [cap]    hash slot -> ideal index
+    int32_t* lvl;        // [cap/2]  ideal index -> hash slot
+    int32_t* lvl_off;    // [kMaxNodes + 3]
+    int32_t* counter;    // [2]      number of ideals, number of child links
+    uint64_t* a_avail;   // [cap/2]  available-node mask per ideal index
+    uint64_t* a_cnt;     // [cap/2]  completion count per ideal index
+    int32_t* a_cbase;    // [cap/2+1] first child link per ideal index
+    uint16_t* a_child;   // [child_cap] child ideal indices, ascending node order
+    int cap, child_cap;
 };
+
+// read-only view of the automaton
+struct AutoView {
+    const uint64_t* avail;
+    const uint64_t* cnt;
+    const int32_t* cbase;
+    const uint16_t* child;
+    int nI;
+};
+AMBI_HD AutoView auto_view(const IdealTable& T) { return AutoView{T.a_avail, T.a_cnt, T.a_cbase, T.a_child, T.counter[0]}; }
 
 AMBI_HD int ideal_lookup(const IdealTable& T, uint64_t key) {
     uint32_t h = hash_mask(key) & (uint32_t)(T.cap - 1);
@@ -93,7 +120,7 @@ AMBI_HD int ideal_insert(const IdealTable& T, uint64_t key, bool* fresh) {
     return -1;
 }
 
-// Level-synchronous frontier expansion over the ideal lattice + backward count.  SPMD over group g.
+// Level-synchronous frontier expansion over the ideal lattice + backward count + automaton.  SPMD over group g.
 // Returns status; *R_out = number of topological orders (saturated at 2^62).
 template <class G>
 AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const IdealTable& T, uint64_t* R_out) {
@@ -103,7 +130,7 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
     if (g.tid() == 0) {
         bool fresh;
         int s = ideal_insert(T, 0ull, &fresh);
-        T.lvl[0] = s; T.lvl_off[0] = 0; T.lvl_off[1] = 1; *T.counter = 1;
+        T.lvl[0] = s; T.pos[s] = 0; T.lvl_off[0] = 0; T.lvl_off[1] = 1; T.counter[0] = 1; T.counter[1] = 0;
     }
     g.sync();
     int overflow = 0;
@@ -115,21 +142,22 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
             uint64_t I = T.keys[T.lvl[idx]];
             uint64_t av = avail_mask(pred, K, I);
             while (av) {
-                int v = __builtin_ctzll(av);
+                int v = ctz64(av);
                 av &= av - 1;
                 bool fresh;
                 int s = ideal_insert(T, I | (1ull << v), &fresh);
                 if (s < 0) { overflow = 1; break; }
                 if (fresh) {
-                    int pos = atomic_add_i32(T.counter, 1);
-                    if (pos >= maxIdeals) { overflow = 1; break; }
-                    T.lvl[pos] = s;
+                    int p = atomic_add_i32(T.counter, 1);
+                    if (p >= maxIdeals || p >= 65535) { overflow = 1; break; }
+                    T.lvl[p] = s;
+                    T.pos[s] = p;
                 }
             }
         }
         g.sync();
         if (g.any(overflow != 0)) return ST_ERR_IDEALS_CAPACITY;
-        if (g.tid() == 0) T.lvl_off[d + 2] = *T.counter;
+        if (g.tid() == 0) T.lvl_off[d + 2] = T.counter[0];
         g.sync();
         last_level = d + 1;
     }
@@ -149,7 +177,7 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
             uint64_t av = avail_mask(pred, K, I);
             uint64_t c = 0;
             while (av) {
-                int v = __builtin_ctzll(av);
+                int v = ctz64(av);
                 av &= av - 1;
                 int s = ideal_lookup(T, I | (1ull << v));
                 if (s >= 0) { c += T.cnt[s]; if (c > kCountSat) c = kCountSat; }
@@ -158,23 +186,61 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
         }
         g.sync();
     }
-    int s0 = ideal_lookup(T, 0ull);
-    *R_out = (s0 >= 0) ? T.cnt[s0] : 0;
+    // automaton: avail / count / child links per ideal index
+    const int nI = T.counter[0];
+    int carry = 0;
+    for (int base = 0; base < nI; base += g.size()) {
+        int p = base + g.tid();
+        int nch = 0;
+        if (p < nI) {
+            int slot = T.lvl[p];
+            uint64_t av = avail_mask(pred, K, T.keys[slot]);
+            T.a_avail[p] = av;
+            T.a_cnt[p] = T.cnt[slot];
+            nch = popc64(av);
+        }
+        int tot;
+        int ex = g.exscan_i32(nch, &tot);
+        if (p < nI) T.a_cbase[p] = carry + ex;
+        carry += tot;
+    }
+    if (g.tid() == 0) { T.a_cbase[nI] = carry; T.counter[1] = carry; }
+    g.sync();
+    if (carry > T.child_cap) return ST_ERR_IDEALS_CAPACITY;
+    for (int p = g.tid(); p < nI; p += g.size()) {
+        uint64_t I = T.keys[T.lvl[p]];
+        uint64_t av = T.a_avail[p];
+        int k = T.a_cbase[p];
+        while (av) {
+            int v = ctz64(av);
+            av &= av - 1;
+            int s = ideal_lookup(T, I | (1ull << v));
+            T.a_child[k++] = (uint16_t)(s >= 0 ? T.pos[s] : 0);
+        }
+    }
+    g.sync();
+    *R_out = T.a_cnt[0];
     return ST_OK;
 }
 
-// r-th (0-based) topological order in lexicographic order -> ord[0..K).  One thread.
-AMBI_HD bool order_unrank(const uint64_t* pred, int K, const IdealTable& T, uint64_t r, uint8_t* ord, int stride = 1) {
-    uint64_t I = 0;
+// child of ideal i along node v (v must be available in i)
+AMBI_HD int auto_child(const AutoView& A, int i, uint64_t av, int v) {
+    return A.child[A.cbase[i] + popc64(av & ((1ull << v) - 1))];
+}
+
+// r-th (0-based) topological order in lexicographic order -> ord[d*stride], d in [0,K).  One thread.
+AMBI_HD bool order_unrank(const AutoView& A, int K, uint64_t r, uint8_t* ord, int stride = 1) {
+    int i = 0;
     for (int d = 0; d < K; d++) {
-        uint64_t av = avail_mask(pred, K, I);
+        uint64_t av = A.avail[i];
+        int k = A.cbase[i];
         bool found = false;
         while (av) {
-            int v = __builtin_ctzll(av);
+            int v = ctz64(av);
             av &= av - 1;
-            int s = ideal_lookup(T, I | (1ull << v));
-            uint64_t c = (s >= 0) ? T.cnt[s] : 0;
-            if (r < c) { ord[d * stride] = (uint8_t)v; I |= (1ull << v); found = true; break; }
+            int j = A.child[k++];
+            uint64_t c = A.cnt[j];
+            if (r < c) { ord[d * stride] = (uint8_t)v; i = j; found = true; break; }
             r -= c;
         }
         if (!found) return false;
@@ -182,43 +248,160 @@ AMBI_HD bool order_unrank(const uint64_t* pred, int K, const IdealTable& T, uint
     return true;
 }
 
-// lexicographic successor of ord (in place); false when ord was the last order.  One thread.
-AMBI_HD bool order_next(const uint64_t* pred, int K, uint8_t* ord, int stride = 1) {
-    uint64_t I = (K >= 64) ? ~0ull : ((1ull << K) - 1);
-    for (int d = K - 1; d >= 0; d--) {
-        int v = ord[d * stride];
-        I &= ~(1ull << v);
-        uint64_t higher = (v >= 63) ? 0ull : (~0ull << (v + 1));
-        uint64_t cand = avail_mask(pred, K, I) & higher;
-        if (cand) {
-            int w = __builtin_ctzll(cand);
-            ord[d * stride] = (uint8_t)w;
-            I |= (1ull << w);
-            for (int e = d + 1; e < K; e++) {
-                uint64_t av = avail_mask(pred, K, I);
-                if (!av) return false;   // cannot happen in a DAG
-                int x = __builtin_ctzll(av);
-                ord[e * stride] = (uint8_t)x;
-                I |= (1ull << x);
-            }
-            return true;
-        }
-    }
-    return false;
-}
-
 // the lexicographically LAST order (greedy highest available node): getBFB's orientation flip looks at
 // whether the last order is valid (LGM.cpp:3691-3695)
-AMBI_HD bool order_last(const uint64_t* pred, int K, uint8_t* ord) {
-    uint64_t I = 0;
+AMBI_HD bool order_last(const AutoView& A, int K, uint8_t* ord) {
+    int i = 0;
     for (int d = 0; d < K; d++) {
-        uint64_t av = avail_mask(pred, K, I);
+        uint64_t av = A.avail[i];
         if (!av) return false;
         int v = 63 - __builtin_clzll(av);
         ord[d] = (uint8_t)v;
-        I |= (1ull << v);
+        i = auto_child(A, i, av, v);
     }
     return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row enumeration: `nrows` consecutive orders starting at rank `first`, written as packed rows.
+// ------------------------------------------------------------------------------------------------
+// The current order packed 4 nodes per dword; doubles as the image of the output row.
+template <int NW>
+struct PackedRow {
+    uint32_t w[NW];
+    AMBI_HD void fill(uint32_t v) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) w[i] = v;
+    }
+    AMBI_HD void set(int d, uint32_t val) {
+        const int wi = d >> 2, sh = (d & 3) * 8;
+        const uint32_t m = ~(0xFFu << sh), x = val << sh;
+#pragma unroll
+        for (int i = 0; i < NW; i++) w[i] = (i == wi) ? ((w[i] & m) | x) : w[i];
+    }
+};
+
+// Automaton accessors.  GlobalAuto reads the 64-bit tables in HBM/L2; LdsAuto reads a compact copy (mask type M,
+// 16-bit child bases) staged in the group's memory.
+struct GlobalAuto {
+    AutoView A;
+    AMBI_HD uint64_t avail(int i) const { return A.avail[i]; }
+    AMBI_HD int child(int i, uint64_t av, int v) const { return A.child[A.cbase[i] + popc64(av & ((1ull << v) - 1))]; }
+};
+template <class M>
+struct LdsAuto {
+    const M* av_;           // [nI]
+    const uint16_t* cb_;    // [nI]
+    const uint16_t* ch_;    // [nC]
+    AMBI_HD uint64_t avail(int i) const { return (uint64_t)av_[i]; }
+    AMBI_HD int child(int i, uint64_t av, int v) const { return ch_[cb_[i] + popc64(av & ((1ull << v) - 1))]; }
+};
+template <class M>
+AMBI_HD int64_t lds_auto_bytes(int nI, int nC) { return (int64_t)nI * (int64_t)(sizeof(M) + 2) + 2ll * nC + 16; }
+
+// Per-lane DFS stacks (depth-major so that the 64 lanes of one depth are contiguous): element d at [d*stride].
+template <class M>
+struct LaneStacks {
+    M* avail;        // available nodes of the ideal BEFORE position d
+    uint16_t* idx;   // index of that ideal
+    uint8_t* ord;    // node placed at position d
+    int stride;
+};
+
+// store helpers: 16-byte groups where the destination allows, plain dwords otherwise
+AMBI_HD void store4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint4*>(dst) = make_uint4(a, b, c, d);
+#else
+    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+#endif
+}
+
+// Writes rows [first, first+nrows) of the order table.  `out` points at row `first` (16-byte aligned; rows are NW
+// dwords).  Requires first + nrows <= R.  One thread; all lanes of a wave run it in lockstep on their own ranges.
+template <int NW, class M, class AUTO>
+AMBI_HD void enumerate_rows(const AUTO& au, const AutoView& cntView, int K, uint64_t first, int nrows,
+                            const LaneStacks<M>& S, uint32_t* out) {
+    PackedRow<NW> row;
+    row.fill(0xFFFFFFFFu);
+    // ---- unrank the first order, filling the stacks ----
+    {
+        int i = 0;
+        uint64_t r = first;
+        for (int d = 0; d < K; d++) {
+            uint64_t av = au.avail(i);
+            S.avail[d * S.stride] = (M)av;
+            S.idx[d * S.stride] = (uint16_t)i;
+            int k = cntView.cbase[i];
+            uint64_t a2 = av;
+            int chosen = -1, j = 0;
+            while (a2) {
+                int v = ctz64(a2);
+                a2 &= a2 - 1;
+                j = cntView.child[k++];
+                uint64_t c = cntView.cnt[j];
+                if (r < c) { chosen = v; break; }
+                r -= c;
+            }
+            if (chosen < 0) return;   // rank out of range (caller guarantees this cannot happen)
+            S.ord[d * S.stride] = (uint8_t)chosen;
+            row.set(d, (uint32_t)chosen);
+            i = j;
+        }
+    }
+    // ---- lexicographic successor: deepest position with a larger available node ----
+    auto successor = [&]() -> bool {
+        int d = K - 2;          // position K-1 never has an alternative (exactly one node is left)
+        uint64_t cand = 0;
+        while (d >= 0) {
+            uint64_t av = (uint64_t)S.avail[d * S.stride];
+            int v = S.ord[d * S.stride];
+            cand = av & ~((2ull << v) - 1);
+            if (cand) break;
+            d--;
+        }
+        if (d < 0) return false;   // was the last order
+        uint64_t av = (uint64_t)S.avail[d * S.stride];
+        int i = S.idx[d * S.stride];
+        int w = ctz64(cand);
+        S.ord[d * S.stride] = (uint8_t)w;
+        row.set(d, (uint32_t)w);
+        int j = au.child(i, av, w);
+        for (int e = d + 1; e < K; e++) {
+            uint64_t a = au.avail(j);
+            int x = ctz64(a);
+            S.avail[e * S.stride] = (M)a;
+            S.idx[e * S.stride] = (uint16_t)j;
+            S.ord[e * S.stride] = (uint8_t)x;
+            row.set(e, (uint32_t)x);
+            if (e + 1 < K) j = au.child(j, a, x);
+        }
+        return true;
+    };
+    // rows leave in groups of four (4*NW dwords = NW 16-byte stores); every register index below is static
+    for (int r0 = 0; r0 < nrows; r0 += 4) {
+        PackedRow<NW> b0 = row, b1 = row, b2 = row, b3 = row;
+        const int have = nrows - r0 < 4 ? nrows - r0 : 4;
+        if (have > 1) { successor(); b1 = row; }
+        if (have > 2) { successor(); b2 = row; }
+        if (have > 3) { successor(); b3 = row; }
+        uint32_t* dst = out + (size_t)r0 * NW;
+        if (have == 4) {
+            uint32_t c[4 * NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) { c[k] = b0.w[k]; c[NW + k] = b1.w[k]; c[2 * NW + k] = b2.w[k]; c[3 * NW + k] = b3.w[k]; }
+#pragma unroll
+            for (int k = 0; k < NW; k++) store4(dst + 4 * k, c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]);
+            if (r0 + 4 < nrows) successor();
+        } else {
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                dst[k] = b0.w[k];
+                if (have > 1) dst[NW + k] = b1.w[k];
+                if (have > 2) dst[2 * NW + k] = b2.w[k];
+            }
+        }
+    }
 }
 
 }  // namespace ambi

@@ -56,10 +56,16 @@ AMBI_HD IdealTable unit_ideal_table(const BatchArgs& A, int u) {
     IdealTable T;
     T.keys = A.ideal_keys + U.ideal_off;
     T.cnt = A.ideal_cnt + U.ideal_off;
+    T.pos = A.ideal_pos + U.ideal_off;
     T.lvl = A.ideal_lvl + U.ideal_off / 2;
     T.lvl_off = A.ideal_lvl_off + int64_t(u) * (kMaxNodes + 3);
-    T.counter = A.ideal_counter + u;
+    T.counter = A.ideal_counter + 2 * int64_t(u);
+    T.a_avail = A.auto_avail + U.ideal_off / 2;
+    T.a_cnt = A.auto_cnt + U.ideal_off / 2;
+    T.a_cbase = A.auto_cbase + U.ideal_off / 2 + u;
+    T.a_child = A.auto_child + 4 * U.ideal_off;
     T.cap = U.ideal_cap;
+    T.child_cap = 4 * U.ideal_cap;
     return T;
 }
 
@@ -142,31 +148,39 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
 // ---------------------------------------------------------------------------------------------
 // plan: order-table offsets + enumerate work blocks (one thread block for the whole batch)
 // ---------------------------------------------------------------------------------------------
-AMBI_HD int rows_per_lane_for(int K, int tile_bytes) {
-    int t = tile_bytes / (64 * (K > 0 ? K : 1));
-    if (t < 1) t = 1;
-    if (t > 64) t = 64;
-    return t;
+// Rows each lane of the enumerate kernel produces: the rows of the whole batch are spread over about
+// `target_lanes` lanes; a multiple of 4 (rows leave the registers in 16-byte groups of four) in [4, 1024].
+AMBI_HD int rows_per_lane_for(int64_t total_rows, int target_lanes) {
+    int64_t t = (total_rows + target_lanes - 1) / (target_lanes > 0 ? target_lanes : 1);
+    t = (t + 3) & ~int64_t(3);
+    if (t < 4) t = 4;
+    if (t > 1024) t = 1024;
+    return (int)t;
 }
+AMBI_HD int64_t order_bytes(int64_t R, int K) { return (R * row_stride(K) + 15) & ~int64_t(15); }
 
-// serial reference form (used by the host simulation and, with one thread, by the plan kernel's tail)
+// serial reference form of the plan kernel (host simulation)
 AMBI_HD void plan_serial(const BatchArgs& A) {
+    int64_t total_rows = 0;
+    for (int u = 0; u < A.n_units; u++) {
+        const UnitOut* out = unit_out(A.results, u);
+        if (out->status == ST_OK && out->num_orders < (int64_t)kCountSat) total_rows += out->num_orders;
+    }
+    const int T = rows_per_lane_for(total_rows, A.target_lanes);
     int64_t off = 0, blk = 0;
     for (int u = 0; u < A.n_units; u++) {
         UnitOut* out = unit_out(A.results, u);
         A.blk_off[u] = blk;
-        A.rows_per_lane[u] = 1;
+        A.rows_per_lane[u] = T;
         if (out->status != ST_OK) continue;
         const int K = out->K;
         const int64_t R = out->num_orders;
-        int64_t bytes = (R * K + 15) & ~int64_t(15);
         if (R >= (int64_t)kCountSat) { out->status = ST_ERR_ORDERS_CAPACITY; continue; }
+        const int64_t bytes = order_bytes(R, K);
         // plain prefix sum: a unit that does not fit still advances the offset (so orders_needed is the true total)
         if (off + bytes > A.order_arena_bytes) { out->status = ST_ERR_ORDERS_CAPACITY; off += bytes; continue; }
         out->order_off = off;
         off += bytes;
-        int T = rows_per_lane_for(K, A.tile_bytes);
-        A.rows_per_lane[u] = T;
         blk += (R + 64ll * T - 1) / (64ll * T);
     }
     A.blk_off[A.n_units] = blk;
@@ -174,19 +188,46 @@ AMBI_HD void plan_serial(const BatchArgs& A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// stage_enumerate: one work block = 64*T consecutive ranks of one unit, handled by one wave-sized group.
-// tile: [64*T*K] bytes of group memory laid out exactly like the destination rows; ord: [64][64] bytes;
-// pred: [64] masks.  `lane` / `nlanes`: the caller maps threads to lanes (HostGroup loops over all 64).
+// stage_enumerate: one work block = 64*T consecutive ranks of one unit = one wavefront; lane l writes rows
+// [base + l*T, base + (l+1)*T) straight from registers (ambi_orders.hpp: enumerate_rows).
+// Per-lane DFS stacks live in group memory; the automaton is read from a compact LDS copy when it fits
+// (LdsAuto) and from HBM/L2 otherwise (GlobalAuto).
 // ---------------------------------------------------------------------------------------------
-AMBI_HD void enumerate_lane(const uint64_t* pred, int K, const IdealTable& T, int64_t R, int64_t first_rank, int rows,
-                            uint8_t* ord, int ord_stride, uint8_t* tile_rows) {
-    // rows consecutive orders starting at first_rank -> tile_rows[r*K + d]
+template <class M>
+AMBI_HD int64_t enum_stack_bytes(int K) { return pad8(int64_t(64) * K * (int64_t)(sizeof(M) + 3)); }
+
+template <int NW, class M, class AUTO>
+AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R, int64_t first_rank, int T,
+                            uint8_t* stack_mem, int lane, int lanes, uint8_t* unit_rows) {
     if (first_rank >= R) return;
-    if (!order_unrank(pred, K, T, (uint64_t)first_rank, ord, ord_stride)) return;
-    for (int r = 0; r < rows; r++) {
-        if (first_rank + r >= R) break;
-        for (int d = 0; d < K; d++) tile_rows[r * K + d] = ord[d * ord_stride];
-        if (r + 1 < rows && first_rank + r + 1 < R) order_next(pred, K, ord, ord_stride);
+    int64_t nrows = R - first_rank;
+    if (nrows > T) nrows = T;
+    LaneStacks<M> S;
+    S.stride = lanes;
+    S.avail = reinterpret_cast<M*>(stack_mem) + lane;
+    S.idx = reinterpret_cast<uint16_t*>(stack_mem + (size_t)lanes * K * sizeof(M)) + lane;
+    S.ord = stack_mem + (size_t)lanes * K * (sizeof(M) + 2) + lane;
+    uint32_t* out = reinterpret_cast<uint32_t*>(unit_rows + first_rank * (int64_t)(NW * 4));
+    enumerate_rows<NW, M, AUTO>(au, V, K, (uint64_t)first_rank, (int)nrows, S, out);
+}
+
+// dispatch on K: NW = Kpad/4 dwords per row; 32-bit masks while K <= 32
+template <class AUTO32, class AUTO64>
+AMBI_HD void enumerate_lane_dispatch(const AUTO32& a32, const AUTO64& a64, const AutoView& V, int K, int64_t R,
+                                     int64_t first_rank, int T, uint8_t* stack_mem, int lane, int lanes, uint8_t* unit_rows) {
+    const int nw = row_stride(K) / 4;
+    switch (nw) {
+        case 1: enumerate_lane<1, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 2: enumerate_lane<2, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 3: enumerate_lane<3, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 4: enumerate_lane<4, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 5: enumerate_lane<5, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 6: enumerate_lane<6, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 7: enumerate_lane<7, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 8: enumerate_lane<8, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        case 9: case 10: case 11: case 12:
+            enumerate_lane<12, uint64_t>(a64, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+        default: enumerate_lane<16, uint64_t>(a64, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
     }
 }
 
@@ -247,7 +288,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     for (int pass = 0; pass < 2 && found < 0; pass++) {
         int64_t lim = R < A.first_budget ? R : A.first_budget;
         for (int64_t nidx = 0; nidx < lim; nidx++) {
-            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * K + d];
+            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * row_stride(K) + d];
             g.sync();
             int Lo = 0;
             int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo);
@@ -284,7 +325,7 @@ AMBI_HD int eval_indexed(const G& g, const BatchArgs& A, int u, const FirstWork&
     const UnitIn& U = A.units[u];
     const int K = out->K;
     const uint8_t* rows = A.order_arena + out->order_off;
-    for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * K + d];
+    for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * row_stride(K) + d];
     g.sync();
     InvMap inv{W.inv_src, W.inv_tgt};
     return eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);

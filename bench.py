@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])
     ap.add_argument("--K", type=int, default=19)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
-    ap.add_argument("--tile-bytes", type=int, default=0)
+    ap.add_argument("--target-lanes", type=int, default=0)
     return ap.parse_args()
 
 
@@ -68,7 +68,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="ambi_bench_")
     graphs, files = [], []
     batch = api.Batch(lib)
-    batch.configure(tile_bytes=args.tile_bytes)
+    batch.configure(target_lanes=args.target_lanes)
     for i in range(B):
         s = synth.make_sample(args.segs, args.juncs, args.tier, args.K, seed=1000 * 2 + rank * B + i)
         lh, sols = s.write(tmp, "s%d" % i)

@@ -107,8 +107,8 @@ int ambi_batch_add_unit(ambi_batch_t* b, int32_t n_seg, int32_t seg_base, const 
 int ambi_batch_size(const ambi_batch_t* b, int32_t* n_units);
 
 /* Tunables (before upload): order-table arena bytes (0 = size it from the first run), ideal-table slots per unit,
- * first-valid scan budget, LDS tile bytes of the enumerate kernel. */
-int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t tile_bytes);
+ * first-valid scan budget, number of lanes the enumerate kernel spreads the order-table rows over. */
+int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t target_lanes);
 
 /* Packs the units and copies the inputs to HBM on the current device (inputs stay resident across runs). */
 int ambi_batch_upload(ambi_batch_t* b);

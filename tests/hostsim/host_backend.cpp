@@ -18,8 +18,9 @@ class HostSimBackend : public Backend {
     std::vector<UnitIn> units_;
     std::vector<Dag> dags_;
     std::vector<uint8_t> results_, arena_;
-    std::vector<uint64_t> ikeys_, icnt_;
-    std::vector<int32_t> ilvl_, ilvl_off_, icounter_, rows_per_lane_, scratch_;
+    std::vector<uint64_t> ikeys_, icnt_, aavail_, acnt_;
+    std::vector<uint16_t> achild_;
+    std::vector<int32_t> ilvl_, ilvl_off_, icounter_, ipos_, acbase_, rows_per_lane_, scratch_;
     std::vector<int64_t> blk_off_;
     int32_t n_pending_ = 0;
     int64_t orders_needed_ = 0;
@@ -38,8 +39,11 @@ class HostSimBackend : public Backend {
         dags_.assign(U, Dag{});
         results_.assign((size_t)hb.result_bytes, 0);
         ikeys_.assign((size_t)hb.ideal_slots, 0); icnt_.assign((size_t)hb.ideal_slots, 0);
+        ipos_.assign((size_t)hb.ideal_slots, 0);
         ilvl_.assign((size_t)hb.ideal_slots / 2 + 1, 0);
-        ilvl_off_.assign(U * (kMaxNodes + 3), 0); icounter_.assign(U, 0);
+        ilvl_off_.assign(U * (kMaxNodes + 3), 0); icounter_.assign(2 * U, 0);
+        aavail_.assign((size_t)hb.ideal_slots / 2 + 1, 0); acnt_.assign((size_t)hb.ideal_slots / 2 + 1, 0);
+        acbase_.assign((size_t)hb.ideal_slots / 2 + U + 1, 0); achild_.assign((size_t)hb.ideal_slots * 4 + 8, 0);
         rows_per_lane_.assign(U, 1); blk_off_.assign(U + 1, 0);
         scratch_.assign((size_t)hb.scratch_ints + 8, 0);
         arena_.assign((size_t)(cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : 0), 0);
@@ -48,7 +52,9 @@ class HostSimBackend : public Backend {
 
     void bind(uint32_t flags) {
         A_.n_units = (int32_t)units_.size();
-        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.tile_bytes = cfg_.tile_bytes;
+        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
+        A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
+        A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data();
         A_.units = units_.data(); A_.seg_cn = hb_.seg_cn.data(); A_.juncs = hb_.juncs.data(); A_.elems = hb_.elems.data();
         A_.dags = dags_.data(); A_.results = results_.data();
         A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_lvl = ilvl_.data();
@@ -62,7 +68,7 @@ class HostSimBackend : public Backend {
     void enumerate_all() {
         HostGroup g;
         const int64_t total = blk_off_[units_.size()];
-        std::vector<uint8_t> tile((size_t)A_.tile_bytes + 64 * 64);
+        std::vector<uint8_t> stacks((size_t)enum_stack_bytes<uint64_t>(64));
         for (int64_t b = 0; b < total; b++) {
             int lo = 0, hi = (int)units_.size();
             while (hi - lo > 1) { int mid = (lo + hi) / 2; if (blk_off_[mid] <= b) lo = mid; else hi = mid; }
@@ -71,11 +77,11 @@ class HostSimBackend : public Backend {
             const int K = out->K, T = rows_per_lane_[u];
             const int64_t R = out->num_orders, base_rank = (b - blk_off_[u]) * 64ll * T;
             IdealTable tbl = unit_ideal_table(A_, u);
-            uint8_t ord[64];
+            AutoView V = auto_view(tbl);
+            GlobalAuto ga{V};
             for (int lane = 0; lane < 64; lane++)
-                enumerate_lane(dags_[u].pred, K, tbl, R, base_rank + (int64_t)lane * T, T, ord, 1, tile.data() + (size_t)lane * T * K);
-            int64_t rows = R - base_rank < 64ll * T ? R - base_rank : 64ll * T;
-            memcpy(A_.order_arena + out->order_off + base_rank * K, tile.data(), (size_t)(rows * K));
+                enumerate_lane_dispatch(ga, ga, V, K, R, base_rank + (int64_t)lane * T, T, stacks.data(), lane, 64,
+                                        A_.order_arena + out->order_off);
         }
         (void)g;
     }
@@ -166,7 +172,9 @@ class HostSimBackend : public Backend {
     int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
         const UnitOut* h = unit_out(results_.data(), unit);
         if (h->order_off < 0 || first < 0 || first + count > h->num_orders) return ST_ERR_BAD_INPUT;
-        memcpy(out, arena_.data() + h->order_off + first * h->K, (size_t)(count * h->K));
+        const int stride = row_stride(h->K);
+        for (int64_t r = 0; r < count; r++)
+            memcpy(out + r * h->K, arena_.data() + h->order_off + (first + r) * stride, (size_t)h->K);
         return 0;
     }
     int copy_dag(int unit, Dag* out) override { *out = dags_[unit]; return 0; }
