@@ -375,7 +375,7 @@ class HipBackend : public Backend {
         // LDS budgets (dynamic shared memory), sized for the largest unit of the batch
         lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
         lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
-        lds_finish_ = (int)finish_work_bytes(hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
+        lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
         enum_stack_lds_ = (int)(hb.max_k > 32 ? enum_stack_bytes<uint64_t>(hb.max_k) : enum_stack_bytes<uint32_t>(hb.max_k > 0 ? hb.max_k : 1));
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         const int kLdsLimit = 160 * 1024 - 1024;

@@ -1,18 +1,40 @@
 // ambi_finish.hpp -- post-assembly edits of the per-segment path and output-junction synthesis.
 //
 // Restates LocalGenomicMap::indelBFB (LGM.cpp:3746-3837) and the output junction loop of main()
-// (localhap.cpp:267-289) as SPMD code over a workgroup: the path (int16 signed local ids) sits in LDS, every
-// std::find is a strided scan + min-reduction, erase/insert are chunked LDS shifts, and the O(m^2) deque chaining
-// of structural variants is replaced by "next matching junction" min-reductions that visit the junctions in
-// exactly the reference's order.
+// (localhap.cpp:267-289) as SPMD code over a workgroup.  The path (int16 signed local ids) sits in LDS.
+//
+// indelBFB walks the structural variants (SVs) in junction order, chains them into groups with a deque, and for
+// every group looks its end vertices up in the path with std::find.  MI355X form:
+//   * first/last-occurrence tables of every vertex (LDS, atomic min/max in one sweep over the path) answer every
+//     std::find of a two-vertex group in O(1); only an actual edit (rare) rebuilds them;
+//   * all SVs that cannot chain with a later SV ("singletons", decided once by an all-pairs test) are evaluated in
+//     parallel against the tables; the first one (in junction order) that edits the path -- or that needs the
+//     general deque chaining -- is found with one min-reduction, handled, and the sweep resumes behind it.  The
+//     skipped SVs are exactly those for which the reference executes `continue`, so the result is the reference's.
 #pragma once
 #include "ambi_common.hpp"
 #include "ambi_eval.hpp"
 #include "ambi_group.hpp"
+#include "ambi_orders.hpp"
 
 namespace ambi {
 
 struct OutJunc { int32_t u, v, count; };   // consecutive vertices (u,v) of a path that are not a reference adjacency
+
+AMBI_HD void atomic_min_i32(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+AMBI_HD void atomic_max_i32(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
 
 // std::find(path+from, path+to, val): first index in [from,to) or `to`.  from > to behaves like an empty range.
 template <class G>
@@ -24,12 +46,56 @@ AMBI_HD int find_first(const G& g, const cell_t* path, int from, int to, int val
     return best == 0x7fffffff ? to : best;
 }
 
-// Scratch for indel_bfb: sv[m] junction indices, taken[m] flags, grp[2*m+4] deque storage.
+// Scratch for indel_bfb (group memory).
 struct IndelScratch {
-    int32_t* sv;
-    uint8_t* taken;
-    int32_t* grp;
+    int32_t* sv;        // [m]      qualifying junction indices, in junction order
+    uint8_t* taken;     // [m]
+    uint8_t* has_ext;   // [m]      a later SV could chain onto this one
+    int32_t* grp;       // [2m+4]   deque storage of the general path
+    int32_t* first;     // [2n+1]   first occurrence of vertex v at [v+n]
+    int32_t* last;      // [2n+1]   last occurrence
 };
+
+struct SingleEdit { int kind, a, b; };   // kind 0: none, 1: erase [a,b), 2: duplicate [a,b) after b-1... (see apply)
+
+// Decision of LGM.cpp:3779-3818 for a two-vertex group (g0,g1), answered from the occurrence tables.
+AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const cell_t* path, int P, const int32_t* first, const int32_t* last) {
+    SingleEdit E{0, 0, 0};
+    const bool same = (g0 > 0) == (g1 > 0);
+    const bool deletion = same && ((g0 > 0 && iabs(g0) < iabs(g1)) || (g0 < 0 && iabs(g0) > iabs(g1)));
+    if (!same || deletion) {
+        const int limit = same ? 3 : 5;
+        int pos1 = P, pos2 = P;     // pos2: P = absent, -1 = present but farther than `limit`
+        for (int attempt = 0; attempt < 2; attempt++) {
+            int f0 = first[g0 + n];
+            pos1 = f0 == 0x7fffffff ? P : f0;
+            pos2 = P;
+            if (pos1 != P && last[g1 + n] > pos1) {
+                pos2 = -1;
+                int hi = pos1 + limit < P - 1 ? pos1 + limit : P - 1;
+                for (int q = pos1 + 1; q <= hi; q++) if (path[q] == g1) { pos2 = q; break; }
+            }
+            if (attempt == 0 && (pos1 == P || pos2 == P)) { int t = g0; g0 = -g1; g1 = -t; continue; }
+            break;
+        }
+        if (pos1 == P || pos2 == P || pos2 < 0) return E;
+        if (pos2 - (pos1 + 1) <= 0) return E;   // erase of an empty range: no state change
+        E.kind = 1; E.a = pos1 + 1; E.b = pos2;
+        return E;
+    }
+    // duplication
+    int pos1 = P, pos2 = P;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int f0 = first[g0 + n], f1 = first[g1 + n];
+        pos1 = f0 == 0x7fffffff ? P : f0;
+        pos2 = (f1 != 0x7fffffff && f1 < pos1) ? f1 : pos1;
+        if (attempt == 0 && (pos1 == P || pos2 == pos1)) { int t = g0; g0 = -g1; g1 = -t; continue; }
+        break;
+    }
+    if (pos1 == P || pos2 == pos1) return E;
+    E.kind = 2; E.a = pos2; E.b = pos1 + 1;   // insert a copy of [a,b) at b
+    return E;
+}
 
 // LGM.cpp:3746-3837.  path/P are updated in place.  Returns 1 when the reference prints the
 // "BFB path with insertion, deletion, or duplication:" caption (any qualifying SV exists), 0 otherwise,
@@ -59,15 +125,72 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
     g.sync();
     if (nsv == 0) return 0;
 
-    int start_scan = 0;
-    while (true) {
-        // first junction not yet consumed starts a new group
-        int first = 0x7fffffff;
-        for (int i = start_scan + g.tid(); i < nsv; i += g.size())
-            if (!S.taken[i]) { first = i; break; }
-        first = g.min_i32(first);
-        if (first == 0x7fffffff) break;
-        start_scan = first + 1;
+    // -- which SVs could be chained onto by a LATER one (superset of what the deque chaining can do)
+    for (int i = g.tid(); i < nsv; i += g.size()) {
+        const Junction& Ji = juncs[S.sv[i]];
+        const int front = a_src(Ji), back = a_tgt(Ji);
+        int ext = 0;
+        for (int j = i + 1; j < nsv; j++) {
+            const Junction& J = juncs[S.sv[j]];
+            if (a_tgt(J) == front || b_tgt(J) == front || back == a_src(J) || back == b_src(J)) { ext = 1; break; }
+        }
+        S.has_ext[i] = (uint8_t)ext;
+    }
+    g.sync();
+
+    auto rebuild_tables = [&]() {
+        for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { S.first[i] = 0x7fffffff; S.last[i] = -1; }
+        g.sync();
+        for (int i = g.tid(); i < P; i += g.size()) {
+            int v = path[i] + n;
+            atomic_min_i32(&S.first[v], i);
+            atomic_max_i32(&S.last[v], i);
+        }
+        g.sync();
+    };
+    auto apply_single = [&](const SingleEdit& E) -> int {
+        if (E.kind == 1) {
+            int cnt = E.b - E.a;
+            shift_down(g, path, P, E.a, cnt);
+            P -= cnt;
+        } else if (E.kind == 2) {
+            int cnt = E.b - E.a;
+            if (P + cnt > pcap) return ST_ERR_PATH_CAPACITY;
+            shift_up(g, path, P, E.b, cnt);
+            for (int k = g.tid(); k < cnt; k += g.size()) path[E.b + k] = path[E.a + k];
+            P += cnt;
+            g.sync();
+        }
+        return 0;
+    };
+
+    bool tables_ok = false;
+    int f = 0;
+    while (f < nsv) {
+        if (!tables_ok) { rebuild_tables(); tables_ok = true; }
+        // parallel sweep: first SV at or after f that is not a no-op
+        int stop = 0x7fffffff;
+        for (int i = f + g.tid(); i < nsv; i += g.size()) {
+            if (S.taken[i]) continue;
+            if (S.has_ext[i]) { stop = i; break; }
+            const Junction& J = juncs[S.sv[i]];
+            SingleEdit E = eval_single(a_src(J), a_tgt(J), n, path, P, S.first, S.last);
+            if (E.kind != 0) { stop = i; break; }
+        }
+        stop = g.min_i32(stop);
+        if (stop == 0x7fffffff) break;
+        if (!S.has_ext[stop]) {
+            const Junction& J = juncs[S.sv[stop]];
+            SingleEdit E = eval_single(a_src(J), a_tgt(J), n, path, P, S.first, S.last);   // uniform re-evaluation
+            g.sync();
+            int rc = apply_single(E);
+            if (rc < 0) { *P_io = P; return rc; }
+            tables_ok = false;
+            f = stop + 1;
+            continue;
+        }
+        // ---- general path: deque chaining from SV `stop` (LGM.cpp:3762-3776) ----
+        const int first = stop;
         int head = m + 2, tail = m + 2;
         {
             const Junction& J = juncs[S.sv[first]];
@@ -100,7 +223,20 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
             g.sync();
             cursor = cand + 1;
         }
-        // -- apply the group (LGM.cpp:3779-3832)
+        f = stop + 1;
+        // -- apply the group (LGM.cpp:3779-3832).  All std::finds of a group precede its edit, so the occurrence
+        // tables (valid here) answer them; a real scan is needed only for "next occurrence after pos1" when the vertex
+        // occurs both before and after pos1.
+        auto t_find = [&](int val) -> int { int f0 = S.first[val + n]; return f0 == 0x7fffffff ? P : f0; };
+        auto t_find_before = [&](int pos1, int val) -> int { int f0 = S.first[val + n]; return (f0 != 0x7fffffff && f0 < pos1) ? f0 : pos1; };
+        auto t_find_after = [&](int pos1, int val) -> int {
+            if (pos1 >= P) return P;
+            int f0 = S.first[val + n];
+            if (f0 != 0x7fffffff && f0 > pos1) return f0;
+            if (S.last[val + n] <= pos1) return P;
+            return find_first(g, path, pos1 + 1, P, val);
+        };
+        tables_ok = false;   // cleared up front; restored below when the group turns out to be a no-op
         int gs = tail - head;
         auto complement_all = [&]() {
             g.sync();
@@ -115,27 +251,27 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
             if ((g0 > 0) == (g1 > 0)) {
                 bool deletion = (g0 > 0 && iabs(g0) < iabs(g1)) || (g0 < 0 && iabs(g0) > iabs(g1));
                 if (deletion) {
-                    int pos1 = find_first(g, path, 0, P, g0);
-                    int pos2 = find_first(g, path, pos1 + 1, P, g1);
+                    int pos1 = t_find(g0);
+                    int pos2 = t_find_after(pos1, g1);
                     if (pos1 == P || pos2 == P) {
                         complement_all();
                         g0 = S.grp[head]; g1 = S.grp[head + 1];
-                        pos1 = find_first(g, path, 0, P, g0);
-                        pos2 = find_first(g, path, pos1 + 1, P, g1);
+                        pos1 = t_find(g0);
+                        pos2 = t_find_after(pos1, g1);
                     }
-                    if (pos1 == P || pos2 == P || pos2 - pos1 > 3) continue;
+                    if (pos1 == P || pos2 == P || pos2 - pos1 > 3) { tables_ok = true; continue; }
                     int cnt = pos2 - (pos1 + 1);
                     if (cnt > 0) { shift_down(g, path, P, pos1 + 1, cnt); P -= cnt; }
                 } else {   // duplication
-                    int pos1 = find_first(g, path, 0, P, g0);
-                    int pos2 = find_first(g, path, 0, pos1, g1);
+                    int pos1 = t_find(g0);
+                    int pos2 = t_find_before(pos1, g1);
                     if (pos1 == P || pos2 == pos1) {
                         complement_all();
                         g0 = S.grp[head]; g1 = S.grp[head + 1];
-                        pos1 = find_first(g, path, 0, P, g0);
-                        pos2 = find_first(g, path, 0, pos1, g1);
+                        pos1 = t_find(g0);
+                        pos2 = t_find_before(pos1, g1);
                     }
-                    if (pos1 == P || pos2 == pos1) continue;
+                    if (pos1 == P || pos2 == pos1) { tables_ok = true; continue; }
                     int cnt = pos1 + 1 - pos2;
                     if (P + cnt > pcap) { *P_io = P; return ST_ERR_PATH_CAPACITY; }
                     shift_up(g, path, P, pos1 + 1, cnt);
@@ -144,29 +280,29 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
                     g.sync();
                 }
             } else {   // inversion
-                int pos1 = find_first(g, path, 0, P, g0);
-                int pos2 = find_first(g, path, pos1 + 1, P, g1);
+                int pos1 = t_find(g0);
+                int pos2 = t_find_after(pos1, g1);
                 if (pos1 == P || pos2 == P) {
                     complement_all();
                     g0 = S.grp[head]; g1 = S.grp[head + 1];
-                    pos1 = find_first(g, path, 0, P, g0);
-                    pos2 = find_first(g, path, pos1 + 1, P, g1);
+                    pos1 = t_find(g0);
+                    pos2 = t_find_after(pos1, g1);
                 }
-                if (pos1 == P || pos2 == P || pos2 - pos1 > 5) continue;
+                if (pos1 == P || pos2 == P || pos2 - pos1 > 5) { tables_ok = true; continue; }
                 int cnt = pos2 - (pos1 + 1);
                 if (cnt > 0) { shift_down(g, path, P, pos1 + 1, cnt); P -= cnt; }
             }
         } else {   // insertion
             int gf = S.grp[head], gb = S.grp[tail - 1];
-            int pos1 = find_first(g, path, 0, P, gf);
-            int pos2 = find_first(g, path, pos1 + 1, P, gb);
+            int pos1 = t_find(gf);
+            int pos2 = t_find_after(pos1, gb);
             if (pos1 == P || pos2 == P) {
                 complement_all();
                 gf = S.grp[head]; gb = S.grp[tail - 1];
-                pos1 = find_first(g, path, 0, P, gf);
-                pos2 = find_first(g, path, pos1 + 1, P, gb);
+                pos1 = t_find(gf);
+                pos2 = t_find_after(pos1, gb);
             }
-            if (pos1 == P || pos2 == P) continue;
+            if (pos1 == P || pos2 == P) { tables_ok = true; continue; }
             int cnt = pos2 - (pos1 + 1);
             if (cnt > 0) { shift_down(g, path, P, pos1 + 1, cnt); P -= cnt; }
             int ins = gs - 2;
@@ -183,43 +319,63 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
 
 // localhap.cpp:267-289: consecutive path vertices that are not |id difference| == 1 on one strand become
 // output junctions; a repeat (same edge or its complement edge) bumps the count.  First-appearance order.
-// cand = scratch of P ints.  Returns the number of output junctions or a negative Status.
+// cand = scratch of cand_cap ints.  Returns the number of output junctions or a negative Status.
 template <class G>
 AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out, int cap, int32_t* cand, int cand_cap) {
     if (P <= 0) return 0;
-    int nc = 0;
-    for (int base = 0; base + 1 < P; base += g.size()) {
-        int i = base + g.tid();
-        int q = 0;
-        if (i + 1 < P) {
-            int u = path[i], v = path[i + 1];
-            bool adj = (iabs(iabs(u) - iabs(v)) == 1) && ((u > 0) == (v > 0));
-            q = adj ? 0 : 1;
+    // each thread owns a contiguous slice of the path so that ONE group scan orders all junction steps
+    const int steps = P - 1;
+    const int per = (steps + g.size() - 1) / g.size();
+    const int lo = g.tid() * per, hi = lo + per < steps ? lo + per : steps;
+    auto is_step = [&](int i) {
+        int u = path[i], v = path[i + 1];
+        return !((iabs(iabs(u) - iabs(v)) == 1) && ((u > 0) == (v > 0)));
+    };
+    int mine = 0;
+    for (int i = lo; i < hi; i++) mine += is_step(i) ? 1 : 0;
+    int nc;
+    int at = g.exscan_i32(mine, &nc);
+    if (2 * nc > cand_cap) return ST_ERR_OUTJUNC_CAPACITY;
+    for (int i = lo; i < hi; i++) if (is_step(i)) cand[at++] = i;
+    g.sync();
+    // A step joins the FIRST earlier step that is the same edge or its complement edge (the reference bumps that
+    // entry's count, localhap.cpp:275-282); a record can never coexist with its complement, so classes are disjoint.
+    int32_t* rep = cand + nc;      // [nc] representative (first occurrence) of every step, then its output slot
+    for (int c = g.tid(); c < nc; c += g.size()) {
+        const int u = path[cand[c]], v = path[cand[c] + 1];
+        int r = c;
+        for (int k = 0; k < c; k++) {
+            const int a = path[cand[k]], b = path[cand[k] + 1];
+            if ((a == u && b == v) || (-b == u && -a == v)) { r = k; break; }
         }
+        rep[c] = r;
+    }
+    g.sync();
+    int nout = 0;
+    for (int base = 0; base < nc; base += g.size()) {
+        const int c = base + g.tid();
+        const int lead = (c < nc && rep[c] == c) ? 1 : 0;
         int tot;
-        int ex = g.exscan_i32(q, &tot);
-        if (q && nc + ex < cand_cap) cand[nc + ex] = i;
-        nc += tot;
+        const int ex = g.exscan_i32(lead, &tot);
+        if (lead && nout + ex < cap) {
+            OutJunc& o = out[nout + ex];
+            o.u = path[cand[c]]; o.v = path[cand[c] + 1]; o.count = 1;
+        }
+        g.sync();
+        if (lead) rep[c] = -(nout + ex) - 1;   // leaders now carry their slot (encoded negative)
+        nout += tot;
     }
     g.sync();
-    if (nc > cand_cap) return ST_ERR_OUTJUNC_CAPACITY;
-    int nout = 0, err = 0;
-    if (g.tid() == 0) {
-        for (int c = 0; c < nc; c++) {
-            int u = path[cand[c]], v = path[cand[c] + 1];
-            bool has = false;
-            for (int k = 0; k < nout; k++)
-                if ((out[k].u == u && out[k].v == v) || (-out[k].v == u && -out[k].u == v)) { has = true; out[k].count += 1; }
-            if (!has) {
-                if (nout >= cap) { err = 1; break; }
-                out[nout].u = u; out[nout].v = v; out[nout].count = 1; nout++;
-            }
+    if (nout > cap) return ST_ERR_OUTJUNC_CAPACITY;
+    for (int c = g.tid(); c < nc; c += g.size()) {
+        const int r = rep[c];
+        if (r >= 0) {                       // follower: its leader's slot is stored in rep[r]
+            const int slot = -rep[r] - 1;
+            atomic_add_i32(&out[slot].count, 1);
         }
     }
-    nout = g.bcast_i32(nout, 0);
-    err = g.bcast_i32(err, 0);
     g.sync();
-    return err ? (int)ST_ERR_OUTJUNC_CAPACITY : nout;
+    return nout;
 }
 
 }  // namespace ambi

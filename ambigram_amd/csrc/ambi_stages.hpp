@@ -28,10 +28,17 @@ struct PrepareWork {      // group-local memory (LDS on the GPU)
     int32_t* target_cn;   // [n+1]
     Element* elems;       // [K]
     Dag* dag;
+    int32_t* slot_cnt;    // [n+1]  contributions per normal-junction slot
+    int32_t* fb;          // [m]    fold-back junction list
+    int32_t* sv;          // [m]    getIndelBias SV list
+    int32_t* idx;         // [64]   node order
+    Rec3* loops;          // [64]   records permuted by the library sort
+    uint8_t* taken;       // [m]
 };
 AMBI_HD int64_t prepare_work_bytes(int n, int m, int K) {
     return pad8(int64_t(sizeof(Junction)) * m) + pad8(8ll * (n + 1)) + pad8(16ll * (n + 1)) + pad8(4ll * (n + 1)) +
-           pad8(4ll * (n + 1)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(sizeof(Dag));
+           pad8(4ll * (n + 1)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(sizeof(Dag)) +
+           pad8(4ll * (n + 1)) + 2 * pad8(4ll * m) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(m);
 }
 AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
     PrepareWork W;
@@ -42,7 +49,13 @@ AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
     W.inv_junc = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
     W.target_cn = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
     W.elems = reinterpret_cast<Element*>(base + o); o += pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
-    W.dag = reinterpret_cast<Dag*>(base + o);
+    W.dag = reinterpret_cast<Dag*>(base + o); o += pad8(sizeof(Dag));
+    W.slot_cnt = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
+    W.fb = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.idx = reinterpret_cast<int32_t*>(base + o); o += pad8(4 * 64);
+    W.loops = reinterpret_cast<Rec3*>(base + o); o += pad8(sizeof(Rec3) * 64);
+    W.taken = base + o;
     return W;
 }
 
@@ -88,24 +101,20 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     for (int i = g.tid(); i <= n; i += g.size()) W.target_cn[i] = 0;
     g.sync();
 
-    int status = ST_OK, bias = 1;
+    int status = ST_OK;
     double inv_sum = 0;
-    if (g.tid() == 0) {
-        get_junc_cn(n, W.juncs, m, W.junc_cn, W.inv_junc);
-        bias = compute_bias(n, W.juncs, W.junc_cn, W.inv_junc);
-        int32_t* sv = A.scratch_i32 + A.scratch_off[u];
-        get_indel_bias(n, W.juncs, m, W.seg_cn, sv, sv + m);
-        inv_sum = inversion_cn_sum(n, W.junc_cn);
-        double a = inv_sum < 0 ? -inv_sum : inv_sum;
-        if (a < 0.000001 && !U.has_components) status = ST_SHORTCUT;   // localhap.cpp:164
-        else if (U.infeasible) status = ST_INFEASIBLE;               // localhap.cpp:213
-        else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
-        else {
-            add_target_cn(W.elems, K, n, W.target_cn);
-            status = construct_dag(W.elems, K, U.seg_base, *W.dag);
-        }
+    get_junc_cn_g(g, n, W.juncs, m, W.junc_cn, W.inv_junc, W.slot_cnt, W.fb);            // localhap.cpp:136-139
+    const int bias = compute_bias_g(g, n, W.juncs, W.junc_cn, W.inv_junc);                // :141-146
+    get_indel_bias_g(g, n, W.juncs, m, W.seg_cn, W.sv, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
+    const bool no_fbi = no_foldback_g(g, n, W.junc_cn, &inv_sum);                         // :150-153
+    if (no_fbi && !U.has_components) status = ST_SHORTCUT;                                // :164
+    else if (U.infeasible) status = ST_INFEASIBLE;                                        // :213
+    else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
+    else {
+        target_cn_g(g, W.elems, K, n, W.target_cn);                                       // :222-232
+        DagScratch DS{W.idx, W.loops};
+        status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS);                  // :236
     }
-    status = g.bcast_i32(status, 0);
     g.sync();
 
     uint64_t R = 0;
@@ -342,13 +351,16 @@ struct FinishWork {
     int32_t* sv;        // [m]
     int32_t* grp;       // [2m+4]
     int32_t* cand;      // [out_cap + bkp_cap]  candidate junction steps
+    int32_t* first;     // [2n+1] first occurrence of every vertex in the path
+    int32_t* last;      // [2n+1] last occurrence
     uint8_t* taken;     // [m]
+    uint8_t* has_ext;   // [m]
 };
-AMBI_HD int64_t finish_work_bytes(int m, int bkp_cap, int path_cap, int out_cap) {
+AMBI_HD int64_t finish_work_bytes(int n, int m, int bkp_cap, int path_cap, int out_cap) {
     return pad8(2ll * path_cap) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(Junction)) * m) +
-           pad8(4ll * m) + pad8(4ll * (2 * m + 4)) + pad8(4ll * (out_cap + bkp_cap)) + pad8(m);
+           pad8(4ll * m) + pad8(4ll * (2 * m + 4)) + pad8(4ll * (out_cap + bkp_cap)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
 }
-AMBI_HD FinishWork carve_finish(uint8_t* base, int m, int bkp_cap, int path_cap, int out_cap) {
+AMBI_HD FinishWork carve_finish(uint8_t* base, int n, int m, int bkp_cap, int path_cap, int out_cap) {
     FinishWork W;
     int64_t o = 0;
     W.path = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * path_cap);
@@ -358,7 +370,10 @@ AMBI_HD FinishWork carve_finish(uint8_t* base, int m, int bkp_cap, int path_cap,
     W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
     W.grp = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * m + 4));
     W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (out_cap + bkp_cap));
-    W.taken = base + o;
+    W.first = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
+    W.last = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
+    W.taken = base + o; o += pad8(m);
+    W.has_ext = base + o;
     return W;
 }
 
@@ -386,7 +401,7 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
         return;
     }
     if (status != ST_OK) return;
-    FinishWork W = carve_finish(work, m, U.bkp_cap, U.path_cap, U.out_cap);
+    FinishWork W = carve_finish(work, n, m, U.bkp_cap, U.path_cap, U.out_cap);
     const int L = out->bkp_len;
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
     copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
@@ -396,7 +411,7 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     if (P < 0) { if (g.tid() == 0) out->status = P; g.sync(); return; }
     for (int i = g.tid(); i < P; i += g.size()) { int v = W.path[i]; gpath[i] = v > 0 ? v + base : v - base; }
     int P2 = P;
-    IndelScratch S{W.sv, W.taken, W.grp};
+    IndelScratch S{W.sv, W.taken, W.has_ext, W.grp, W.first, W.last};
     int printed = indel_bfb(g, n, W.juncs, m, W.path, &P2, U.path_cap, S);
     if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
     for (int i = g.tid(); i < P2; i += g.size()) { int v = W.path[i]; gpath2[i] = v > 0 ? v + base : v - base; }

@@ -115,7 +115,7 @@ def planted_mixed(rng, s, e, K, cn_choices=(1, 2)):
 
 
 def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperfect=0, n_del=0, n_dup=0,
-                translocations=0, name=None, prop=None, cn_choices=(1, 2)):
+                translocations=0, name=None, prop=None, cn_choices=(1, 2), near_inv=0):
     """Build one synthetic sample. `tier` in {chain, wide, mixed}. For wide, K must be odd (K = 2k+1)."""
     rng = random.Random(seed)
     name = name or "syn_n%d_m%d_%s_K%d_s%d" % (n_seg, n_junc, tier, K, seed)
@@ -195,6 +195,17 @@ def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperf
                 break
             i = rng.randint(s + 2, e - 1)
             add(i, '+', i - 1, '+', 1)
+    # short inversions (strand switch 3..5 segments apart): the indelBFB "inversion" branch erases across them
+    for (s, e) in ranges[:1]:
+        for _ in range(near_inv):
+            if e - s < 8:
+                break
+            i = rng.randint(s, e - 5)
+            j = i + rng.randint(3, 5)
+            if rng.random() < 0.5:
+                add(i, '+', j, '-', 1)
+            else:
+                add(j, '-', i, '+', 1)
     # translocations between consecutive chromosomes
     for t in range(translocations):
         if n_chr < 2:
@@ -202,7 +213,11 @@ def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperf
         c0 = t % (n_chr - 1)
         (s0, e0), (s1, e1) = ranges[c0], ranges[c0 + 1]
         add(rng.randint(s0, e0), '+', rng.randint(s1, e1), '+', 1)
-    # padding: distant inversions inside a chromosome (ignored by getJuncCN/getIndelBias, seen by indelBFB)
+    # padding: distant head-to-head inversions  H:i:+ H:j:-  (|i-j| >= 6) inside a chromosome.  The reference ignores
+    # them in getJuncCN/getIndelBias, but indelBFB collects, groups and looks every one of them up in the path
+    # (LGM.cpp:3750-3818).  Head-to-head junctions cannot chain with one another in its deque grouping (an edge
+    # target is always a '-' vertex, a group front always '+'), so they stay 2-vertex "inversion" groups whose ends
+    # are more than 5 path cells apart: unexplained SVs that are examined but do not rewrite the BFB path.
     guard = 0
     while len(juncs) < n_junc and guard < 100 * n_junc:
         guard += 1
@@ -211,10 +226,7 @@ def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperf
             continue
         i = rng.randint(s, e - 7)
         j = rng.randint(i + 6, e)
-        if rng.random() < 0.5:
-            add(i, '+', j, '-', 1)
-        else:
-            add(i, '-', j, '+', 1)
+        add(i, '+', j, '-', 1)
     # text
     L = []
     L.append("SAMPLE_NAME %s" % name)

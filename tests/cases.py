@@ -25,6 +25,12 @@ def synthetic_cases(workdir, small_only=True):
             s = synth.make_sample(n, m, tier, K, seed, imperfect=seed % 3, n_del=seed % 2, n_dup=(seed + 1) % 2)
             lh, sols = s.write(workdir)
             out.append((s.name, lh, sols))
+    # SV-heavy samples: deletions, duplications and short inversions that really edit the path (indelBFB)
+    for seed in range(6):
+        s = synth.make_sample(48, 70 + 10 * seed, ("chain", "wide", "mixed")[seed % 3], 7, 700 + seed, imperfect=seed % 2,
+                              n_del=2 + seed, n_dup=1 + seed, near_inv=3 + seed, name="svheavy%d" % seed)
+        lh, sols = s.write(workdir)
+        out.append((s.name, lh, sols))
     # multi-chromosome with translocation (BFB-TRX, PROP C2)
     s = synth.make_sample(96, 200, "chain", 5, seed=11, n_chr=3, translocations=1, prop="PROP C2:chr1:chr2 M:chr1", name="multi3")
     lh, sols = s.write(workdir)

@@ -142,7 +142,7 @@ class HostSimBackend : public Backend {
         if (n_pending_ > 0) search_pending();
         for (int u = 0; u < Un; u++) {
             const UnitIn& U = units_[u];
-            std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_junc, U.bkp_cap, U.path_cap, U.out_cap));
+            std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, U.path_cap, U.out_cap));
             stage_finish(g, A_, u, work.data());
         }
         return 0;
