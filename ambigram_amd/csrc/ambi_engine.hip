@@ -124,6 +124,7 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
 // every byte of the table is written exactly once and nothing is staged through an LDS tile.
 // LDS per wave: [enum_stack_lds] per-lane DFS stacks (depth-major) | [enum_auto_lds] compact copy of the unit's
 // automaton (avail masks, child bases, child links) when it fits, else the automaton is read through L2.
+template <int CLS>
 __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int wave_bytes = A.enum_stack_lds + A.enum_auto_lds;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
         const int u = lo;
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
+        if (enum_class_of(K) != CLS) continue;   // rows of this width belong to another instantiation
         const int64_t R = out->num_orders;
         const int64_t base_rank = (b - A.blk_off[u]) * 64ll * T;
         const IdealTable tbl = unit_ideal_table(A, u);
@@ -147,17 +149,20 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
         const bool wide = K > 32;
         const int msz = wide ? 8 : 4;
         uint8_t* av_l = amem;
-        uint16_t* cb_l = reinterpret_cast<uint16_t*>(amem + (size_t)nI * msz);
+        uint32_t* rec_l = reinterpret_cast<uint32_t*>(amem + (size_t)nI * msz);
+        uint16_t* cb_l = reinterpret_cast<uint16_t*>(rec_l + nI);
         uint16_t* ch_l = cb_l + nI;
         if (u != staged_unit) {
             g.sync();
-            const int64_t need = (int64_t)nI * (msz + 2) + 2ll * nC + 16;
+            const int64_t need = (int64_t)nI * (msz + 6) + 2ll * nC + 16;
             in_lds = need <= A.enum_auto_lds && nC < 65536;
             if (in_lds) {
                 for (int i = lane; i < nI; i += 64) {
-                    if (wide) reinterpret_cast<uint64_t*>(av_l)[i] = V.avail[i];
-                    else reinterpret_cast<uint32_t*>(av_l)[i] = (uint32_t)V.avail[i];
+                    const uint64_t av = V.avail[i];
+                    if (wide) reinterpret_cast<uint64_t*>(av_l)[i] = av;
+                    else reinterpret_cast<uint32_t*>(av_l)[i] = (uint32_t)av;
                     cb_l[i] = (uint16_t)V.cbase[i];
+                    rec_l[i] = av ? make_rec(av, V.child[V.cbase[i]]) : 0u;
                 }
                 for (int i = lane; i < nC; i += 64) ch_l[i] = V.child[i];
             }
@@ -167,12 +172,12 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
         uint8_t* rows = A.order_arena + out->order_off;   // 16-byte aligned; lane ranges start at multiples of 4 rows
         const int64_t first = base_rank + (int64_t)lane * T;
         if (in_lds) {
-            LdsAuto<uint32_t> a32{reinterpret_cast<const uint32_t*>(av_l), cb_l, ch_l};
-            LdsAuto<uint64_t> a64{reinterpret_cast<const uint64_t*>(av_l), cb_l, ch_l};
-            enumerate_lane_dispatch(a32, a64, V, K, R, first, T, stacks, lane, 64, rows);
+            LdsAuto<uint32_t> a32{reinterpret_cast<const uint32_t*>(av_l), rec_l, cb_l, ch_l};
+            LdsAuto<uint64_t> a64{reinterpret_cast<const uint64_t*>(av_l), rec_l, cb_l, ch_l};
+            enumerate_lane_dispatch<CLS>(a32, a64, V, K, R, first, T, stacks, lane, 64, rows);
         } else {
             GlobalAuto ga{V};
-            enumerate_lane_dispatch(ga, ga, V, K, R, first, T, stacks, lane, 64, rows);
+            enumerate_lane_dispatch<CLS>(ga, ga, V, K, R, first, T, stacks, lane, 64, rows);
         }
     }
 }
@@ -292,7 +297,7 @@ class HipBackend : public Backend {
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; int32_t* d_ilvl_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
     int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
-    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096;
+    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096, enum_classes_ = 0;
     uint8_t* d_arena_ = nullptr; int64_t arena_bytes_ = 0;
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
@@ -376,7 +381,7 @@ class HipBackend : public Backend {
         lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
         lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
         lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
-        enum_stack_lds_ = (int)(hb.max_k > 32 ? enum_stack_bytes<uint64_t>(hb.max_k) : enum_stack_bytes<uint32_t>(hb.max_k > 0 ? hb.max_k : 1));
+        enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         const int kLdsLimit = 160 * 1024 - 1024;
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit) {
@@ -388,7 +393,11 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
+        enum_classes_ = 0;
+        for (const UnitIn& un : hb.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
         uploaded_ = true; arena_checked_ = false;
         return 0;
     }
@@ -457,7 +466,9 @@ class HipBackend : public Backend {
         }
         const int U = A_.n_units;
         tick("ambi_enumerate_kernel", 2, true);
-        hipLaunchKernelGGL(ambi_enumerate_kernel, dim3(2048), dim3(256), lds_enum_, stream_, A_);
+        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
+        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
+        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
         tick("ambi_enumerate_kernel", 2, false);
         tick("ambi_first_kernel", 3, true);
         hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, stream_, A_);

@@ -273,38 +273,66 @@ struct PackedRow {
 #pragma unroll
         for (int i = 0; i < NW; i++) w[i] = v;
     }
-    AMBI_HD void set(int d, uint32_t val) {
-        const int wi = d >> 2, sh = (d & 3) * 8;
-        const uint32_t m = ~(0xFFu << sh), x = val << sh;
+    AMBI_HD uint32_t word(int wi) const {
+        uint32_t r = 0;
 #pragma unroll
-        for (int i = 0; i < NW; i++) w[i] = (i == wi) ? ((w[i] & m) | x) : w[i];
+        for (int i = 0; i < NW; i++) r = (i == wi) ? w[i] : r;
+        return r;
+    }
+    AMBI_HD void set_word(int wi, uint32_t v) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) w[i] = (i == wi) ? v : w[i];
+    }
+    AMBI_HD uint32_t get(int d) const { return (word(d >> 2) >> ((d & 3) * 8)) & 0xFFu; }
+    AMBI_HD void set(int d, uint32_t val) {
+        const int sh = (d & 3) * 8;
+        set_word(d >> 2, (word(d >> 2) & ~(0xFFu << sh)) | (val << sh));
     }
 };
 
+// Greedy-descent record of an ideal: [15:0] index of its first child (lowest available node appended),
+// [23:16] that node, [24] the ideal has more than one available node (= a branch point of the DFS).
+AMBI_HD uint32_t make_rec(uint64_t av, int first_child) {
+    return (uint32_t)first_child | ((uint32_t)ctz64(av) << 16) | ((popc64(av) > 1 ? 1u : 0u) << 24);
+}
+
 // Automaton accessors.  GlobalAuto reads the 64-bit tables in HBM/L2; LdsAuto reads a compact copy (mask type M,
-// 16-bit child bases) staged in the group's memory.
+// greedy-descent records, 16-bit child bases and links) staged in the group's memory.
+// mask arithmetic in the width of the mask type (32-bit ALU ops while K <= 32)
+AMBI_HD int mctz(uint32_t x) { return __builtin_ctz(x); }
+AMBI_HD int mctz(uint64_t x) { return __builtin_ctzll(x); }
+AMBI_HD int mpopc(uint32_t x) { return __builtin_popcount(x); }
+AMBI_HD int mpopc(uint64_t x) { return __builtin_popcountll(x); }
+template <class M> AMBI_HD M mbelow(int v) { return (M)(((M)1 << v) - 1); }          // bits < v
+template <class M> AMBI_HD M mabove(int v) { return (M)~((((M)2) << v) - 1); }       // bits > v  (v <= width-2)
+
 struct GlobalAuto {
+    typedef uint64_t mask_t;
     AutoView A;
     AMBI_HD uint64_t avail(int i) const { return A.avail[i]; }
-    AMBI_HD int child(int i, uint64_t av, int v) const { return A.child[A.cbase[i] + popc64(av & ((1ull << v) - 1))]; }
+    AMBI_HD int child(int i, uint64_t av, int v) const { return A.child[A.cbase[i] + mpopc(av & mbelow<uint64_t>(v))]; }
+    AMBI_HD uint32_t rec(int i) const { return make_rec(A.avail[i], A.child[A.cbase[i]]); }
 };
 template <class M>
 struct LdsAuto {
+    typedef M mask_t;
     const M* av_;           // [nI]
+    const uint32_t* rec_;   // [nI]
     const uint16_t* cb_;    // [nI]
     const uint16_t* ch_;    // [nC]
-    AMBI_HD uint64_t avail(int i) const { return (uint64_t)av_[i]; }
-    AMBI_HD int child(int i, uint64_t av, int v) const { return ch_[cb_[i] + popc64(av & ((1ull << v) - 1))]; }
+    AMBI_HD M avail(int i) const { return av_[i]; }
+    AMBI_HD int child(int i, M av, int v) const { return ch_[cb_[i] + mpopc((M)(av & mbelow<M>(v)))]; }
+    AMBI_HD uint32_t rec(int i) const { return rec_[i]; }
 };
 template <class M>
-AMBI_HD int64_t lds_auto_bytes(int nI, int nC) { return (int64_t)nI * (int64_t)(sizeof(M) + 2) + 2ll * nC + 16; }
+AMBI_HD int64_t lds_auto_bytes(int nI, int nC) { return (int64_t)nI * (int64_t)(sizeof(M) + 6) + 2ll * nC + 16; }
 
-// Per-lane DFS stacks (depth-major so that the 64 lanes of one depth are contiguous): element d at [d*stride].
-template <class M>
+// Per-lane DFS stacks, only meaningful at BRANCH depths (positions that still have a larger available node):
+// idx = ideal before that position, prev = next shallower branch depth (0xFF: none).  Depth-major layout so that
+// the 64 lanes of one depth are contiguous: element d at [d*stride].
 struct LaneStacks {
-    M* avail;        // available nodes of the ideal BEFORE position d
-    uint16_t* idx;   // index of that ideal
-    uint8_t* ord;    // node placed at position d
+    uint16_t* idx;
+    uint8_t* prev;
     int stride;
 };
 
@@ -319,19 +347,22 @@ AMBI_HD void store4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t 
 
 // Writes rows [first, first+nrows) of the order table.  `out` points at row `first` (16-byte aligned; rows are NW
 // dwords).  Requires first + nrows <= R.  One thread; all lanes of a wave run it in lockstep on their own ranges.
-template <int NW, class M, class AUTO>
+//
+// DFS without a backtracking loop: `top` is the deepest branch depth, every branch depth remembers the next
+// shallower one, so the successor jumps straight to `top`, takes the next larger available node there and then
+// descends greedily -- one greedy-descent record (one LDS read) per level.
+template <int NW, class AUTO>
 AMBI_HD void enumerate_rows(const AUTO& au, const AutoView& cntView, int K, uint64_t first, int nrows,
-                            const LaneStacks<M>& S, uint32_t* out) {
+                            const LaneStacks& S, uint32_t* out) {
     PackedRow<NW> row;
     row.fill(0xFFFFFFFFu);
-    // ---- unrank the first order, filling the stacks ----
+    int top = -1;
+    // ---- unrank the first order, recording the branch depths ----
     {
         int i = 0;
         uint64_t r = first;
         for (int d = 0; d < K; d++) {
-            uint64_t av = au.avail(i);
-            S.avail[d * S.stride] = (M)av;
-            S.idx[d * S.stride] = (uint16_t)i;
+            const uint64_t av = cntView.avail[i];
             int k = cntView.cbase[i];
             uint64_t a2 = av;
             int chosen = -1, j = 0;
@@ -344,39 +375,44 @@ AMBI_HD void enumerate_rows(const AUTO& au, const AutoView& cntView, int K, uint
                 r -= c;
             }
             if (chosen < 0) return;   // rank out of range (caller guarantees this cannot happen)
-            S.ord[d * S.stride] = (uint8_t)chosen;
+            if (a2) {                 // a larger available node remains at this depth
+                S.idx[d * S.stride] = (uint16_t)i;
+                S.prev[d * S.stride] = (uint8_t)(top < 0 ? 0xFF : top);
+                top = d;
+            }
             row.set(d, (uint32_t)chosen);
             i = j;
         }
     }
-    // ---- lexicographic successor: deepest position with a larger available node ----
-    auto successor = [&]() -> bool {
-        int d = K - 2;          // position K-1 never has an alternative (exactly one node is left)
-        uint64_t cand = 0;
-        while (d >= 0) {
-            uint64_t av = (uint64_t)S.avail[d * S.stride];
-            int v = S.ord[d * S.stride];
-            cand = av & ~((2ull << v) - 1);
-            if (cand) break;
-            d--;
-        }
-        if (d < 0) return false;   // was the last order
-        uint64_t av = (uint64_t)S.avail[d * S.stride];
-        int i = S.idx[d * S.stride];
-        int w = ctz64(cand);
-        S.ord[d * S.stride] = (uint8_t)w;
-        row.set(d, (uint32_t)w);
+    // ---- lexicographic successor ----
+    auto successor = [&]() {
+        const int d = top;
+        if (d < 0) return;         // was the last order
+        typedef typename AUTO::mask_t M;
+        const int i = S.idx[d * S.stride];
+        const M av = au.avail(i);
+        const int v = (int)row.get(d);
+        const M cand = (M)(av & mabove<M>(v));
+        const int w = mctz(cand);
+        int nt = d;
+        if ((M)(cand & (M)(cand - 1)) == 0) { int p = S.prev[d * S.stride]; nt = (p == 0xFF) ? -1 : p; }
         int j = au.child(i, av, w);
+        int wi = d >> 2;
+        uint32_t cur = row.word(wi);
+        { const int sh = (d & 3) * 8; cur = (cur & ~(0xFFu << sh)) | ((uint32_t)w << sh); }
         for (int e = d + 1; e < K; e++) {
-            uint64_t a = au.avail(j);
-            int x = ctz64(a);
-            S.avail[e * S.stride] = (M)a;
-            S.idx[e * S.stride] = (uint16_t)j;
-            S.ord[e * S.stride] = (uint8_t)x;
-            row.set(e, (uint32_t)x);
-            if (e + 1 < K) j = au.child(j, a, x);
+            const uint32_t rc = au.rec(j);
+            if ((e & 3) == 0) { row.set_word(wi, cur); wi++; cur = 0xFFFFFFFFu; }
+            { const int sh = (e & 3) * 8; cur = (cur & ~(0xFFu << sh)) | (((rc >> 16) & 0xFFu) << sh); }
+            if (rc & (1u << 24)) {
+                S.idx[e * S.stride] = (uint16_t)j;
+                S.prev[e * S.stride] = (uint8_t)(nt < 0 ? 0xFF : nt);
+                nt = e;
+            }
+            j = (int)(rc & 0xFFFFu);
         }
-        return true;
+        row.set_word(wi, cur);
+        top = nt;
     };
     // rows leave in groups of four (4*NW dwords = NW 16-byte stores); every register index below is static
     for (int r0 = 0; r0 < nrows; r0 += 4) {

@@ -202,8 +202,7 @@ AMBI_HD void plan_serial(const BatchArgs& A) {
 // Per-lane DFS stacks live in group memory; the automaton is read from a compact LDS copy when it fits
 // (LdsAuto) and from HBM/L2 otherwise (GlobalAuto).
 // ---------------------------------------------------------------------------------------------
-template <class M>
-AMBI_HD int64_t enum_stack_bytes(int K) { return pad8(int64_t(64) * K * (int64_t)(sizeof(M) + 3)); }
+AMBI_HD int64_t enum_stack_bytes(int K) { return pad8(int64_t(64) * K * 3); }
 
 template <int NW, class M, class AUTO>
 AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R, int64_t first_rank, int T,
@@ -211,32 +210,44 @@ AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R,
     if (first_rank >= R) return;
     int64_t nrows = R - first_rank;
     if (nrows > T) nrows = T;
-    LaneStacks<M> S;
+    LaneStacks S;
     S.stride = lanes;
-    S.avail = reinterpret_cast<M*>(stack_mem) + lane;
-    S.idx = reinterpret_cast<uint16_t*>(stack_mem + (size_t)lanes * K * sizeof(M)) + lane;
-    S.ord = stack_mem + (size_t)lanes * K * (sizeof(M) + 2) + lane;
+    S.idx = reinterpret_cast<uint16_t*>(stack_mem) + lane;
+    S.prev = stack_mem + (size_t)lanes * K * 2 + lane;
     uint32_t* out = reinterpret_cast<uint32_t*>(unit_rows + first_rank * (int64_t)(NW * 4));
-    enumerate_rows<NW, M, AUTO>(au, V, K, (uint64_t)first_rank, (int)nrows, S, out);
+    enumerate_rows<NW, AUTO>(au, V, K, (uint64_t)first_rank, (int)nrows, S, out);
 }
 
-// dispatch on K: NW = Kpad/4 dwords per row; 32-bit masks while K <= 32
-template <class AUTO32, class AUTO64>
+// Row-width classes of the enumerate kernel (one kernel instantiation each, so that the register budget of the wide
+// rows does not throttle the occupancy of the narrow ones): 0: K <= 20, 1: K <= 32, 2: K <= 63.
+AMBI_HD int enum_class_of(int K) { return K <= 20 ? 0 : (K <= 32 ? 1 : 2); }
+
+// dispatch on K: NW = Kpad/4 dwords per row; 32-bit masks while K <= 32.  CLS < 0: all classes (host simulation).
+template <int CLS, class AUTO32, class AUTO64>
 AMBI_HD void enumerate_lane_dispatch(const AUTO32& a32, const AUTO64& a64, const AutoView& V, int K, int64_t R,
                                      int64_t first_rank, int T, uint8_t* stack_mem, int lane, int lanes, uint8_t* unit_rows) {
     const int nw = row_stride(K) / 4;
-    switch (nw) {
-        case 1: enumerate_lane<1, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 2: enumerate_lane<2, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 3: enumerate_lane<3, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 4: enumerate_lane<4, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 5: enumerate_lane<5, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 6: enumerate_lane<6, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 7: enumerate_lane<7, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 8: enumerate_lane<8, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        case 9: case 10: case 11: case 12:
-            enumerate_lane<12, uint64_t>(a64, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
-        default: enumerate_lane<16, uint64_t>(a64, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); break;
+    if (CLS < 0 || CLS == 0) {
+        switch (nw) {
+            case 1: enumerate_lane<1, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            case 2: enumerate_lane<2, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            case 3: enumerate_lane<3, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            case 4: enumerate_lane<4, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            case 5: enumerate_lane<5, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            default: break;
+        }
+    }
+    if (CLS < 0 || CLS == 1) {
+        switch (nw) {
+            case 6: enumerate_lane<6, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            case 7: enumerate_lane<7, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            case 8: enumerate_lane<8, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
+            default: break;
+        }
+    }
+    if (CLS < 0 || CLS == 2) {
+        if (nw == 12) enumerate_lane<12, uint64_t>(a64, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows);
+        else if (nw == 16) enumerate_lane<16, uint64_t>(a64, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows);
     }
 }
 

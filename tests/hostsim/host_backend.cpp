@@ -68,7 +68,7 @@ class HostSimBackend : public Backend {
     void enumerate_all() {
         HostGroup g;
         const int64_t total = blk_off_[units_.size()];
-        std::vector<uint8_t> stacks((size_t)enum_stack_bytes<uint64_t>(64));
+        std::vector<uint8_t> stacks((size_t)enum_stack_bytes(64));
         for (int64_t b = 0; b < total; b++) {
             int lo = 0, hi = (int)units_.size();
             while (hi - lo > 1) { int mid = (lo + hi) / 2; if (blk_off_[mid] <= b) lo = mid; else hi = mid; }
@@ -80,7 +80,7 @@ class HostSimBackend : public Backend {
             AutoView V = auto_view(tbl);
             GlobalAuto ga{V};
             for (int lane = 0; lane < 64; lane++)
-                enumerate_lane_dispatch(ga, ga, V, K, R, base_rank + (int64_t)lane * T, T, stacks.data(), lane, 64,
+                enumerate_lane_dispatch<-1>(ga, ga, V, K, R, base_rank + (int64_t)lane * T, T, stacks.data(), lane, 64,
                                         A_.order_arena + out->order_off);
         }
         (void)g;
