@@ -52,6 +52,7 @@ def _declare(L):
         "ambi_graph_segments": (C.c_int, [vp, pi32, pi32, pi32, pi32, pd, pd]),
         "ambi_graph_junctions": (C.c_int, [vp, pi32, pi8, pi32, pi8, pd, pd, pu8, pu8]),
         "ambi_graph_chromosome": (C.c_int, [vp, i32, pi32, pi32]),
+        "ambi_graph_chrom_name": (i64, [vp, i32, C.c_char_p, i64]),
         "ambi_graph_read_juncs": (C.c_int, [vp, C.c_char_p]),
         "ambi_graph_log": (i64, [vp, C.c_char_p, i64]),
         "ambi_graph_props": (C.c_int, [vp, pi32, pi32, C.c_char_p, i64]),
@@ -81,6 +82,11 @@ def _declare(L):
         "ambi_batch_traffic": (C.c_int, [vp, pi64, pi64, pi64]),
         "ambi_format_path": (i64, [vp, pi32, i32, C.c_char_p, i64]),
         "ambi_translocation_bfb": (C.c_int, [vp, pi32, pi64, i32, pi32, i32]),
+        "ambi_ilp_build": (C.c_int, [vp, i32, pd, pd, i32, C.c_double, i32, _P(vp)]),
+        "ambi_ilp_destroy": (None, [vp]),
+        "ambi_ilp_sizes": (C.c_int, [vp, pi64, pi64, pi32, pi32]),
+        "ambi_ilp_copy": (C.c_int, [vp, pi64, pi32, pd, pd, pd, pd, pd, pd]),
+        "ambi_ilp_write_lp": (C.c_int, [vp, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -493,3 +499,39 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
     b.close()
     g.close()
     return res
+
+
+class IlpModel:
+    """ILP of one chromosome (BFB_ILP, LGM.cpp:4397-4752) built on the host in closed form."""
+
+    def __init__(self, lib, graph, chr_, seg_cn, junc_cn, bias, max_cn_total, juncs_info=False):
+        self.lib = lib
+        self.h = C.c_void_p()
+        sc = np.ascontiguousarray(seg_cn, np.float64)
+        jc = np.ascontiguousarray(np.asarray(junc_cn, np.float64).reshape(-1))
+        rc = lib.ambi_ilp_build(graph.h, chr_, sc.ctypes.data_as(_P(C.c_double)), jc.ctypes.data_as(_P(C.c_double)), int(bias),
+                                float(max_cn_total), 1 if juncs_info else 0, C.byref(self.h))
+        if rc != 0:
+            raise AmbiError(lib, rc, "ilp_build")
+        r, z, c, i = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        lib.ambi_ilp_sizes(self.h, C.byref(r), C.byref(z), C.byref(c), C.byref(i))
+        self.n_rows, self.nnz, self.n_cols, self.n_int = r.value, z.value, c.value, i.value
+
+    def arrays(self):
+        rp = np.zeros(self.n_rows + 1, np.int64); col = np.zeros(self.nnz, np.int32); val = np.zeros(self.nnz)
+        rlo, rup = np.zeros(self.n_rows), np.zeros(self.n_rows)
+        clo, cup, obj = np.zeros(self.n_cols), np.zeros(self.n_cols), np.zeros(self.n_cols)
+        p = lambda a, t: a.ctypes.data_as(_P(t))
+        self.lib.ambi_ilp_copy(self.h, p(rp, C.c_int64), p(col, C.c_int32), p(val, C.c_double), p(rlo, C.c_double), p(rup, C.c_double),
+                               p(clo, C.c_double), p(cup, C.c_double), p(obj, C.c_double))
+        return dict(row_ptr=rp, col=col, val=val, row_lo=rlo, row_up=rup, col_lo=clo, col_up=cup, obj=obj)
+
+    def write_lp(self, path):
+        rc = self.lib.ambi_ilp_write_lp(self.h, path.encode())
+        if rc != 0:
+            raise AmbiError(self.lib, rc, "write_lp")
+
+    def close(self):
+        if self.h:
+            self.lib.ambi_ilp_destroy(self.h)
+            self.h = C.c_void_p()

@@ -199,6 +199,7 @@ int ambi_batch_upload(ambi_batch_t* b) {
 int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream) {
     if (!b) return AMBI_ERR_ARG;
     if (!b->uploaded) return AMBI_ERR_STATE;
+    if (flags & AMBI_FLAG_ALL) return AMBI_ERR_UNSUPPORTED;   // --all (every valid order) is not on the device yet: refuse, never guess
     b->downloaded = false;
     return b->be->run(flags, hip_stream);
 }
@@ -338,6 +339,60 @@ int ambi_translocation_bfb(const ambi_graph_t* g, int32_t* paths, const int64_t*
         for (size_t i = 0; i < pp[c].size(); i++) paths[offsets[c] + i] = pp[c][i];
     if (out) for (size_t i = 0; i < res.size() && (int)i < cap; i++) out[i] = res[i];
     return (int)res.size();
+}
+
+}  // extern "C"
+
+// ---- ILP model of one chromosome (host; LocalGenomicMap::BFB_ILP, LGM.cpp:4397-4752) ----
+#include "ambi_ilp.hpp"
+struct ambi_ilp { ambi::IlpModel m; };
+
+extern "C" {
+
+int ambi_ilp_build(const ambi_graph_t* g, int32_t chr, const double* seg_cn, const double* junc_cn, int32_t bias,
+                   double max_cn_total, int32_t juncs_info, ambi_ilp_t** out) {
+    if (!g || !seg_cn || !junc_cn || !out || chr < 0 || chr >= g->g.n_chr()) return AMBI_ERR_ARG;
+    const int s = g->g.source_ids[chr], e = g->g.sink_ids[chr], n = e - s + 1;
+    std::vector<double> cn(n), fold(n);
+    for (int i = 0; i < n; i++) { cn[i] = seg_cn[i + 1]; fold[i] = junc_cn[2 * (i + 1) + 1]; }
+    std::vector<std::vector<int32_t>> comps;
+    for (auto& c : g->g.components)
+        if (!c.empty() && c[0] >= 1 && c[0] <= g->g.n_seg() && g->g.seg_partition[c[0] - 1] == chr) comps.push_back(c);
+    ambi_ilp* p = new ambi_ilp();
+    ambi::build_bfb_ilp(s, e, cn.data(), fold.data(), bias, max_cn_total, comps, juncs_info != 0, p->m);
+    *out = p;
+    return 0;
+}
+void ambi_ilp_destroy(ambi_ilp_t* p) { delete p; }
+int ambi_ilp_sizes(const ambi_ilp_t* p, int64_t* n_rows, int64_t* nnz, int32_t* n_cols, int32_t* n_int) {
+    if (!p) return AMBI_ERR_ARG;
+    if (n_rows) *n_rows = p->m.n_rows();
+    if (nnz) *nnz = p->m.nnz();
+    if (n_cols) *n_cols = p->m.n_cols;
+    if (n_int) *n_int = p->m.n_int;
+    return 0;
+}
+int ambi_ilp_copy(const ambi_ilp_t* p, int64_t* row_ptr, int32_t* col, double* val, double* row_lo, double* row_up,
+                  double* col_lo, double* col_up, double* obj) {
+    if (!p) return AMBI_ERR_ARG;
+    const ambi::IlpModel& m = p->m;
+    if (row_ptr) memcpy(row_ptr, m.row_ptr.data(), m.row_ptr.size() * sizeof(int64_t));
+    if (col) memcpy(col, m.col.data(), m.col.size() * sizeof(int32_t));
+    if (val) memcpy(val, m.val.data(), m.val.size() * sizeof(double));
+    if (row_lo) memcpy(row_lo, m.row_lo.data(), m.row_lo.size() * sizeof(double));
+    if (row_up) memcpy(row_up, m.row_up.data(), m.row_up.size() * sizeof(double));
+    if (col_lo) memcpy(col_lo, m.col_lo.data(), m.col_lo.size() * sizeof(double));
+    if (col_up) memcpy(col_up, m.col_up.data(), m.col_up.size() * sizeof(double));
+    if (obj) memcpy(obj, m.obj.data(), m.obj.size() * sizeof(double));
+    return 0;
+}
+int64_t ambi_graph_chrom_name(const ambi_graph_t* g, int32_t seg_id, char* buf, int64_t cap) {
+    if (!g || seg_id < 1 || seg_id > g->g.n_seg()) return AMBI_ERR_ARG;
+    return copy_text(g->g.seg_chrom[seg_id - 1], buf, cap);
+}
+int ambi_ilp_write_lp(const ambi_ilp_t* p, const char* path) {
+    if (!p || !path) return AMBI_ERR_ARG;
+    return ambi::write_lp(path, p->m) ? 0 : AMBI_ERR_OPEN;
 }
 
 }  // extern "C"

@@ -1,0 +1,162 @@
+// ambi_ilp.cpp -- see ambi_ilp.hpp
+#include "ambi_ilp.hpp"
+
+#include <cfloat>
+#include <cstdio>
+#include <set>
+
+namespace ambi {
+
+namespace {
+struct Tri {   // index arithmetic of the (a,b), s <= a <= b <= e triangle in lexicographic order
+    int s, e, n, num_pat;
+    Tri(int s_, int e_) : s(s_), e(e_), n(e_ - s_ + 1), num_pat((e_ - s_ + 1) * (e_ - s_ + 2) / 2) {}
+    int P(int a, int b) const { int da = a - s; return da * n - da * (da - 1) / 2 + (b - a); }
+    int L(int a, int b) const { return num_pat + P(a, b); }
+};
+}  // namespace
+
+void build_bfb_ilp(int s, int e, const double* seg_cn, const double* fold_cn, int bias, double max_cn_total,
+                   const std::vector<std::vector<int32_t>>& components, bool juncs_info, IlpModel& m) {
+    const double INF = DBL_MAX;
+    const Tri T(s, e);
+    const int n = T.n, num_pat = T.num_pat, num_el = 2 * num_pat, num_eps = 2 * n;
+    const int num_var = num_el + num_eps + 1;
+    m = IlpModel();
+    m.n_cols = num_var;
+    m.n_int = num_el;
+    m.row_ptr.push_back(0);
+    auto put = [&](int c, double v) { m.col.push_back(c); m.val.push_back(v); };
+    auto end_row = [&](double lo, double up) { m.row_ptr.push_back((int64_t)m.col.size()); m.row_lo.push_back(lo); m.row_up.push_back(up); };
+
+    // -- per segment: CN fit +-eps (LGM.cpp:4426-4451) and fold-back fit +-eps (LGM.cpp:4453-4494)
+    for (int i = s; i <= e; i++) {
+        const int k = i - s;
+        for (int rep = 0; rep < 2; rep++) {
+            // elements covering i, in (a,b) order: patterns (coef 1), then loops (coef 2)
+            for (int a = s; a <= i; a++) for (int b = i; b <= e; b++) put(T.P(a, b), 1);
+            for (int a = s; a <= i; a++) for (int b = i; b <= e; b++) put(T.L(a, b), 2);
+            put(num_el + 2 * k, rep == 0 ? 1 : -1);
+            if (rep == 0) end_row(seg_cn[k], INF); else end_row(-INF, seg_cn[k]);
+        }
+        for (int rep = 0; rep < 2; rep++) {
+            // patterns starting at i (when another one exists) and ending at i get 0.5, in column order
+            // (column order = (a,b) lexicographic: rows a < i first, then the a == i row)
+            if (i > s) for (int a = s; a < i; a++) put(T.P(a, i), 0.5);
+            if (i < e) for (int b = i; b <= e; b++) put(T.P(i, b), 0.5);
+            else if (i > s) put(T.P(i, i), 0.5);
+            // loops with an end at i: coef 1, column order
+            for (int a = s; a < i; a++) put(T.L(a, i), 1);
+            for (int b = i; b <= e; b++) put(T.L(i, b), 1);
+            put(num_el + 2 * k + 1, rep == 0 ? 1 : -1);
+            if (rep == 0) end_row(fold_cn[k], INF); else end_row(-INF, fold_cn[k]);
+        }
+    }
+    put(num_var - 1, 1); end_row(bias, bias);   // LGM.cpp:4498-4503
+
+    // -- pattern nesting (LGM.cpp:4544-4583)
+    for (int a = s; a <= e; a++) for (int b = a; b <= e; b++) {
+        if (a > s || b < e) {
+            for (int j = s; j < a; j++) put(T.P(j, b), 1);
+            for (int j = b + 1; j <= e; j++) put(T.P(a, j), 1);
+            put(T.P(a, b), -1); end_row(0, INF);
+        }
+        if (a < b) {
+            for (int j = a; j < b; j++) put(T.P(a, j), 1);
+            for (int j = a + 1; j <= b; j++) put(T.P(j, b), 1);
+            put(T.P(a, b), 1); end_row(0, 2);
+        }
+    }
+    // -- child loops need a parent (LGM.cpp:4587-4612)
+    for (int a = s; a <= e; a++) for (int b = a; b <= e; b++) {
+        if (a > s || b < e) {
+            for (int j = s; j < a; j++) { put(T.P(j, b), 1); put(T.L(j, b), 1); }
+            for (int j = b + 1; j <= e; j++) { put(T.P(a, j), 1); put(T.L(a, j), 1); }
+            put(T.L(a, b), -1); end_row(0, INF);
+        }
+    }
+    // -- loop + child loops (LGM.cpp:4615-4646)
+    for (int a = s; a <= e; a++) for (int b = a + 1; b <= e; b++) {
+        for (int rep = 0; rep < 2; rep++) {
+            for (int j = a; j < b; j++) put(T.L(a, j), 1);
+            for (int j = a + 1; j <= b; j++) put(T.L(j, b), 1);
+            put(rep == 0 ? T.L(a, b) : T.P(a, b), 1); end_row(0, 2);
+        }
+    }
+    // -- pattern + child loops/patterns (LGM.cpp:4649-4681)
+    for (int a = s; a <= e; a++) for (int b = a + 1; b <= e; b++) {
+        for (int j = a; j < b; j++) put(T.L(a, j), 1);
+        for (int j = a + 1; j <= b; j++) put(T.P(j, b), 1);
+        put(T.P(a, b), 1); end_row(0, 2);
+        for (int j = a; j < b; j++) put(T.P(a, j), 1);
+        for (int j = a + 1; j <= b; j++) put(T.L(j, b), 1);
+        put(T.P(a, b), 1); end_row(0, 2);
+    }
+    // -- linked/long-read components (LGM.cpp:4684-4703)
+    if (!components.empty() && juncs_info) {
+        std::set<std::pair<int, int>> seen;
+        for (auto& c : components) {
+            if (c.empty()) continue;
+            int lo = c.front() < c.back() ? c.front() : c.back(), hi = c.front() < c.back() ? c.back() : c.front();
+            if (lo == s && hi == e) continue;
+            if (!seen.insert({lo, hi}).second) continue;
+            bool in = lo >= s && hi <= e;
+            put(in ? T.L(lo, hi) : 0, 1);
+            put(in ? T.P(lo, hi) : 0, 1);
+        }
+        end_row(0, 5);
+    }
+    // -- bounds, objective (LGM.cpp:4708-4747)
+    m.col_lo.assign(num_var, 0); m.col_up.assign(num_var, INF); m.obj.assign(num_var, 0);
+    for (int c = 0; c < num_pat; c++) m.col_up[c] = 1;
+    for (int c = num_pat; c < num_el; c++) m.col_up[c] = max_cn_total;
+    for (int c = num_el; c < num_var - 1; c++) m.obj[c] = 1;
+    m.col_lo[num_var - 1] = m.col_up[num_var - 1] = bias;
+    m.obj[num_var - 1] = -1;
+}
+
+bool write_lp(const std::string& path, const IlpModel& m) {
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    const double INF = DBL_MAX;
+    auto term = [&](double v, int c, bool first) {
+        if (v == 1) fprintf(f, first ? " x%d" : " + x%d", c);
+        else if (v == -1) fprintf(f, " - x%d", c);
+        else if (v < 0) fprintf(f, " - %.15g x%d", -v, c);
+        else fprintf(f, first ? " %.15g x%d" : " + %.15g x%d", v, c);
+    };
+    fprintf(f, "\\Problem name: ambigram_bfb\n\nMinimize\nobj:");
+    bool first = true; int on_line = 0;
+    for (int c = 0; c < m.n_cols; c++) if (m.obj[c] != 0) { term(m.obj[c], c, first); first = false; if (++on_line % 8 == 0) fprintf(f, "\n"); }
+    fprintf(f, "\nSubject To\n");
+    int64_t name = 0;
+    for (int64_t r = 0; r < m.n_rows(); r++) {
+        const double lo = m.row_lo[r], up = m.row_up[r];
+        auto body = [&]() {
+            bool fst = true; int cnt = 0;
+            for (int64_t k = m.row_ptr[r]; k < m.row_ptr[r + 1]; k++) { term(m.val[k], m.col[k], fst); fst = false; if (++cnt % 8 == 0) fprintf(f, "\n"); }
+        };
+        bool nonneg = true;
+        for (int64_t k = m.row_ptr[r]; k < m.row_ptr[r + 1]; k++) if (m.val[k] < 0) nonneg = false;
+        if (lo == up) { fprintf(f, "R%lld:", (long long)name++); body(); fprintf(f, " = %.15g\n", lo); }
+        else if (lo <= -INF) { fprintf(f, "R%lld:", (long long)name++); body(); fprintf(f, " <= %.15g\n", up); }
+        else if (up >= INF) { fprintf(f, "R%lld:", (long long)name++); body(); fprintf(f, " >= %.15g\n", lo); }
+        else {
+            fprintf(f, "R%lld:", (long long)name++); body(); fprintf(f, " <= %.15g\n", up);
+            if (!(lo <= 0 && nonneg)) { fprintf(f, "R%lld:", (long long)name++); body(); fprintf(f, " >= %.15g\n", lo); }
+        }
+    }
+    fprintf(f, "Bounds\n");
+    for (int c = 0; c < m.n_cols; c++) {
+        if (m.col_lo[c] == m.col_up[c]) fprintf(f, " x%d = %.15g\n", c, m.col_lo[c]);
+        else if (m.col_up[c] >= INF) { if (m.col_lo[c] != 0) fprintf(f, " x%d >= %.15g\n", c, m.col_lo[c]); }
+        else fprintf(f, " %.15g <= x%d <= %.15g\n", m.col_lo[c], c, m.col_up[c]);
+    }
+    fprintf(f, "Integers\n");
+    for (int c = 0; c < m.n_int; c++) fprintf(f, " x%d%s", c, (c % 10 == 9) ? "\n" : "");
+    fprintf(f, "\nEnd\n");
+    fclose(f);
+    return true;
+}
+
+}  // namespace ambi

@@ -1,0 +1,197 @@
+// ambigram_cli.cpp -- drop-in for `Ambigram --op bfb` (localhap.cpp:19-388) on top of the C ABI of the HIP engine.
+//
+// Same flags (localhap.cpp:22-40), same stdout lines in the same order, same side files (<prefix>.lp, <prefix>.sol via
+// the external `cbc`, appended simulation_sv.txt and time.csv), same exit codes for unreadable .lh / missing .sol.
+// The per-chromosome stages run on the GPU through libambigram_hip.so; the ILP model is built on the host
+// (ambi_ilp_build) and solved by whatever `cbc` is on PATH, exactly as the reference shells out (localhap.cpp:179-181).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/ambigram_hip.h"
+
+namespace {
+
+struct Args { std::map<std::string, std::string> kv; bool help = false; };
+
+Args parse(int argc, char** argv) {
+    Args a;
+    for (int i = 1; i < argc; i++) {
+        std::string t = argv[i];
+        if (t == "--help") { a.help = true; continue; }
+        if (t.rfind("--", 0) != 0) continue;
+        std::string k = t.substr(2), v;
+        size_t eq = k.find('=');
+        if (eq != std::string::npos) { v = k.substr(eq + 1); k = k.substr(0, eq); }
+        else if (i + 1 < argc && std::string(argv[i + 1]).rfind("--", 0) != 0) v = argv[++i];
+        else v = "true";
+        a.kv[k] = v;
+    }
+    return a;
+}
+bool truthy(const std::string& s) { return s == "true" || s == "1" || s == "True"; }
+
+void print_log(const ambi_graph_t* g, size_t* printed) {
+    int64_t n = ambi_graph_log(g, nullptr, 0);
+    std::string buf((size_t)n + 1, '\0');
+    ambi_graph_log(g, &buf[0], n + 1);
+    buf.resize((size_t)n);
+    std::cout << buf.substr(*printed);
+    *printed = buf.size();
+}
+
+std::string path_text(const ambi_graph_t* g, const std::vector<int32_t>& p) {
+    int64_t n = ambi_format_path(g, p.data(), (int32_t)p.size(), nullptr, 0);
+    std::string s((size_t)n + 1, '\0');
+    ambi_format_path(g, p.data(), (int32_t)p.size(), &s[0], n + 1);
+    s.resize((size_t)n);
+    return s;
+}
+
+struct OutJ { int u, v; double cn; };
+void merge_steps(std::vector<OutJ>& acc, int u, int v, double c, bool increase) {
+    for (auto& j : acc)
+        if ((j.u == u && j.v == v) || (j.u == -v && j.v == -u)) { if (increase) j.cn += c; return; }
+    acc.push_back({u, v, c});
+}
+
+int die(const std::string& msg) { std::cerr << msg << std::endl; return 1; }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Args A = parse(argc, argv);
+    if (A.help) {
+        std::cout << "Local Haplotype constructer\nUsage:\n  Ambigram --op bfb --in_lh <file> --lp_prefix <name> [--juncdb <file> --junc_info true] "
+                     "[--reversed true] [--all true]\n";
+        return 0;
+    }
+    const std::string op = A.kv.count("op") ? A.kv["op"] : "";
+    std::cout << op << std::endl;   // localhap.cpp:47
+    if (op != "bfb") return die(op == "sc_bfb" ? "sc_bfb is not supported by the MI355X engine yet" : "unknown --op");
+    auto t_begin = std::chrono::steady_clock::now();
+    const std::string lh = A.kv["in_lh"], prefix = A.kv["lp_prefix"], juncs = A.kv.count("juncdb") ? A.kv["juncdb"] : "";
+    const bool junc_info = truthy(A.kv["junc_info"]), reversed = truthy(A.kv["reversed"]), all = truthy(A.kv["all"]);
+    if (all) return die("--all is not supported by the MI355X engine yet");
+
+    ambi_graph_t* g = nullptr;
+    int rc = ambi_graph_read_lh(lh.c_str(), &g);
+    if (rc == AMBI_ERR_OPEN) return die("Cannot open file " + lh);            // Graph.cpp:111-114
+    if (rc != 0) return die(std::string("input error: ") + ambi_error_string(rc));
+    size_t printed = 0;
+    print_log(g, &printed);
+    if (!juncs.empty()) { if ((rc = ambi_graph_read_juncs(g, juncs.c_str())) != 0) return die(ambi_error_string(rc)); print_log(g, &printed); }
+    int32_t n_seg, n_junc, n_chr, ins_mode, con_mode;
+    char main_chr[256];
+    ambi_graph_sizes(g, &n_seg, &n_junc, &n_chr);
+    ambi_graph_props(g, &ins_mode, &con_mode, main_chr, sizeof(main_chr));
+    std::vector<double> cn_all(n_seg);
+    std::vector<int32_t> seg_start(n_seg), seg_end(n_seg);
+    ambi_graph_segments(g, nullptr, nullptr, seg_start.data(), seg_end.data(), nullptr, cn_all.data());
+
+    std::vector<std::vector<int32_t>> paths(n_chr);
+    std::vector<OutJ> out_acc;
+    int num_inv = 0;
+    for (int c = 0; c < n_chr; c++) {
+        int32_t s, e;
+        ambi_graph_chromosome(g, c, &s, &e);
+        const int n = e - s + 1;
+        // localhap.cpp:136-170: junction CNs, bias, getIndelBias, shortcut -- a solution-less probe of this chromosome
+        ambi_batch_t* probe; ambi_batch_create(&probe);
+        if ((rc = ambi_batch_add_chromosome(probe, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
+        if ((rc = ambi_batch_upload(probe)) != 0 || (rc = ambi_batch_run(probe, 0, nullptr)) != 0 || (rc = ambi_batch_download(probe)) != 0)
+            return die(std::string("engine: ") + ambi_error_string(rc));
+        ambi_unit_result_t pr; ambi_batch_unit_result(probe, 0, &pr);
+        std::vector<double> junc_cn(2 * (n + 1)), seg_cn(n + 1);
+        std::vector<int32_t> inv(n + 1);
+        ambi_batch_unit_prepare(probe, 0, junc_cn.data(), seg_cn.data(), nullptr, inv.data());
+        for (int i = 1; i <= n; i++) { cn_all[s - 1 + i - 1] = seg_cn[i]; if (inv[i] >= 0) num_inv++; }
+        ambi_batch_t* b; ambi_batch_create(&b);
+        if (pr.status == AMBI_ST_SHORTCUT) {
+            ambi_batch_add_chromosome(b, g, c, 0, nullptr, nullptr, 0);
+        } else {
+            double max_cn = 0;
+            for (double v : cn_all) max_cn += v;
+            ambi_ilp_t* ilp = nullptr;
+            if ((rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp)) != 0) return die(ambi_error_string(rc));
+            std::cout << "Declare done" << std::endl << "ILP formula done" << std::endl << "Variable constrains done" << std::endl;
+            ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
+            ambi_ilp_destroy(ilp);
+            std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181
+            std::cout.flush();
+            (void)system(cmd.c_str());
+            rc = ambi_batch_add_chromosome_sol(b, g, c, ("./" + prefix + ".sol").c_str());
+            if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:187-190
+            if (rc < 0) return die(ambi_error_string(rc));
+        }
+        ambi_batch_destroy(probe);
+        if ((rc = ambi_batch_upload(b)) != 0 || (rc = ambi_batch_run(b, reversed ? AMBI_FLAG_REVERSED : 0, nullptr)) != 0 ||
+            (rc = ambi_batch_download(b)) != 0)
+            return die(std::string("engine: ") + ambi_error_string(rc));
+        ambi_unit_result_t r; ambi_batch_unit_result(b, 0, &r);
+        if (r.status < 0 || r.status == AMBI_ST_NO_VALID_ORDER) return die(std::string("bfb: ") + ambi_error_string(r.status));
+        std::vector<int32_t> p(r.path_len), q(r.path_indel_len);
+        ambi_batch_unit_path(b, 0, 0, p.data(), r.path_len);
+        ambi_batch_unit_path(b, 0, 1, q.data(), r.path_indel_len);
+        std::cout << path_text(g, p) << std::endl;                                   // printBFB (LGM.cpp:3411-3429)
+        if (r.status == AMBI_ST_INFEASIBLE) std::cout << "ILP is unsolvable.\n";    // localhap.cpp:217
+        else if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(g, q) << std::endl;
+        paths[c] = q;
+        std::vector<int32_t> ju(r.n_out_junc), jv(r.n_out_junc), jc(r.n_out_junc);
+        ambi_batch_unit_out_juncs(b, 0, ju.data(), jv.data(), jc.data(), r.n_out_junc);
+        for (int k = 0; k < r.n_out_junc; k++) merge_steps(out_acc, ju[k], jv[k], jc[k], true);   // localhap.cpp:267-289
+        ambi_batch_destroy(b);
+    }
+    int path_len = 0, cn_sum = 0, max_cn_i = 0;
+    for (auto& p : paths) path_len += (int)p.size();
+    for (double v : cn_all) { cn_sum += v; max_cn_i = (max_cn_i > v) ? max_cn_i : v; }   // localhap.cpp:290-293 (int fed with doubles)
+    if (ins_mode == 2 || con_mode == 2) {   // localhap.cpp:295-316
+        if (!main_chr[0]) return die("BFB-TRX needs PROP M:<chr>");
+        std::cout << "BFB with translocation:\n";
+        std::vector<int64_t> offs(n_chr + 1, 0);
+        for (int c = 0; c < n_chr; c++) offs[c + 1] = offs[c] + (int64_t)paths[c].size();
+        std::vector<int32_t> flat((size_t)offs[n_chr] + 1), out((size_t)offs[n_chr] * 2 + 16);
+        for (int c = 0; c < n_chr; c++) std::copy(paths[c].begin(), paths[c].end(), flat.begin() + offs[c]);
+        int len = ambi_translocation_bfb(g, flat.data(), offs.data(), n_chr, out.data(), (int32_t)out.size());
+        if (len < 0) return die(ambi_error_string(len));
+        out.resize(len);
+        std::cout << path_text(g, out) << std::endl;
+        for (int i = 0; i + 1 < len; i++) {
+            int u = out[i], v = out[i + 1];
+            if (!(std::abs(std::abs(u) - std::abs(v)) == 1 && (u > 0) == (v > 0))) merge_steps(out_acc, u, v, 1, false);
+        }
+    }
+    // side files (localhap.cpp:326-337, 382-388)
+    {
+        std::vector<int32_t> js(n_junc), jt(n_junc); std::vector<int8_t> jsd(n_junc), jtd(n_junc); std::vector<double> jcn(n_junc);
+        ambi_graph_sizes(g, &n_seg, &n_junc, &n_chr);
+        js.resize(n_junc); jt.resize(n_junc); jsd.resize(n_junc); jtd.resize(n_junc); jcn.resize(n_junc);
+        ambi_graph_junctions(g, js.data(), jsd.data(), jt.data(), jtd.data(), nullptr, jcn.data(), nullptr, nullptr);
+        auto chrom = [&](int id) { char b[256]; ambi_graph_chrom_name(g, id, b, sizeof(b)); return std::string(b); };
+        auto vend = [&](int id, int dir) { return dir > 0 ? seg_end[id - 1] : seg_start[id - 1]; };      // Vertex::getEnd
+        auto vstart = [&](int id, int dir) { return dir > 0 ? seg_start[id - 1] : seg_end[id - 1]; };    // Vertex::getStart
+        std::ofstream sv("simulation_sv.txt", std::ios_base::app);
+        for (int j = 0; j < n_junc; j++)
+            sv << lh << "\t" << juncs << "\t" << chrom(js[j]) << "\t" << vend(js[j], jsd[j]) << "\t" << (jsd[j] > 0 ? '+' : '-') << "\t"
+               << chrom(jt[j]) << "\t" << vstart(jt[j], jtd[j]) << "\t" << (jtd[j] > 0 ? '+' : '-') << "\t" << jcn[j] << "\tinput\n";
+        for (auto& j : out_acc) {
+            int a = std::abs(j.u), b = std::abs(j.v), ad = j.u > 0 ? 1 : -1, bd = j.v > 0 ? 1 : -1;
+            sv << lh << "\t" << juncs << "\t" << chrom(a) << "\t" << vend(a, ad) << "\t" << (ad > 0 ? '+' : '-') << "\t"
+               << chrom(b) << "\t" << vstart(b, bd) << "\t" << (bd > 0 ? '+' : '-') << "\t" << j.cn << "\toutput\n";
+        }
+        auto t_end = std::chrono::steady_clock::now();
+        std::ofstream tf("time.csv", std::ios_base::app);
+        tf << lh.substr(0, lh.find(".")) << "," << n_seg << "," << num_inv << "," << n_junc - num_inv << "," << cn_sum << "," << path_len << ","
+           << max_cn_i << "," << std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_begin).count() / 1000000.0 << "\n";
+    }
+    ambi_graph_destroy(g);
+    return 0;
+}

@@ -85,25 +85,15 @@ def main():
     bad = [r for r in res if r["status"] != 0]
     if bad:
         raise SystemExit("bench: %d units did not reconstruct: %r" % (len(bad), bad[0]))
+    from ambigram_amd.dist import PathExchange
     total_cells = sum(r["path_indel_len"] for r in res)
-    cell_cap = total_cells
-    if world > 1:
-        t = torch.tensor([cell_cap], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cell_cap = int(t.item())
-    lengths = torch.zeros(B, dtype=torch.int32, device="cuda")
-    cells = torch.zeros(max(cell_cap, 1), dtype=torch.int32, device="cuda")
-    tot = torch.zeros(1, dtype=torch.int64, device="cuda")
-    if world > 1:
-        lengths_all = torch.zeros(B * world, dtype=torch.int32, device="cuda")
-        gather_list = [torch.zeros_like(cells) for _ in range(world)] if rank == 0 else None
+    px = PathExchange(B, total_cells, "cuda", world=world, rank=rank)
+    lengths, cells, tot, cell_cap = px.lengths, px.cells, px.total, px.cell_cap
 
     def step():
         batch.run(0, stream)
         batch.pack_paths(1, lengths.data_ptr(), cells.data_ptr(), cell_cap, tot.data_ptr(), stream)
-        if world > 1:   # the single end-of-batch exchange: path lengths, then the concatenated int32 paths
-            dist.all_gather_into_tensor(lengths_all, lengths)
-            dist.gather(cells, gather_list, dst=0)
+        px.exchange()   # N > 1: the single end-of-batch exchange (path lengths, then the concatenated int32 paths)
 
     def barrier():
         if world > 1:

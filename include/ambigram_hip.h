@@ -73,6 +73,8 @@ int ambi_graph_segments(const ambi_graph_t* g, int32_t* id, int32_t* chr_id, int
 int ambi_graph_junctions(const ambi_graph_t* g, int32_t* src, int8_t* sdir, int32_t* tgt, int8_t* tdir, double* cov,
                          double* cn, uint8_t* inferred, uint8_t* bounded);
 int ambi_graph_chromosome(const ambi_graph_t* g, int32_t chr, int32_t* source_id, int32_t* sink_id);
+/* chromosome name of segment `seg_id` (the SEG line's H:id:<chrom>:start:end); returns the length needed */
+int64_t ambi_graph_chrom_name(const ambi_graph_t* g, int32_t seg_id, char* buf, int64_t cap);
 /* replaces LocalGenomicMap::readComponents (LocalGenomicMap.cpp:5096-5156, localhap.cpp:102); may add junctions */
 int ambi_graph_read_juncs(ambi_graph_t* g, const char* juncs_path);
 /* stdout lines the reference prints while loading (progress, SEG echoes, .juncs breakpoints), '\n' separated.
@@ -170,6 +172,24 @@ int ambi_batch_traffic(const ambi_batch_t* b, int64_t* input_bytes, int64_t* ord
 int64_t ambi_format_path(const ambi_graph_t* g, const int32_t* path, int32_t len, char* buf, int64_t cap);
 /* paths: concatenated per-chromosome paths with offsets[n_chr+1]; result written to out (cap cells). Returns length. */
 int ambi_translocation_bfb(const ambi_graph_t* g, int32_t* paths, const int64_t* offsets, int32_t n_chr, int32_t* out, int32_t cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * ILP model of one chromosome (host side; the solve stays with the external `cbc`, localhap.cpp:179-181).
+ * Replaces LocalGenomicMap::BFB_ILP (LocalGenomicMap.cpp:4397-4752): same rows, same row order, same in-row entry
+ * order, generated in O(nnz) instead of the reference's O(n * numPat^2) assembly loop (:4464-4477).
+ * seg_cn / junc_cn: the arrays ambi_batch_unit_prepare returns for the chromosome (local ids, slot 0 unused);
+ * max_cn_total: sum of the CN of ALL segments of the graph at that point (:4708-4711).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ambi_ilp ambi_ilp_t;
+int ambi_ilp_build(const ambi_graph_t* g, int32_t chr, const double* seg_cn, const double* junc_cn, int32_t bias,
+                   double max_cn_total, int32_t juncs_info, ambi_ilp_t** out);
+void ambi_ilp_destroy(ambi_ilp_t* p);
+int ambi_ilp_sizes(const ambi_ilp_t* p, int64_t* n_rows, int64_t* nnz, int32_t* n_cols, int32_t* n_int);
+/* CSR copy-out; infinity is +-DBL_MAX (OsiClp getInfinity()); any pointer may be NULL */
+int ambi_ilp_copy(const ambi_ilp_t* p, int64_t* row_ptr, int32_t* col, double* val, double* row_lo, double* row_up,
+                  double* col_lo, double* col_up, double* obj);
+/* writes <path> as CPLEX-LP text with CoinUtils column names x<j> (what `cbc <prefix>.lp solve solu <prefix>.sol` reads) */
+int ambi_ilp_write_lp(const ambi_ilp_t* p, const char* path);
 
 #ifdef __cplusplus
 }

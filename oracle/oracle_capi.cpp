@@ -102,6 +102,45 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
     return dup(o.str());
 }
 
+// ILP model of chromosome `chr` exactly as main() would hand it to BFB_ILP (localhap.cpp:111-173): graph loaded,
+// partitions set, .juncs read, getJuncCN / bias / getIndelBias applied for chromosomes 0..chr.  literal != 0 runs the
+// reference's O(numPat^2) coefficient loop (LGM.cpp:4464-4477) instead of its closed form.  JSON: CSR + bounds.
+char* oracle_ilp_json(const char* lh, const char* juncs, int chr, int junc_info, int literal, double* seconds) {
+    Graph g; std::string err;
+    std::ostringstream o;
+    o.precision(17);
+    bool ok = readGraph(lh, g, err) && calculateHapDepth(g, err);
+    if (!ok || chr < 0 || chr >= (int)g.sinkIds.size()) { o << "{\"ok\":false}"; return dup(o.str()); }
+    calculateCopyNum(g);
+    for (size_t i = 0; i < g.sourceIds.size(); i++)
+        for (int j = g.sourceIds[i]; j <= g.sinkIds[i]; j++) g.segs[j - 1].partition = (int)i;
+    std::vector<std::vector<int>> components;
+    std::vector<std::string> log;
+    readComponents(g, juncs ? juncs : "", components, log);
+    std::vector<double> juncCN; int bias = 1;
+    for (int c = 0; c <= chr; c++) {
+        Inversions inv;
+        getJuncCN(g, g.sourceIds[c], g.sinkIds[c], inv, juncCN);
+        bias = computeBias(g, g.sourceIds[c], g.sinkIds[c], inv, juncCN);
+        getIndelBias(g, g.sourceIds[c], g.sinkIds[c]);
+    }
+    std::vector<std::vector<int>> valid;
+    for (auto& comp : components) if (g.segById(comp[0])->partition == chr) valid.push_back(comp);
+    IlpModel m;
+    auto t0 = std::chrono::steady_clock::now();
+    buildBfbIlp(g, g.sourceIds[chr], g.sinkIds[chr], juncCN, valid, junc_info != 0, bias, m, literal != 0);
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    o << "{\"ok\":true,\"n_cols\":" << m.numCols << ",\"n_int\":" << m.numInt << ",\"bias\":" << bias << ",\"row_ptr\":";
+    { std::vector<long long> rp(m.rowPtr.begin(), m.rowPtr.end()); jarr(o, rp); }
+    o << ",\"col\":"; jarr(o, m.colIdx);
+    o << ",\"val\":"; jdarr(o, m.val);
+    o << ",\"row_lo\":"; jdarr(o, m.rowLo); o << ",\"row_up\":"; jdarr(o, m.rowUp);
+    o << ",\"col_lo\":"; jdarr(o, m.colLo); o << ",\"col_up\":"; jdarr(o, m.colUp);
+    o << ",\"obj\":"; jdarr(o, m.obj);
+    o << "}";
+    return dup(o.str());
+}
+
 // Parsed-graph dump (after calculateHapDepth/calculateCopyNum), same JSON shape as oracle/_ref's ref_graph_dump.
 char* oracle_graph_dump(const char* lh) {
     Graph g; std::string err;

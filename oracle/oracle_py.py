@@ -62,6 +62,19 @@ def graph_dump(lh):
     return _take(lib().oracle_graph_dump(lh.encode()))
 
 
+def ilp(lh, chr_=0, juncs="", junc_info=False, literal=False):
+    """ILP model of one chromosome (BFB_ILP, LGM.cpp:4397-4752) as CSR + bounds; `literal` runs the reference's
+    O(numPat^2) coefficient loop instead of its closed form."""
+    L = lib()
+    L.oracle_ilp_json.restype = ctypes.c_void_p
+    L.oracle_ilp_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_double)]
+    sec = ctypes.c_double(0)
+    out = _take(L.oracle_ilp_json(lh.encode(), juncs.encode(), chr_, 1 if junc_info else 0, 1 if literal else 0, ctypes.byref(sec)))
+    out["seconds"] = sec.value
+    return out
+
+
 def ref_graph_dump(lh):
     """Parsed graph from the REAL reference graph model (oracle/_ref, container-only). None if unavailable."""
     exe = os.path.join(_HERE, "_ref", "ref_graph_dump")

@@ -1,0 +1,98 @@
+"""The drop-in CLI (ambigram_amd/csrc/ambigram_cli.cpp) keeps the reference's contract: flags, stdout
+lines, side files, exit codes.  CPU run: the CLI source linked against the host simulation; the external `cbc`
+(localhap.cpp:179-181) is a script on PATH that hands back the planted solution, the way a real solver would write
+`<prefix>.sol`.  The GPU variant of this test lives in test_gpu_parity.py::test_cli_on_gpu."""
+import os
+import stat
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tests", "data")
+
+
+def fake_cbc(bindir, sols):
+    """`cbc <p>.lp solve solu <p>.sol`: copies the next planted solution to $4 (one per call)."""
+    os.makedirs(bindir, exist_ok=True)
+    counter = os.path.join(bindir, "calls")
+    with open(counter, "w") as f:
+        f.write("0")
+    exe = os.path.join(bindir, "cbc")
+    lines = ["#!/bin/sh", "n=$(cat %s)" % counter, "echo $((n+1)) > %s" % counter, "test -s \"$1\" || exit 3", "case $n in"]
+    for i, s in enumerate(sols):
+        lines.append("  %d) cp %s \"$4\" ;;" % (i, s))
+    lines += ["esac", "echo \"fake cbc: call $n\"", ""]
+    with open(exe, "w") as f:
+        f.write("\n".join(lines))
+    os.chmod(exe, os.stat(exe).st_mode | stat.S_IEXEC)
+    return exe
+
+
+def run_cli(exe, cwd, bindir, *args):
+    env = dict(os.environ, PATH=bindir + os.pathsep + os.environ.get("PATH", ""))
+    return subprocess.run([exe] + list(args), cwd=cwd, env=env, capture_output=True, text=True, timeout=300)
+
+
+@pytest.fixture(scope="module")
+def cli(hostsim_lib):
+    exe = os.path.join(ROOT, "tests", "hostsim", "Ambigram_hostsim")
+    assert os.path.exists(exe)
+    return exe
+
+
+def check_readme(exe, cwd, oracle):
+    bindir = os.path.join(cwd, "bin")
+    fake_cbc(bindir, [os.path.join(DATA, "readme6.sol")])
+    lh = os.path.join(DATA, "readme6.lh")
+    r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "readme")
+    assert r.returncode == 0, r.stderr
+    want = oracle.run_bfb(lh, [os.path.join(DATA, "readme6.sol")])["log"]
+    got = [l for l in r.stdout.splitlines() if not l.startswith("fake cbc")]
+    assert got == want
+    assert got[-1] == "1+2+3+4+5+6+|6-5-4-3-2-|2+3+4+|4-3-|3+4+|4-3-2-|2+3+4+5+6+|6-5-4-3-2-1-"   # README.md:122
+    assert os.path.exists(os.path.join(cwd, "readme.lp")) and os.path.exists(os.path.join(cwd, "readme.sol"))
+    # time.csv: name,nSeg,nInv,nOtherJunc,cnSum,pathLen,maxCN,seconds  (readme6,6,4,0,32,32,8,<sec>)
+    row = open(os.path.join(cwd, "time.csv")).read().strip().split(",")
+    assert row[1:7] == ["6", "4", "0", "32", "32", "8"]
+    sv = open(os.path.join(cwd, "simulation_sv.txt")).read().strip().splitlines()
+    assert sum(l.endswith("input") for l in sv) == 4 and sum(l.endswith("output") for l in sv) >= 1
+    # reversed
+    fake_cbc(bindir, [os.path.join(DATA, "readme6.sol")])
+    r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "readme", "--reversed", "true")
+    assert r.stdout.splitlines()[-1] == "6-5-4-3-2-1-|1+2+3+4+5+6+|6-5-4-3-2-|2+3+4+|4-3-|3+4+|4-3-2-|2+3+4+5+6+"
+
+
+def check_trx(exe, cwd, oracle):
+    bindir = os.path.join(cwd, "bin")
+    sols = [os.path.join(DATA, "trx_c2_chr0.sol"), os.path.join(DATA, "trx_c2_chr1.sol")]
+    fake_cbc(bindir, sols)
+    lh = os.path.join(DATA, "trx_c2.lh")
+    r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "trx")
+    assert r.returncode == 0, r.stderr
+    got = [l for l in r.stdout.splitlines() if not l.startswith("fake cbc")]
+    assert got == oracle.run_bfb(lh, sols)["log"]
+    assert got[-2:] == ["BFB with translocation:", "1+2+3+4+|4-3-2-|2+3+||6+7+|7-6-|6+7+|7-6-"]
+
+
+def check_errors(exe, cwd):
+    bindir = os.path.join(cwd, "nobin")
+    os.makedirs(bindir, exist_ok=True)
+    r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", os.path.join(cwd, "missing.lh"), "--lp_prefix", "x")
+    assert r.returncode == 1 and "Cannot open file" in r.stderr          # Graph.cpp:111-114
+    env_path = os.environ.get("PATH", "")
+    if not any(os.path.exists(os.path.join(p, "cbc")) for p in env_path.split(os.pathsep) if p):
+        r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", os.path.join(DATA, "readme6.lh"), "--lp_prefix", "nosol")
+        assert r.returncode == 1 and "ILP error: cannot open file" in r.stderr   # localhap.cpp:187-190
+
+
+def test_cli_readme(cli, oracle, tmp_path):
+    check_readme(cli, str(tmp_path), oracle)
+
+
+def test_cli_two_chromosome_trx(cli, oracle, tmp_path):
+    check_trx(cli, str(tmp_path), oracle)
+
+
+def test_cli_errors(cli, tmp_path):
+    check_errors(cli, str(tmp_path))

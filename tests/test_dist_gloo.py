@@ -1,0 +1,67 @@
+"""Multi-process path (world_size 2, gloo, CPU): sample sharding + the single end-of-batch gather of
+ambigram_amd/dist.py, with the engine's stage code running on the host simulation.  The GPU run uses the same
+PathExchange over RCCL (bench.py)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %(root)r)
+    import torch
+    import torch.distributed as dist
+    from ambigram_amd import api, synth
+    from ambigram_amd.dist import PathExchange, shard
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    lib = api.load(%(lib)r)
+    tmp = %(tmp)r
+    N = 10                                    # samples of the whole job
+    mine = shard(N, rank, world)
+    batch, graphs = api.Batch(lib), []
+    for i in mine:
+        s = synth.make_sample(40, 80, ("chain", "wide", "mixed")[i %% 3], 7, seed=3000 + i, n_del=i %% 2)
+        lh, sols = s.write(tmp, "d%%d" %% i)
+        g = api.Graph(lib, lh); graphs.append(g)
+        batch.add_chromosome_sol(g, 0, sols[0])
+    batch.upload(); batch.run(0); batch.download()
+    n_units = batch.size()
+    assert n_units == N // world
+    cells_needed = sum(batch.unit_result(u)["path_indel_len"] for u in range(n_units))
+    px = PathExchange(n_units, cells_needed, "cpu", world=world, rank=rank)
+    batch.pack_paths(1, px.lengths.data_ptr(), px.cells.data_ptr(), px.cell_cap, px.total.data_ptr())
+    px.exchange()
+    got = px.collect()
+    if rank == 0:
+        json.dump(got, open(os.path.join(tmp, "gathered.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_gather_matches_oracle(oracle, hostsim_lib, workdir):
+    tmp = os.path.join(workdir, "dist")
+    os.makedirs(tmp, exist_ok=True)
+    lib_path = os.path.join(ROOT, "tests", "hostsim", "libambigram_hostsim.so")
+    script = os.path.join(tmp, "worker.py")
+    with open(script, "w") as f:
+        f.write(WORKER % dict(root=ROOT, lib=lib_path, tmp=tmp))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    import json
+    from ambigram_amd import synth
+    from ambigram_amd.dist import shard
+    got = json.load(open(os.path.join(tmp, "gathered.json")))
+    assert len(got) == 2
+    for r in range(2):
+        for k, i in enumerate(shard(10, r, 2)):
+            s = synth.make_sample(40, 80, ("chain", "wide", "mixed")[i % 3], 7, seed=3000 + i, n_del=i % 2)
+            lh, sols = s.write(tmp, "o%d" % i)
+            want = oracle.run_bfb(lh, sols)["chr"][0]["path_indel"]
+            assert got[r][k] == want, (r, i)

@@ -133,3 +133,17 @@ def test_pack_paths_matches_download(hip_lib, oracle, workdir):
     flat = [v for e in expect for v in e["path_indel"]]
     assert int(total.item()) == len(flat)
     assert cells.cpu().tolist()[:len(flat)] == flat
+
+
+def test_cli_on_gpu(hip_lib, oracle, tmp_path):
+    """The drop-in CLI binary (ambigram_amd/bin/Ambigram, linked against libambigram_hip.so) on the GPU."""
+    import os
+    import test_cli_dropin as t
+    exe = os.path.join(t.ROOT, "ambigram_amd", "bin", "Ambigram")
+    assert os.path.exists(exe), "build the CLI first (__graft_entry__.build)"
+    d1, d2, d3 = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for d in (d1, d2, d3):
+        d.mkdir()
+    t.check_readme(exe, str(d1), oracle)
+    t.check_trx(exe, str(d2), oracle)
+    t.check_errors(exe, str(d3))

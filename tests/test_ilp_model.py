@@ -1,0 +1,85 @@
+"""ILP model (BFB_ILP, LGM.cpp:4397-4752): the engine's O(nnz) host generator == the oracle's restatement, and the
+oracle's closed form == the reference's literal O(numPat^2) coefficient loop.  Host-only (no GPU needed): the .lh is
+parsed by the engine's reader, the junction CNs / bias come from the oracle here so the test runs on the CPU."""
+import os
+
+import numpy as np
+import pytest
+
+from ambigram_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tests", "data")
+
+
+def _model_from_engine(lib, lh, chr_, juncs, junc_info, run_lib):
+    g = api.Graph(lib, lh)
+    if juncs:
+        g.read_juncs(juncs)
+    # prepare outputs (junction CN, CN after getIndelBias, bias) come from a solution-less probe batch
+    b = api.Batch(run_lib)
+    g2 = api.Graph(run_lib, lh)
+    if juncs:
+        g2.read_juncs(juncs)
+    for c in range(g2.n_chr):
+        b.add_chromosome(g2, c, [], [])
+    b.upload(); b.run(0); b.download()
+    seg = g.segments()
+    cn_all = seg["cn"].copy()
+    for c in range(chr_ + 1):                      # getIndelBias of chromosomes 0..chr has run by then (localhap.cpp:147)
+        s, e = g.chromosome(c)
+        prep = b.unit_prepare(c, e - s + 1)
+        cn_all[s - 1:e] = prep["seg_cn"][1:]
+    s, e = g.chromosome(chr_)
+    prep = b.unit_prepare(chr_, e - s + 1)
+    bias = b.unit_result(chr_)["bias"]
+    m = api.IlpModel(lib, g, chr_, prep["seg_cn"], prep["junc_cn"], bias, float(cn_all.sum()), juncs_info=junc_info)
+    return m
+
+
+def _same(m, o):
+    a = m.arrays()
+    assert o["ok"] and m.n_cols == o["n_cols"] and m.n_int == o["n_int"]
+    assert a["row_ptr"].tolist() == o["row_ptr"]
+    assert a["col"].tolist() == o["col"]
+    assert np.array_equal(a["val"], np.array(o["val"]))
+    for k in ["row_lo", "row_up", "col_lo", "col_up", "obj"]:
+        assert np.array_equal(a[k], np.array(o[k])), k
+
+
+def test_readme_ilp_size_and_equality(hostsim_lib, oracle):
+    lh = os.path.join(DATA, "readme6.lh")
+    m = _model_from_engine(hostsim_lib, lh, 0, "", False, hostsim_lib)
+    # n=6 -> 55 columns, 140 rows, 1068 nonzeros
+    assert (m.n_cols, m.n_rows, m.nnz) == (55, 140, 1068)
+    _same(m, oracle.ilp(lh, 0))
+    _same(m, oracle.ilp(lh, 0, literal=True))
+
+
+@pytest.mark.parametrize("n,seed", [(9, 1), (17, 2), (33, 3)])
+def test_synthetic_ilp_equality(hostsim_lib, oracle, workdir, n, seed):
+    s = synth.make_sample(n, 2 * n + 4, "chain", 4, seed, imperfect=1, n_del=1, n_dup=1)
+    lh, _ = s.write(workdir, "ilp%d" % n)
+    m = _model_from_engine(hostsim_lib, lh, 0, "", False, hostsim_lib)
+    _same(m, oracle.ilp(lh, 0, literal=(n <= 17)))
+
+
+def test_multichr_and_juncs_row(hostsim_lib, oracle, workdir):
+    lh = os.path.join(DATA, "trx_c2.lh")
+    for c in (0, 1):
+        _same(_model_from_engine(hostsim_lib, lh, c, "", False, hostsim_lib), oracle.ilp(lh, c))
+    j = os.path.join(workdir, "r6.juncs")
+    with open(j, "w") as f:
+        f.write("6+ 6- 5- 4- 3- 2- 2+\n2- 2+ 3+ 4+ 5+ 6+ 6-\n6+ 6- 5- 4- 3-\n")
+    lh6 = os.path.join(DATA, "readme6.lh")
+    _same(_model_from_engine(hostsim_lib, lh6, 0, j, True, hostsim_lib), oracle.ilp(lh6, 0, juncs=j, junc_info=True))
+
+
+def test_lp_text_is_written(hostsim_lib, workdir):
+    lh = os.path.join(DATA, "readme6.lh")
+    m = _model_from_engine(hostsim_lib, lh, 0, "", False, hostsim_lib)
+    p = os.path.join(workdir, "readme6.lp")
+    m.write_lp(p)
+    text = open(p).read()
+    assert "Minimize" in text and "Subject To" in text and "Integers" in text and text.rstrip().endswith("End")
+    assert text.count("\nR") >= 140
