@@ -89,6 +89,10 @@ struct BatchArgs {
     int32_t target_lanes;        // enumerate kernel: lanes to spread the rows of the batch over (sets rows per lane)
     int32_t enum_stack_lds;      // enumerate kernel: LDS bytes per wave for the per-lane DFS stacks
     int32_t enum_auto_lds;       // enumerate kernel: LDS bytes per wave for the compact automaton copy
+    int32_t block_lds;           // block-emission kernel: LDS bytes per workgroup for automaton + suffix tables
+    int32_t* unit_fallback;      // [U] set by ambi_blocks_build_kernel when a unit's tables do not fit block_lds
+    uint8_t* block_img;          // [U][block_lds] block-emission table images (built once per unit, copied to LDS by users)
+    int32_t* block_hdr;          // [U][8]  BlockImageHeader
     const UnitIn* units;
     const double* seg_cn;
     const Junction* juncs;

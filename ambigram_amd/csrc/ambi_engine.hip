@@ -92,7 +92,7 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
                 else {
                     live = true;
                     bytes = order_bytes(R, K);
-                    blocks = (R + 64ll * T - 1) / (64ll * T);
+                    blocks = (R + 256ll * T - 1) / (256ll * T);   // one work block = one workgroup = 4 waves x 64*T rows
                 }
             }
         }
@@ -134,15 +134,18 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
     const int64_t total = A.blk_off[A.n_units];
     int staged_unit = -1;
     bool in_lds = false;
-    for (int64_t b = (int64_t)blockIdx.x * wpb + wave; b < total; b += (int64_t)gridDim.x * wpb) {
+    (void)wpb;
+    // general path: only units whose block tables did not fit (flagged by ambi_enumerate_blocks_kernel)
+    for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
         const int u = lo;
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
         if (enum_class_of(K) != CLS) continue;   // rows of this width belong to another instantiation
+        if (!A.unit_fallback[u]) continue;
         const int64_t R = out->num_orders;
-        const int64_t base_rank = (b - A.blk_off[u]) * 64ll * T;
+        const int64_t base_rank = (b - A.blk_off[u]) * 256ll * T + (int64_t)wave * 64 * T;
         const IdealTable tbl = unit_ideal_table(A, u);
         const AutoView V = auto_view(tbl);
         const int nI = V.nI, nC = tbl.counter[1];
@@ -179,6 +182,85 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
             GlobalAuto ga{V};
             enumerate_lane_dispatch<CLS>(ga, ga, V, K, R, first, T, stacks, lane, 64, rows);
         }
+    }
+}
+
+// Builds the block-emission tables of every unit once (LDS), and parks the position-independent image in HBM.
+__global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    const int u = blockIdx.x;
+    const UnitOut* out = unit_out(A.results, u);
+    if (out->status != ST_OK || out->order_off < 0) return;
+    const IdealTable tbl = unit_ideal_table(A, u);
+    const int K = out->K;
+    BlockTables B;
+    const bool fits = stage_block_tables(g, tbl, K, row_stride(K) / 4, ambi_lds, A.block_lds, B);
+    BlockImageHeader* hdr = reinterpret_cast<BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
+    const int64_t image = fits ? (reinterpret_cast<uint8_t*>(B.suf) - ambi_lds) + 4ll * B.suf_words : 0;
+    if (threadIdx.x == 0) {
+        hdr->fits = fits ? 1 : 0; hdr->nI = tbl.counter[0]; hdr->nC = tbl.counter[1];
+        hdr->suf_words = fits ? B.suf_words : 0; hdr->image_bytes = (int32_t)image;
+        A.unit_fallback[u] = fits ? 0 : 1;
+    }
+    if (!fits) return;
+    const int64_t nvec = (image + 15) >> 4;
+    uint4* dst = reinterpret_cast<uint4*>(A.block_img + (int64_t)u * A.block_lds);
+    const uint4* src = reinterpret_cast<const uint4*>(ambi_lds);
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+}
+
+// Fast path: block emission (ambi_enum_blocks.hpp).  One workgroup per work block of 256*T rows; the workgroup stages
+// the unit's automaton + suffix-block tables in LDS once, then every wave walks its 64*T rows block by block with a
+// wave-uniform DFS and writes them with fully coalesced 16-byte stores.
+// LDS: [block_lds] tables | per wave: idx[64] u16, prev[64] u8, pw[16] u32.
+template <int CLS>
+__global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t* tmem = ambi_lds;
+    uint8_t* wmem = ambi_lds + A.block_lds + (size_t)wave * 256;
+    uint16_t* idx = reinterpret_cast<uint16_t*>(wmem);
+    uint8_t* prev = wmem + 128;
+    uint32_t* pw = reinterpret_cast<uint32_t*>(wmem + 192);
+    const int64_t total = A.blk_off[A.n_units];
+    int staged_unit = -1;
+    bool fits = false;
+    BlockTables B;
+    WaveGroup wg;
+    auto wsync = [&]() { wg.sync(); };
+    for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
+        int lo = 0, hi = A.n_units;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
+        const int u = lo;
+        const UnitOut* out = unit_out(A.results, u);
+        const int K = out->K, T = A.rows_per_lane[u];
+        if (enum_class_of(K) != CLS) continue;
+        const IdealTable tbl = unit_ideal_table(A, u);
+        if (u != staged_unit) {
+            g.sync();
+            const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
+            fits = hdr->fits != 0;
+            if (fits) {   // coalesced copy of the unit's table image into LDS
+                const int64_t nvec = ((int64_t)hdr->image_bytes + 15) >> 4;
+                const uint4* src = reinterpret_cast<const uint4*>(A.block_img + (int64_t)u * A.block_lds);
+                uint4* dst = reinterpret_cast<uint4*>(tmem);
+                for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+                (void)carve_block_tables(tmem, hdr->nI, hdr->nC, B);
+                B.suf_words = hdr->suf_words;
+            }
+            staged_unit = u;
+            g.sync();
+        }
+        if (!fits) continue;
+        const int64_t R = out->num_orders;
+        const int64_t wlo = (b - A.blk_off[u]) * 256ll * T + (int64_t)wave * 64 * T;
+        int64_t whi = wlo + 64ll * T;
+        if (whi > R) whi = R;
+        if (wlo < R)
+            emit_blocks_dispatch<CLS>(B, auto_view(tbl), K, (uint64_t)wlo, (uint64_t)whi, A.order_arena + out->order_off, idx, prev, pw,
+                                      lane, lane + 1, wsync);
     }
 }
 
@@ -297,7 +379,8 @@ class HipBackend : public Backend {
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; int32_t* d_ilvl_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
     int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
-    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096, enum_classes_ = 0;
+    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096, enum_classes_ = 0, block_lds_ = 49152, lds_blocks_ = 0;
+    int32_t* d_fallback_ = nullptr; uint8_t* d_blk_img_ = nullptr; int32_t* d_blk_hdr_ = nullptr;
     uint8_t* d_arena_ = nullptr; int64_t arena_bytes_ = 0;
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
@@ -312,7 +395,7 @@ class HipBackend : public Backend {
 
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilvl_, d_ilvl_off_,
-                        d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_,
+                        d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_npending_) (void)hipHostFree(h_npending_);
@@ -367,6 +450,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_scratch_, (size_t)hb.scratch_ints + 8))) return rc;
         if ((rc = dalloc(&d_scratch_off_, U))) return rc;
         if ((rc = dalloc(&d_pack_off_, U + 1))) return rc;
+        if ((rc = dalloc(&d_fallback_, U))) return rc;
         HIP_CK(hipHostMalloc((void**)&h_npending_, sizeof(int32_t)));
         HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t)));
         arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
@@ -383,8 +467,13 @@ class HipBackend : public Backend {
         lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
         enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
+        { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
+        lds_blocks_ = block_lds_ + 4 * 256;
+        if ((rc = dalloc(&d_blk_img_, U * (size_t)block_lds_))) return rc;
+        if ((rc = dalloc(&d_blk_hdr_, U * 8))) return rc;
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds_));
         const int kLdsLimit = 160 * 1024 - 1024;
-        if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit) {
+        if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
                     lds_prepare_, lds_first_, lds_finish_);
             return ST_ERR_BAD_INPUT;
@@ -396,6 +485,9 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
         enum_classes_ = 0;
         for (const UnitIn& un : hb.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
         uploaded_ = true; arena_checked_ = false;
@@ -406,6 +498,7 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size();
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
+        A_.block_lds = block_lds_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
@@ -417,7 +510,7 @@ class HipBackend : public Backend {
 
     // Per-kernel HIP events on the run's stream.  A ring of kTimingSlots event sets lets a timed region of many runs be
     // averaged without a host sync per run: run r records into slot r % kTimingSlots.
-    static constexpr int kTimingSlots = 64, kTimedKernels = 5;
+    static constexpr int kTimingSlots = 64, kTimedKernels = 6;
     void tick(const char* name, size_t idx, bool begin) {
         if (!timing_) return;
         const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
@@ -465,17 +558,24 @@ class HipBackend : public Backend {
             arena_checked_ = true;
         }
         const int U = A_.n_units;
-        tick("ambi_enumerate_kernel", 2, true);
+        (void)hipMemsetAsync(d_fallback_, 0, sizeof(int32_t) * (size_t)U, stream_);
+        tick("ambi_blocks_build_kernel", 2, true);
+        hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(U), dim3(256), block_lds_, stream_, A_);
+        tick("ambi_blocks_build_kernel", 2, false);
+        tick("ambi_enumerate_kernel", 3, true);
+        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
+        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
+        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
         if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
         if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
         if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
-        tick("ambi_enumerate_kernel", 2, false);
-        tick("ambi_first_kernel", 3, true);
+        tick("ambi_enumerate_kernel", 3, false);
+        tick("ambi_first_kernel", 4, true);
         hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, stream_, A_);
-        tick("ambi_first_kernel", 3, false);
-        tick("ambi_finish_kernel", 4, true);
+        tick("ambi_first_kernel", 4, false);
+        tick("ambi_finish_kernel", 5, true);
         hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, stream_, A_, (const int32_t*)nullptr);
-        tick("ambi_finish_kernel", 4, false);
+        tick("ambi_finish_kernel", 5, false);
         HIP_CK(hipGetLastError());
         HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t), hipMemcpyDeviceToHost, stream_));

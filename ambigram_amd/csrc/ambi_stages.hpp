@@ -10,6 +10,7 @@
 //   stage_finish    bkp -> path, indelBFB, output junctions
 #pragma once
 #include "ambi_batch.hpp"
+#include "ambi_enum_blocks.hpp"
 #include "ambi_eval.hpp"
 #include "ambi_finish.hpp"
 #include "ambi_orders.hpp"
@@ -190,7 +191,7 @@ AMBI_HD void plan_serial(const BatchArgs& A) {
         if (off + bytes > A.order_arena_bytes) { out->status = ST_ERR_ORDERS_CAPACITY; off += bytes; continue; }
         out->order_off = off;
         off += bytes;
-        blk += (R + 64ll * T - 1) / (64ll * T);
+        blk += (R + 256ll * T - 1) / (256ll * T);   // one work block = 256*T rows = one workgroup (4 waves x 64*T)
     }
     A.blk_off[A.n_units] = blk;
     *A.orders_needed = off;
@@ -216,6 +217,19 @@ AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R,
     S.prev = stack_mem + (size_t)lanes * K * 2 + lane;
     uint32_t* out = reinterpret_cast<uint32_t*>(unit_rows + first_rank * (int64_t)(NW * 4));
     enumerate_rows<NW, AUTO>(au, V, K, (uint64_t)first_rank, (int)nrows, S, out);
+}
+
+// Block-emission form (ambi_enum_blocks.hpp) of one wave's rows [rlo, rhi); dispatch on the row width.
+template <int CLS, class SYNC>
+AMBI_HD void emit_blocks_dispatch(const BlockTables& B, const AutoView& V, int K, uint64_t rlo, uint64_t rhi, uint8_t* unit_rows,
+                                  uint16_t* idx, uint8_t* prev, uint32_t* pw_lds, int lane_lo, int lane_hi, const SYNC& ws) {
+    const int nw = row_stride(K) / 4;
+    uint32_t* table = reinterpret_cast<uint32_t*>(unit_rows);
+#define AMBI_EB(N) emit_blocks_wave<N>(B, V, rlo, rhi, table, idx, prev, pw_lds, lane_lo, lane_hi, ws); return;
+    if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_EB(1) case 2: AMBI_EB(2) case 3: AMBI_EB(3) case 4: AMBI_EB(4) case 5: AMBI_EB(5) default: break; } }
+    if (CLS < 0 || CLS == 1) { switch (nw) { case 6: AMBI_EB(6) case 7: AMBI_EB(7) case 8: AMBI_EB(8) default: break; } }
+    if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_EB(12) } else if (nw == 16) { AMBI_EB(16) } }
+#undef AMBI_EB
 }
 
 // Row-width classes of the enumerate kernel (one kernel instantiation each, so that the register budget of the wide

@@ -135,7 +135,7 @@ def main():
 
     # ---- algorithmic bytes: B = 8n + 24m + 16K + 2RK + 4EL + 4P per unit, split per kernel ----
     n, m = args.segs, None
-    per_kernel = {"ambi_prepare_kernel": 0, "ambi_plan_kernel": 0, "ambi_enumerate_kernel": 0, "ambi_first_kernel": 0, "ambi_finish_kernel": 0}
+    per_kernel = {"ambi_prepare_kernel": 0, "ambi_plan_kernel": 0, "ambi_blocks_build_kernel": 0, "ambi_enumerate_kernel": 0, "ambi_first_kernel": 0, "ambi_finish_kernel": 0}
     formula = 0
     for u, r in enumerate(res):
         mj = graphs[u].n_junc

@@ -69,21 +69,37 @@ class HostSimBackend : public Backend {
         HostGroup g;
         const int64_t total = blk_off_[units_.size()];
         std::vector<uint8_t> stacks((size_t)enum_stack_bytes(64));
+        const char* env = getenv("AMBI_BLOCK_LDS");
+        const int64_t block_lds = env ? atoll(env) : cfg_.block_lds;
+        std::vector<uint8_t> tables((size_t)(block_lds > 64 ? block_lds : 64));
+        std::vector<uint16_t> idx(64); std::vector<uint8_t> prev(64); std::vector<uint32_t> pw(16);
+        auto nosync = []() {};
         for (int64_t b = 0; b < total; b++) {
             int lo = 0, hi = (int)units_.size();
             while (hi - lo > 1) { int mid = (lo + hi) / 2; if (blk_off_[mid] <= b) lo = mid; else hi = mid; }
             const int u = lo;
             UnitOut* out = unit_out(A_.results, u);
             const int K = out->K, T = rows_per_lane_[u];
-            const int64_t R = out->num_orders, base_rank = (b - blk_off_[u]) * 64ll * T;
+            const int64_t R = out->num_orders, base_rank = (b - blk_off_[u]) * 256ll * T;
             IdealTable tbl = unit_ideal_table(A_, u);
             AutoView V = auto_view(tbl);
-            GlobalAuto ga{V};
-            for (int lane = 0; lane < 64; lane++)
-                enumerate_lane_dispatch<-1>(ga, ga, V, K, R, base_rank + (int64_t)lane * T, T, stacks.data(), lane, 64,
-                                        A_.order_arena + out->order_off);
+            uint8_t* rows = A_.order_arena + out->order_off;
+            BlockTables BT;
+            const bool fast = stage_block_tables(g, tbl, K, row_stride(K) / 4, tables.data(), block_lds, BT);
+            for (int w = 0; w < 4; w++) {
+                const int64_t wlo = base_rank + (int64_t)w * 64 * T;
+                int64_t whi = wlo + 64ll * T;
+                if (whi > R) whi = R;
+                if (wlo >= R) break;
+                if (fast) {
+                    emit_blocks_dispatch<-1>(BT, V, K, (uint64_t)wlo, (uint64_t)whi, rows, idx.data(), prev.data(), pw.data(), 0, 64, nosync);
+                } else {
+                    GlobalAuto ga{V};
+                    for (int lane = 0; lane < 64; lane++)
+                        enumerate_lane_dispatch<-1>(ga, ga, V, K, R, wlo + (int64_t)lane * T, T, stacks.data(), lane, 64, rows);
+                }
+            }
         }
-        (void)g;
     }
 
     // slow path of the first-valid search: all orders, forward pass then flipped pass (LGM.cpp:3519-3696)
