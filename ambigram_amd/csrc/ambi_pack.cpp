@@ -2,6 +2,7 @@
 #include "ambi_pack.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 
 namespace ambi {
@@ -37,9 +38,21 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
     // bkp never grows beyond one seed/append per pattern (2 cells) and 4*cn cells per loop (LGM.cpp:3527-3643)
     int64_t bkp_cap = std::max<int64_t>(4, (L + 7) & ~int64_t(7));
     if (bkp_cap > 32760) return ST_ERR_BKP_CAPACITY;
-    // every breakpoint pair expands to at most n cells (LGM.cpp:3661-3670); a duplication (indelBFB) may repeat a
-    // stretch, so leave the same amount again as head-room
-    int64_t path_cap = std::min<int64_t>(kPathCapLimit, std::max<int64_t>(64, (bkp_cap / 2) * (int64_t)n_seg * 2));
+    // every breakpoint pair expands to at most n cells (LGM.cpp:3661-3670).  indelBFB can only GROW the path through
+    // a duplication (same-strand SV pointing backwards, LGM.cpp:3794-3805: repeats a stretch) or an insertion group
+    // (:3820-3832: adds at most one cell per chained SV); size the head-room accordingly.
+    int64_t bound = std::max<int64_t>(64, ((L + 1) / 2) * (int64_t)n_seg);
+    int64_t n_sv = 0;
+    bool may_dup = false;
+    for (int j = 0; j < n_junc; j++) {
+        const bool same = (j_sdir[j] > 0) == (j_tdir[j] > 0);
+        const bool normal = same && ((j_sdir[j] > 0 && j_tgt[j] - j_src[j] == 1) || (j_sdir[j] <= 0 && j_src[j] - j_tgt[j] == 1));
+        const bool fbi = !same && std::abs(j_src[j] - j_tgt[j]) <= 2;
+        if (normal || fbi) continue;
+        n_sv++;
+        if (same) may_dup = true;
+    }
+    int64_t path_cap = std::min<int64_t>(kPathCapLimit, bound * (may_dup ? 2 : 1) + n_sv + 64);
     path_cap = (path_cap + 7) & ~int64_t(7);
     U.bkp_cap = (int32_t)bkp_cap;
     U.path_cap = (int32_t)path_cap;

@@ -35,11 +35,16 @@ struct PrepareWork {      // group-local memory (LDS on the GPU)
     int32_t* idx;         // [64]   node order
     Rec3* loops;          // [64]   records permuted by the library sort
     uint8_t* taken;       // [m]
+    uint8_t* hash_mem;    // [kPrepHashBytes] group-local order-ideal hash (fast path of the lattice build)
 };
+// Group-local hash for the ideal lattice: kPrepHashSlots slots (keys u64, cnt u64, pos i32), a level list of
+// kPrepHashSlots/2 ideals, level offsets and the two counters.  Lattices with more ideals use the table in HBM.
+constexpr int kPrepHashSlots = 1024;
+constexpr int64_t kPrepHashBytes = 8ll * kPrepHashSlots * 2 + 4ll * kPrepHashSlots + 4ll * (kPrepHashSlots / 2) + 4ll * (kMaxNodes + 3) + 16;
 AMBI_HD int64_t prepare_work_bytes(int n, int m, int K) {
     return pad8(int64_t(sizeof(Junction)) * m) + pad8(8ll * (n + 1)) + pad8(16ll * (n + 1)) + pad8(4ll * (n + 1)) +
            pad8(4ll * (n + 1)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(sizeof(Dag)) +
-           pad8(4ll * (n + 1)) + 2 * pad8(4ll * m) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(m);
+           pad8(4ll * (n + 1)) + 2 * pad8(4ll * m) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(m) + kPrepHashBytes;
 }
 AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
     PrepareWork W;
@@ -56,7 +61,8 @@ AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
     W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
     W.idx = reinterpret_cast<int32_t*>(base + o); o += pad8(4 * 64);
     W.loops = reinterpret_cast<Rec3*>(base + o); o += pad8(sizeof(Rec3) * 64);
-    W.taken = base + o;
+    W.taken = base + o; o += pad8(m);
+    W.hash_mem = base + o;
     return W;
 }
 
@@ -121,7 +127,26 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     uint64_t R = 0;
     if (status == ST_OK) {
         IdealTable T = unit_ideal_table(A, u);
-        int st = ideal_build_and_count(g, W.dag->pred, K, T, &R);
+        // fast path: hash set, level list and counters in group memory (the automaton itself always goes to HBM)
+        IdealTable TL = T;
+        {
+            uint8_t* h = W.hash_mem;
+            TL.keys = reinterpret_cast<uint64_t*>(h); h += 8ll * kPrepHashSlots;
+            TL.cnt = reinterpret_cast<uint64_t*>(h); h += 8ll * kPrepHashSlots;
+            TL.pos = reinterpret_cast<int32_t*>(h); h += 4ll * kPrepHashSlots;
+            TL.lvl = reinterpret_cast<int32_t*>(h); h += 4ll * (kPrepHashSlots / 2);
+            TL.lvl_off = reinterpret_cast<int32_t*>(h); h += 4ll * (kMaxNodes + 3);
+            TL.counter = reinterpret_cast<int32_t*>(h);
+            TL.cap = kPrepHashSlots;
+        }
+        int st = ideal_build_and_count(g, W.dag->pred, K, TL, &R);
+        if (st == ST_OK) {
+            // consumers read the level offsets and the counters from the table in HBM
+            for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) T.lvl_off[d] = TL.lvl_off[d];
+            for (int t = g.tid(); t < 2; t += g.size()) T.counter[t] = TL.counter[t];
+        } else if (st == ST_ERR_IDEALS_CAPACITY) {
+            st = ideal_build_and_count(g, W.dag->pred, K, T, &R);   // large lattice: hash set in HBM
+        }
         if (st != ST_OK) status = st;
     }
 
