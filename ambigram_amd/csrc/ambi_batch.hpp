@@ -89,9 +89,11 @@ struct BatchArgs {
     int32_t target_lanes;        // enumerate kernel: lanes to spread the rows of the batch over (sets rows per lane)
     int32_t enum_stack_lds;      // enumerate kernel: LDS bytes per wave for the per-lane DFS stacks
     int32_t enum_auto_lds;       // enumerate kernel: LDS bytes per wave for the compact automaton copy
-    int32_t block_lds;           // block-emission kernel: LDS bytes per workgroup for automaton + suffix tables
-    int32_t* unit_fallback;      // [U] set by ambi_blocks_build_kernel when a unit's tables do not fit block_lds
-    uint8_t* block_img;          // [U][block_lds] block-emission table images (built once per unit, copied to LDS by users)
+    int32_t block_lds;           // block emission: LDS bytes per workgroup for a unit's image (directory + suffix rows)
+    int32_t block_scratch_lds;   // ambi_blocks_build_kernel: extra LDS bytes for the automaton copy used while building
+    int32_t block_max;           // block emission: largest block (rows); <= kBlockMaxLimit
+    int32_t* unit_fallback;      // [U] set by ambi_blocks_build_kernel when a unit's image does not fit block_lds
+    uint8_t* block_img;          // [U][block_lds] images (built once per unit, copied to LDS by the emitting workgroups)
     int32_t* block_hdr;          // [U][8]  BlockImageHeader
     const UnitIn* units;
     const double* seg_cn;
@@ -120,7 +122,20 @@ struct BatchArgs {
     // scratch for indel grouping (per unit: sv[m], grp[2m+4] ints, taken[m] bytes)
     int32_t* scratch_i32;
     int64_t* scratch_off;        // [U] offset (ints) into scratch_i32
+    int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)
 };
+
+// stage-level timing marks (diagnostics only; one predictable branch per mark when off)
+constexpr int kStageSlots = 32;
+AMBI_HD int64_t stage_clock() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int64_t)__builtin_readcyclecounter();
+#else
+    return 0;
+#endif
+}
+#define AMBI_MARK(A, g, u, slot) \
+    do { if ((A).stage_clk && (g).tid() == 0) (A).stage_clk[(int64_t)(u) * kStageSlots + (slot)] = stage_clock(); } while (0)
 
 AMBI_HD UnitOut* unit_out(uint8_t* results, int u) { return reinterpret_cast<UnitOut*>(results) + u; }
 

@@ -194,42 +194,34 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     if (out->status != ST_OK || out->order_off < 0) return;
     const IdealTable tbl = unit_ideal_table(A, u);
     const int K = out->K;
-    BlockTables B;
-    const bool fits = stage_block_tables(g, tbl, K, row_stride(K) / 4, ambi_lds, A.block_lds, B);
-    BlockImageHeader* hdr = reinterpret_cast<BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
-    const int64_t image = fits ? (reinterpret_cast<uint8_t*>(B.suf) - ambi_lds) + 4ll * B.suf_words : 0;
+    BlockImageHeader H;
+    const bool fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, ambi_lds + A.block_lds,
+                                        A.block_scratch_lds, ambi_lds, A.block_lds, H);
     if (threadIdx.x == 0) {
-        hdr->fits = fits ? 1 : 0; hdr->nI = tbl.counter[0]; hdr->nC = tbl.counter[1];
-        hdr->suf_words = fits ? B.suf_words : 0; hdr->image_bytes = (int32_t)image;
+        *reinterpret_cast<BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u) = H;
         A.unit_fallback[u] = fits ? 0 : 1;
     }
     if (!fits) return;
-    const int64_t nvec = (image + 15) >> 4;
+    const int64_t nvec = ((int64_t)H.image_bytes + 15) >> 4;
     uint4* dst = reinterpret_cast<uint4*>(A.block_img + (int64_t)u * A.block_lds);
     const uint4* src = reinterpret_cast<const uint4*>(ambi_lds);
     for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
 }
 
-// Fast path: block emission (ambi_enum_blocks.hpp).  One workgroup per work block of 256*T rows; the workgroup stages
-// the unit's automaton + suffix-block tables in LDS once, then every wave walks its 64*T rows block by block with a
-// wave-uniform DFS and writes them with fully coalesced 16-byte stores.
-// LDS: [block_lds] tables | per wave: idx[64] u16, prev[64] u8, pw[16] u32.
+// Fast path: block emission (ambi_enum_blocks.hpp).  One workgroup per work block of 256*T rows; the workgroup copies
+// the unit's image (block directory + suffix rows) from HBM into LDS, then every wave streams its 64*T rows block by
+// block: four LDS reads, four ORs and one fully coalesced 16-byte store per lane and step.
+// LDS: [block_lds] image.
 template <int CLS>
 __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t* tmem = ambi_lds;
-    uint8_t* wmem = ambi_lds + A.block_lds + (size_t)wave * 256;
-    uint16_t* idx = reinterpret_cast<uint16_t*>(wmem);
-    uint8_t* prev = wmem + 128;
-    uint32_t* pw = reinterpret_cast<uint32_t*>(wmem + 192);
     const int64_t total = A.blk_off[A.n_units];
     int staged_unit = -1;
     bool fits = false;
-    BlockTables B;
-    WaveGroup wg;
-    auto wsync = [&]() { wg.sync(); };
+    int nB = 0;
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
@@ -237,30 +229,28 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
         if (enum_class_of(K) != CLS) continue;
-        const IdealTable tbl = unit_ideal_table(A, u);
         if (u != staged_unit) {
             g.sync();
             const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
             fits = hdr->fits != 0;
-            if (fits) {   // coalesced copy of the unit's table image into LDS
+            nB = hdr->nB;
+            if (fits) {   // coalesced copy of the unit's image into LDS
                 const int64_t nvec = ((int64_t)hdr->image_bytes + 15) >> 4;
                 const uint4* src = reinterpret_cast<const uint4*>(A.block_img + (int64_t)u * A.block_lds);
                 uint4* dst = reinterpret_cast<uint4*>(tmem);
                 for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
-                (void)carve_block_tables(tmem, hdr->nI, hdr->nC, B);
-                B.suf_words = hdr->suf_words;
             }
             staged_unit = u;
             g.sync();
         }
         if (!fits) continue;
-        const int64_t R = out->num_orders;
+        const int64_t R = out->num_orders;   // < 2^32 for every unit that has an image
         const int64_t wlo = (b - A.blk_off[u]) * 256ll * T + (int64_t)wave * 64 * T;
         int64_t whi = wlo + 64ll * T;
         if (whi > R) whi = R;
         if (wlo < R)
-            emit_blocks_dispatch<CLS>(B, auto_view(tbl), K, (uint64_t)wlo, (uint64_t)whi, A.order_arena + out->order_off, idx, prev, pw,
-                                      lane, lane + 1, wsync);
+            emit_blocks_dispatch<CLS>(reinterpret_cast<const uint32_t*>(tmem), nB, K, (uint32_t)wlo, (uint32_t)whi,
+                                      A.order_arena + out->order_off, lane, lane + 1);
     }
 }
 
@@ -379,7 +369,8 @@ class HipBackend : public Backend {
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; int32_t* d_ilvl_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
     int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
-    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096, enum_classes_ = 0, block_lds_ = 49152, lds_blocks_ = 0;
+    int enum_stack_lds_ = 0, enum_auto_lds_ = 4096, enum_classes_ = 0, block_lds_ = 49152, lds_blocks_ = 0, block_scratch_lds_ = 32768, lds_build_ = 0, block_max_ = 256;
+    int64_t* d_stage_clk_ = nullptr;
     int32_t* d_fallback_ = nullptr; uint8_t* d_blk_img_ = nullptr; int32_t* d_blk_hdr_ = nullptr;
     uint8_t* d_arena_ = nullptr; int64_t arena_bytes_ = 0;
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
@@ -396,7 +387,7 @@ class HipBackend : public Backend {
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilvl_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
-                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_};
+                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
@@ -451,6 +442,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_scratch_off_, U))) return rc;
         if ((rc = dalloc(&d_pack_off_, U + 1))) return rc;
         if ((rc = dalloc(&d_fallback_, U))) return rc;
+        if (getenv("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
         HIP_CK(hipHostMalloc((void**)&h_npending_, sizeof(int32_t)));
         HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t)));
         arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
@@ -468,11 +460,15 @@ class HipBackend : public Backend {
         enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
-        lds_blocks_ = block_lds_ + 4 * 256;
+        { const char* env = getenv("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
+        lds_blocks_ = block_lds_;
+        block_scratch_lds_ = (cfg.block_scratch_lds + 15) & ~15;
+        lds_build_ = block_lds_ + block_scratch_lds_;
         if ((rc = dalloc(&d_blk_img_, U * (size_t)block_lds_))) return rc;
         if ((rc = dalloc(&d_blk_hdr_, U * 8))) return rc;
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds_));
         const int kLdsLimit = 160 * 1024 - 1024;
+        if (lds_build_ > kLdsLimit) { block_scratch_lds_ = kLdsLimit - block_lds_ > 0 ? ((kLdsLimit - block_lds_) & ~15) : 0; lds_build_ = block_lds_ + block_scratch_lds_; }
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_build_));
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
                     lds_prepare_, lds_first_, lds_finish_);
@@ -498,14 +494,14 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size();
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
-        A_.block_lds = block_lds_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
+        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
         A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_lvl = d_ilvl_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
         A_.order_arena = d_arena_; A_.order_arena_bytes = arena_bytes_;
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
-        A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_;
+        A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
     }
 
     // Per-kernel HIP events on the run's stream.  A ring of kTimingSlots event sets lets a timed region of many runs be
@@ -560,7 +556,7 @@ class HipBackend : public Backend {
         const int U = A_.n_units;
         (void)hipMemsetAsync(d_fallback_, 0, sizeof(int32_t) * (size_t)U, stream_);
         tick("ambi_blocks_build_kernel", 2, true);
-        hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(U), dim3(256), block_lds_, stream_, A_);
+        hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(U), dim3(256), lds_build_, stream_, A_);
         tick("ambi_blocks_build_kernel", 2, false);
         tick("ambi_enumerate_kernel", 3, true);
         if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
@@ -657,7 +653,24 @@ class HipBackend : public Backend {
         if (rc) return rc;
         blob.resize((size_t)hb_.result_bytes);
         HIP_CK(hipMemcpy(blob.data(), d_results_, (size_t)hb_.result_bytes, hipMemcpyDeviceToHost));
+        if (d_stage_clk_) dump_stage_profile();
         return 0;
+    }
+    // AMBI_STAGE_PROFILE=1: mean shader-clock distance between consecutive marks of the per-unit stages (last run)
+    void dump_stage_profile() {
+        const size_t U = hb_.units.size();
+        std::vector<int64_t> clk(U * kStageSlots);
+        if (hipMemcpy(clk.data(), d_stage_clk_, clk.size() * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+        fprintf(stderr, "ambigram_hip stage profile (mean cycles between marks, %zu units):", U);
+        for (int s = 1; s < kStageSlots; s++) {
+            double sum = 0; size_t cnt = 0;
+            for (size_t u = 0; u < U; u++) {
+                const int64_t a = clk[u * kStageSlots + s - 1], b = clk[u * kStageSlots + s];
+                if (a && b && b >= a) { sum += (double)(b - a); cnt++; }
+            }
+            if (cnt) fprintf(stderr, " [%d->%d] %.0f", s - 1, s, sum / cnt);
+        }
+        fprintf(stderr, "\n");
     }
     int device_results(void** ptr, int64_t* bytes) override {
         if (ptr) *ptr = d_results_;

@@ -97,6 +97,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     uint8_t* res = A.results + U.res_off;
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
     UnitOut* out = unit_out(A.results, u);
+    AMBI_MARK(A, g, u, 0);
 
     // coalesced staging of the unit's records (as 32-bit words) into the group's memory
     copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
@@ -107,22 +108,28 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
                int64_t(sizeof(Element) / 4) * K);
     for (int i = g.tid(); i <= n; i += g.size()) W.target_cn[i] = 0;
     g.sync();
+    AMBI_MARK(A, g, u, 1);
 
     int status = ST_OK;
     double inv_sum = 0;
     get_junc_cn_g(g, n, W.juncs, m, W.junc_cn, W.inv_junc, W.slot_cnt, W.fb);            // localhap.cpp:136-139
+    AMBI_MARK(A, g, u, 2);
     const int bias = compute_bias_g(g, n, W.juncs, W.junc_cn, W.inv_junc);                // :141-146
+    AMBI_MARK(A, g, u, 3);
     get_indel_bias_g(g, n, W.juncs, m, W.seg_cn, W.sv, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
+    AMBI_MARK(A, g, u, 4);
     const bool no_fbi = no_foldback_g(g, n, W.junc_cn, &inv_sum);                         // :150-153
     if (no_fbi && !U.has_components) status = ST_SHORTCUT;                                // :164
     else if (U.infeasible) status = ST_INFEASIBLE;                                        // :213
     else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
     else {
         target_cn_g(g, W.elems, K, n, W.target_cn);                                       // :222-232
+        AMBI_MARK(A, g, u, 5);
         DagScratch DS{W.idx, W.loops};
         status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS);                  // :236
     }
     g.sync();
+    AMBI_MARK(A, g, u, 6);
 
     uint64_t R = 0;
     if (status == ST_OK) {
@@ -150,6 +157,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
         if (st != ST_OK) status = st;
     }
 
+    AMBI_MARK(A, g, u, 7);
     // results: junc_cn, seg_cn (after indel bias), target_cn, fold-back map
     copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.junc_cn), reinterpret_cast<const uint32_t*>(W.junc_cn), 4ll * (n + 1));
     copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.seg_cn), reinterpret_cast<const uint32_t*>(W.seg_cn), 2ll * (n + 1));
@@ -178,6 +186,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
         out->inv_cn_sum = inv_sum;
     }
     g.sync();
+    AMBI_MARK(A, g, u, 8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -245,12 +254,12 @@ AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R,
 }
 
 // Block-emission form (ambi_enum_blocks.hpp) of one wave's rows [rlo, rhi); dispatch on the row width.
-template <int CLS, class SYNC>
-AMBI_HD void emit_blocks_dispatch(const BlockTables& B, const AutoView& V, int K, uint64_t rlo, uint64_t rhi, uint8_t* unit_rows,
-                                  uint16_t* idx, uint8_t* prev, uint32_t* pw_lds, int lane_lo, int lane_hi, const SYNC& ws) {
+template <int CLS>
+AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t rlo, uint32_t rhi, uint8_t* unit_rows,
+                                  int lane_lo, int lane_hi) {
     const int nw = row_stride(K) / 4;
     uint32_t* table = reinterpret_cast<uint32_t*>(unit_rows);
-#define AMBI_EB(N) emit_blocks_wave<N>(B, V, rlo, rhi, table, idx, prev, pw_lds, lane_lo, lane_hi, ws); return;
+#define AMBI_EB(N) emit_blocks_wave<N>(img, nB, rlo, rhi, table, lane_lo, lane_hi); return;
     if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_EB(1) case 2: AMBI_EB(2) case 3: AMBI_EB(3) case 4: AMBI_EB(4) case 5: AMBI_EB(5) default: break; } }
     if (CLS < 0 || CLS == 1) { switch (nw) { case 6: AMBI_EB(6) case 7: AMBI_EB(7) case 8: AMBI_EB(8) default: break; } }
     if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_EB(12) } else if (nw == 16) { AMBI_EB(16) } }
@@ -453,20 +462,25 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     if (status != ST_OK) return;
     FinishWork W = carve_finish(work, n, m, U.bkp_cap, U.path_cap, U.out_cap);
     const int L = out->bkp_len;
+    AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
     copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
                int64_t(sizeof(Junction) / 4) * m);
     g.sync();
+    AMBI_MARK(A, g, u, 17);
     int P = expand_bkp(g, W.bkp, L, W.path, U.path_cap, W.offs);
     if (P < 0) { if (g.tid() == 0) out->status = P; g.sync(); return; }
     for (int i = g.tid(); i < P; i += g.size()) { int v = W.path[i]; gpath[i] = v > 0 ? v + base : v - base; }
     int P2 = P;
+    AMBI_MARK(A, g, u, 18);
     IndelScratch S{W.sv, W.taken, W.has_ext, W.grp, W.first, W.last};
     int printed = indel_bfb(g, n, W.juncs, m, W.path, &P2, U.path_cap, S);
     if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
+    AMBI_MARK(A, g, u, 19);
     for (int i = g.tid(); i < P2; i += g.size()) { int v = W.path[i]; gpath2[i] = v > 0 ? v + base : v - base; }
     // output junctions of the final path; records are produced in LDS-free form straight into the blob
     int nout = synth_out_juncs(g, W.path, P2, gout, U.out_cap, W.cand, U.out_cap + U.bkp_cap);
+    AMBI_MARK(A, g, u, 20);
     if (nout >= 0) {
         g.sync();
         for (int k = g.tid(); k < nout; k += g.size()) {
@@ -481,6 +495,7 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
         if (nout < 0) out->status = nout;
     }
     g.sync();
+    AMBI_MARK(A, g, u, 21);
 }
 
 }  // namespace ambi

@@ -12,6 +12,8 @@ DAG-shape tiers (K = number of planted elements, R = number of topological order
   chain : nested loops, each sharing an end with its parent            -> R = 1
   wide  : root l(s,e) + {l(s+i,e)} i=1..k + {l(s,e-j)} j=1..k           -> K = 2k+1, R = C(2k,k)
           (K=19 -> 48 620 orders, K=25 -> 2 704 156 orders)
+  skew  : root + {l(s+i,e)} i=1..K-4 + {l(s,e-j)} j=1..3                -> R = C(K-1,3)  (wide rows, moderate R)
+  mixed : chain of loops + one or two patterns hanging off the telomere
 Seeds follow SURVEY.md 8d: seed = 1000*config + sample_index.
 """
 from dataclasses import dataclass, field
@@ -102,6 +104,18 @@ def planted_wide(rng, s, e, k, cn_choices=(1, 2)):
     return els
 
 
+def planted_skew(rng, s, e, K, cn_choices=(1, 2), k2=3):
+    """root + a long family of K-1-k2 loops and a short one of k2 -> R = C(K-1, k2): many nodes, moderate R."""
+    k1 = K - 1 - k2
+    assert k1 >= 1 and e - s >= k1 + k2 + 1, "chromosome too short for skew tier"
+    els = [Element('l', s, e, rng.choice(cn_choices))]
+    for i in range(1, k1 + 1):
+        els.append(Element('l', s + i, e, rng.choice(cn_choices)))
+    for j in range(1, k2 + 1):
+        els.append(Element('l', s, e - j, rng.choice(cn_choices)))
+    return els
+
+
 def planted_mixed(rng, s, e, K, cn_choices=(1, 2)):
     """chain of loops followed by a short pattern chain hanging off the telomere (adds p-nodes to the DAG)."""
     kl = max(1, K - 2)
@@ -116,7 +130,7 @@ def planted_mixed(rng, s, e, K, cn_choices=(1, 2)):
 
 def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperfect=0, n_del=0, n_dup=0,
                 translocations=0, name=None, prop=None, cn_choices=(1, 2), near_inv=0):
-    """Build one synthetic sample. `tier` in {chain, wide, mixed}. For wide, K must be odd (K = 2k+1)."""
+    """Build one synthetic sample. `tier` in {chain, wide, skew, mixed}. For wide, K must be odd (K = 2k+1)."""
     rng = random.Random(seed)
     name = name or "syn_n%d_m%d_%s_K%d_s%d" % (n_seg, n_junc, tier, K, seed)
     # chromosome ranges
@@ -155,6 +169,8 @@ def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperf
             els = planted_wide(rng, s, e, (K - 1) // 2, cn_choices)
         elif tier == "mixed":
             els = planted_mixed(rng, s, e, K, cn_choices)
+        elif tier == "skew":
+            els = planted_skew(rng, s, e, K, cn_choices)
         else:
             raise ValueError(tier)
         all_elements.append(els)

@@ -33,7 +33,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="samples (units) per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="samples (units) per GPU")
     ap.add_argument("--segs", type=int, default=256)
     ap.add_argument("--juncs", type=int, default=512)
     ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])

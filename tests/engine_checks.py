@@ -141,3 +141,53 @@ def check_batch_many_units(lib, oracle, workdir, n_samples):
     for i, oc in enumerate(expect):
         assert b.unit_path(i, 1).tolist() == oc["path_indel"], i
     return b, graphs, expect
+
+
+def check_enumerate_variants(lib, oracle, workdir, big=False):
+    """The order table (allTopologicalOrders, LGM.cpp:3380-3409) through every enumeration path of the engine:
+    block emission with several block sizes (AMBI_BLOCK_MAX: 1 = one row per block ... 1024), with an LDS budget that
+    forces the general per-lane DFS (AMBI_BLOCK_LDS=64), and with few / many rows per lane -- all byte-identical to the
+    oracle's orders."""
+    import os
+    from ambigram_amd import synth
+    specs = [("wide", 11, 40, 90), ("mixed", 12, 48, 100), ("chain", 9, 40, 80), ("wide", 13, 64, 128)]
+    if big:
+        specs += [("wide", 15, 96, 200), ("mixed", 22, 128, 256), ("chain", 35, 256, 512)]
+    specs += [("skew", 23, 64, 128), ("skew", 27, 64, 128), ("skew", 34, 96, 200), ("skew", 45, 128, 256), ("skew", 50, 128, 256)]
+    samples = []
+    for i, (tier, K, nseg, njunc) in enumerate(specs):
+        s = synth.make_sample(nseg, njunc, tier, K, seed=7100 + i)
+        lh, sols = s.write(workdir, "ev%d" % i)
+        oc = oracle.run_bfb(lh, sols, keep_orders=True)["chr"][0]
+        samples.append((lh, sols, oc))
+    variants = [({}, 0), ({"AMBI_BLOCK_MAX": "1"}, 0), ({"AMBI_BLOCK_MAX": "6"}, 64), ({"AMBI_BLOCK_MAX": "1024", "AMBI_BLOCK_LDS": "150000"}, 0),
+                ({"AMBI_BLOCK_LDS": "64"}, 0), ({"AMBI_BLOCK_LDS": "64"}, 100000), ({"AMBI_BLOCK_MAX": "37"}, 1 << 20)]
+    saved = {k: os.environ.get(k) for k in ("AMBI_BLOCK_MAX", "AMBI_BLOCK_LDS")}
+    try:
+        for env, lanes in variants:
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            graphs, b = [], api.Batch(lib)
+            if lanes:
+                b.configure(target_lanes=lanes)
+            for lh, sols, oc in samples:
+                g = api.Graph(lib, lh)
+                graphs.append(g)
+                b.add_chromosome_sol(g, 0, sols[0])
+            b.upload(); b.run(0); b.download()
+            for u, (lh, sols, oc) in enumerate(samples):
+                r = b.unit_result(u)
+                assert r["status"] == 0 and r["num_orders"] == oc["num_orders"], (env, lanes, u, r)
+                got = b.unit_orders(u, 0, r["num_orders"], r["n_nodes"])
+                if oc["orders"]:
+                    assert got.tolist() == oc["orders"], (env, lanes, u)
+                assert b.unit_path(u, 1).tolist() == oc["path_indel"], (env, lanes, u)
+            b.close()
+            for g in graphs:
+                g.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -62,7 +62,7 @@ class HostSimBackend : public Backend {
         A_.order_arena = arena_.data(); A_.order_arena_bytes = (int64_t)arena_.size();
         A_.blk_off = blk_off_.data(); A_.rows_per_lane = rows_per_lane_.data();
         A_.n_pending = &n_pending_; A_.orders_needed = &orders_needed_;
-        A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data();
+        A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
     }
 
     void enumerate_all() {
@@ -71,9 +71,13 @@ class HostSimBackend : public Backend {
         std::vector<uint8_t> stacks((size_t)enum_stack_bytes(64));
         const char* env = getenv("AMBI_BLOCK_LDS");
         const int64_t block_lds = env ? atoll(env) : cfg_.block_lds;
-        std::vector<uint8_t> tables((size_t)(block_lds > 64 ? block_lds : 64));
-        std::vector<uint16_t> idx(64); std::vector<uint8_t> prev(64); std::vector<uint32_t> pw(16);
-        auto nosync = []() {};
+        const char* envm = getenv("AMBI_BLOCK_MAX");
+        const int block_max = envm ? atoi(envm) : cfg_.block_max;
+        std::vector<uint8_t> image((size_t)(block_lds > 64 ? block_lds : 64));
+        std::vector<uint8_t> bscratch((size_t)cfg_.block_scratch_lds);
+        int built_unit = -1;
+        BlockImageHeader H{};
+        bool fast = false;
         for (int64_t b = 0; b < total; b++) {
             int lo = 0, hi = (int)units_.size();
             while (hi - lo > 1) { int mid = (lo + hi) / 2; if (blk_off_[mid] <= b) lo = mid; else hi = mid; }
@@ -84,15 +88,18 @@ class HostSimBackend : public Backend {
             IdealTable tbl = unit_ideal_table(A_, u);
             AutoView V = auto_view(tbl);
             uint8_t* rows = A_.order_arena + out->order_off;
-            BlockTables BT;
-            const bool fast = stage_block_tables(g, tbl, K, row_stride(K) / 4, tables.data(), block_lds, BT);
+            if (u != built_unit) {   // ambi_blocks_build_kernel: once per unit
+                fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, block_max, bscratch.data(), (int64_t)bscratch.size(),
+                                         image.data(), block_lds, H);
+                built_unit = u;
+            }
             for (int w = 0; w < 4; w++) {
                 const int64_t wlo = base_rank + (int64_t)w * 64 * T;
                 int64_t whi = wlo + 64ll * T;
                 if (whi > R) whi = R;
                 if (wlo >= R) break;
                 if (fast) {
-                    emit_blocks_dispatch<-1>(BT, V, K, (uint64_t)wlo, (uint64_t)whi, rows, idx.data(), prev.data(), pw.data(), 0, 64, nosync);
+                    emit_blocks_dispatch<-1>(reinterpret_cast<const uint32_t*>(image.data()), H.nB, K, (uint32_t)wlo, (uint32_t)whi, rows, 0, 64);
                 } else {
                     GlobalAuto ga{V};
                     for (int lane = 0; lane < 64; lane++)

@@ -42,6 +42,10 @@ def test_batch_many_units(hip_lib, oracle, workdir):
     ec.check_batch_many_units(hip_lib, oracle, workdir, 48)
 
 
+def test_enumerate_variants(hip_lib, oracle, workdir):
+    ec.check_enumerate_variants(hip_lib, oracle, workdir, big=True)
+
+
 def test_config2_full_size_properties(hip_lib, oracle, workdir):
     """BASELINE config 2 (256 seg / 512 junc), wide tier K=19: R = C(18,9) = 48 620 orders.
     Properties that do not need the oracle at full size + one full oracle comparison."""

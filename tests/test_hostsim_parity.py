@@ -30,3 +30,7 @@ def test_juncs_file(hostsim_lib, oracle, workdir):
 
 def test_batch_many_units(hostsim_lib, oracle, workdir):
     ec.check_batch_many_units(hostsim_lib, oracle, workdir, 12)
+
+
+def test_enumerate_variants(hostsim_lib, oracle, workdir):
+    ec.check_enumerate_variants(hostsim_lib, oracle, workdir)
