@@ -23,7 +23,8 @@ class UnitResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("bias", C.c_int32), ("n_nodes", C.c_int32), ("bkp_len", C.c_int32),
                 ("path_len", C.c_int32), ("path_indel_len", C.c_int32), ("indel_printed", C.c_int32),
                 ("n_out_junc", C.c_int32), ("first_forward", C.c_int32), ("evaluated", C.c_int32),
-                ("num_orders", C.c_int64), ("first_valid", C.c_int64), ("inv_cn_sum", C.c_double)]
+                ("num_orders", C.c_int64), ("first_valid", C.c_int64), ("inv_cn_sum", C.c_double),
+                ("path_indel_stored", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AmbiError(RuntimeError):

@@ -49,6 +49,8 @@ struct UnitOut {
     int64_t first_valid;     // index of the first valid order or -1
     int64_t order_off;       // byte offset of this unit's rows in the order-table arena (-1: not materialised)
     double inv_cn_sum;       // localhap.cpp:150-153
+    int32_t path_ind_stored; // 1: indelBFB edited the path and path_ind holds it; 0: path_ind equals path and was not written
+    int32_t reserved;
 };
 
 // Variable part of a unit inside the result blob, in this order (each array padded to 8 bytes):
@@ -102,10 +104,10 @@ struct BatchArgs {
     Dag* dags;                   // [U]
     uint8_t* results;            // result blob; UnitOut[U] at the front
     // ideal tables (pools indexed by UnitIn::ideal_off; cap = UnitIn::ideal_cap slots per unit)
-    uint64_t* ideal_keys;        // [slots]
-    uint64_t* ideal_cnt;         // [slots]
-    int32_t* ideal_pos;          // [slots]
-    int32_t* ideal_lvl;          // [slots/2]
+    uint64_t* ideal_keys;        // [slots]    lattice search in HBM (large lattices): hash keys
+    uint64_t* ideal_cnt;         // [slots]    first half of a unit's range: ideal masks by index, second half: counts
+    int32_t* ideal_pos;          // [slots]    hash slot -> ideal index
+    uint32_t* ideal_link;        // [4*slots]  child links
     int32_t* ideal_lvl_off;      // [U][kMaxNodes+3]
     int32_t* ideal_counter;      // [U][2]
     uint64_t* auto_avail;        // [slots/2]

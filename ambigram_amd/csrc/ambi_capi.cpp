@@ -233,6 +233,7 @@ int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result
     out->path_len = h->path_len; out->path_indel_len = h->path_indel_len; out->indel_printed = h->indel_printed;
     out->n_out_junc = h->n_out_junc; out->first_forward = h->first_forward; out->evaluated = h->evaluated;
     out->num_orders = h->num_orders; out->first_valid = h->first_valid; out->inv_cn_sum = h->inv_cn_sum;
+    out->path_indel_stored = h->path_ind_stored; out->reserved = 0;
     return 0;
 }
 int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int32_t* out, int32_t cap) {
@@ -240,7 +241,8 @@ int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int
     if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     const UnitIn& U = b->hb.units[unit];
     UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-    const int32_t* src = reinterpret_cast<const int32_t*>(b->blob.data() + U.res_off + (which ? L.path_ind : L.path));
+    // the path after indelBFB is stored separately only when indelBFB changed it
+    const int32_t* src = reinterpret_cast<const int32_t*>(b->blob.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
     int len = which ? h->path_indel_len : h->path_len;
     if (out) for (int i = 0; i < len && i < cap; i++) out[i] = src[i];
     return len;

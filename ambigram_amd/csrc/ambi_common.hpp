@@ -67,6 +67,20 @@ struct Junction {
 };
 static_assert(sizeof(Junction) == 24, "junction record is 24 bytes");
 
+// Strand-signed ends of a junction (edge A: sign = strand, Junction.cpp:27-39): all that the per-unit scans need
+// besides the copy number; 4 bytes per junction in group memory instead of the 24-byte record.
+struct JuncEnds { int16_t s, t; };
+struct JuncView {
+    const JuncEnds* e;       // [m] group memory
+    const Junction* full;    // [m] the unit's records in HBM (copy numbers)
+};
+AMBI_HD JuncEnds junc_ends(const Junction& j) {
+    JuncEnds E;
+    E.s = (int16_t)(j.sdir > 0 ? j.src : -j.src);
+    E.t = (int16_t)(j.tdir > 0 ? j.tgt : -j.tgt);
+    return E;
+}
+
 AMBI_HD int a_src(const Junction& j) { return j.sdir > 0 ? j.src : -j.src; }   // edge A (Junction.cpp:27-39)
 AMBI_HD int a_tgt(const Junction& j) { return j.tdir > 0 ? j.tgt : -j.tgt; }
 AMBI_HD int b_src(const Junction& j) { return -a_tgt(j); }                      // edge B = complement

@@ -195,17 +195,13 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     const IdealTable tbl = unit_ideal_table(A, u);
     const int K = out->K;
     BlockImageHeader H;
-    const bool fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, ambi_lds + A.block_lds,
-                                        A.block_scratch_lds, ambi_lds, A.block_lds, H);
+    // the automaton copy sits in LDS, the image is assembled word by word straight in its HBM slot
+    const bool fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, ambi_lds, A.block_scratch_lds,
+                                        A.block_img + (int64_t)u * A.block_lds, A.block_lds, H);
     if (threadIdx.x == 0) {
         *reinterpret_cast<BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u) = H;
         A.unit_fallback[u] = fits ? 0 : 1;
     }
-    if (!fits) return;
-    const int64_t nvec = ((int64_t)H.image_bytes + 15) >> 4;
-    uint4* dst = reinterpret_cast<uint4*>(A.block_img + (int64_t)u * A.block_lds);
-    const uint4* src = reinterpret_cast<const uint4*>(ambi_lds);
-    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
 }
 
 // Fast path: block emission (ambi_enum_blocks.hpp).  One workgroup per work block of 256*T rows; the workgroup copies
@@ -350,7 +346,8 @@ __global__ __launch_bounds__(256) void ambi_pack_copy_kernel(BatchArgs A, int wh
     const int u = blockIdx.x;
     const UnitIn& U = A.units[u];
     const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-    const int32_t* src = reinterpret_cast<const int32_t*>(A.results + U.res_off + (which ? L.path_ind : L.path));
+    const bool stored = which && unit_out(A.results, u)->path_ind_stored;   // else the edited path equals `path`
+    const int32_t* src = reinterpret_cast<const int32_t*>(A.results + U.res_off + (stored ? L.path_ind : L.path));
     const int64_t off = pack_off[u], len = pack_off[u + 1] - off;
     for (int64_t i = threadIdx.x; i < len; i += blockDim.x)
         if (off + i < cap) cells[off + i] = src[i];
@@ -367,7 +364,7 @@ class HipBackend : public Backend {
     // device buffers
     UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; Element* d_elems_ = nullptr;
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
-    uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; int32_t* d_ilvl_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
+    uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; uint32_t* d_ilink_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
     int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
     int enum_stack_lds_ = 0, enum_auto_lds_ = 4096, enum_classes_ = 0, block_lds_ = 49152, lds_blocks_ = 0, block_scratch_lds_ = 32768, lds_build_ = 0, block_max_ = 256;
     int64_t* d_stage_clk_ = nullptr;
@@ -385,7 +382,7 @@ class HipBackend : public Backend {
     long timed_runs_ = 0;
 
     void free_all() {
-        void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilvl_, d_ilvl_off_,
+        void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -426,7 +423,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_results_, (size_t)hb.result_bytes))) return rc;
         if ((rc = dalloc(&d_ikeys_, (size_t)hb.ideal_slots))) return rc;
         if ((rc = dalloc(&d_icnt_, (size_t)hb.ideal_slots))) return rc;
-        if ((rc = dalloc(&d_ilvl_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
+        if ((rc = dalloc(&d_ilink_, (size_t)hb.ideal_slots * 4 + 8))) return rc;
         if ((rc = dalloc(&d_ilvl_off_, U * (kMaxNodes + 3)))) return rc;
         if ((rc = dalloc(&d_icounter_, 2 * U))) return rc;
         if ((rc = dalloc(&d_ipos_, (size_t)hb.ideal_slots))) return rc;
@@ -462,12 +459,12 @@ class HipBackend : public Backend {
         { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
         { const char* env = getenv("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
         lds_blocks_ = block_lds_;
-        block_scratch_lds_ = (cfg.block_scratch_lds + 15) & ~15;
-        lds_build_ = block_lds_ + block_scratch_lds_;
+        const int kLdsLimit = 160 * 1024 - 1024;
+        { const char* env = getenv("AMBI_BLOCK_SCRATCH_LDS"); block_scratch_lds_ = ((env ? atoi(env) : cfg.block_scratch_lds) + 15) & ~15; }
+        if (block_scratch_lds_ > kLdsLimit) block_scratch_lds_ = kLdsLimit & ~15;
+        lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
         if ((rc = dalloc(&d_blk_img_, U * (size_t)block_lds_))) return rc;
         if ((rc = dalloc(&d_blk_hdr_, U * 8))) return rc;
-        const int kLdsLimit = 160 * 1024 - 1024;
-        if (lds_build_ > kLdsLimit) { block_scratch_lds_ = kLdsLimit - block_lds_ > 0 ? ((kLdsLimit - block_lds_) & ~15) : 0; lds_build_ = block_lds_ + block_scratch_lds_; }
         HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_build_));
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
@@ -498,7 +495,7 @@ class HipBackend : public Backend {
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
-        A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_lvl = d_ilvl_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
+        A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_link = d_ilink_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
         A_.order_arena = d_arena_; A_.order_arena_bytes = arena_bytes_;
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;

@@ -165,13 +165,13 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     if (!B.misc[2] || nB > (1 << 24) || 4 * (dw + suf_words) > image_bytes) return false;
     uint32_t* suf = img + dw;
     // ---- directory: block b = b-th stop of the walk, unranked over nblk; first row from the exact 64-bit counts ----
+    // (the image may live in HBM: whole words only, nothing is read back)
     for (int64_t b = g.tid(); b < nB; b += g.size()) {
         uint32_t* e = img + b * S;
-        for (int x = 0; x < NW; x++) e[2 + x] = 0;
-        uint8_t* pb = reinterpret_cast<uint8_t*>(e + 2);
         int i = 0, d = 0;
         uint32_t rem = (uint32_t)b;
         uint64_t row = 0;
+        uint32_t w = 0, w0 = 0, w1 = 0, w2 = 0;   // word being assembled; the first three prefix words (wrap copies)
         while (B.cnt16[i] > block_max) {
             uint64_t av = B.avail[i];
             int k = B.cbase[i];
@@ -185,12 +185,27 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
                 rem -= nb;
                 row += T.a_cnt[nxt];
             }
-            pb[d] = (uint8_t)chosen;
+            w |= (uint32_t)chosen << ((d & 3) * 8);
+            if ((d & 3) == 3) {
+                const int wi = d >> 2;
+                e[2 + wi] = w;
+                if (wi == 0) w0 = w; else if (wi == 1) w1 = w; else if (wi == 2) w2 = w;
+                w = 0;
+            }
             i = nxt; d++;
+        }
+        {   // the partial word and the all-zero words behind the prefix
+            int wi = d >> 2;
+            if ((d & 3) != 0) {
+                e[2 + wi] = w;
+                if (wi == 0) w0 = w; else if (wi == 1) w1 = w; else if (wi == 2) w2 = w;
+                wi++;
+            }
+            for (; wi < NW; wi++) e[2 + wi] = 0;
         }
         e[0] = (uint32_t)row;
         e[1] = B.soff[i];
-        for (int x = NW; x < NW + 3; x++) e[2 + x] = e[2 + (x % NW)];
+        for (int x = NW; x < NW + 3; x++) { const int y = x % NW; e[2 + x] = y == 0 ? w0 : (y == 1 ? w1 : w2); }
     }
     if (g.tid() == 0) img[nB * S] = (uint32_t)R;
     // ---- suffix rows: row r of root p = r-th completion of p in lexicographic order, bytes in their final positions ----
@@ -201,10 +216,11 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         const int p = B.roots[q];
         int rr = f - (int)B.root_row[q];
         uint32_t* dst = suf + B.soff[p] + rr * NW;
-        for (int x = 0; x < NW; x++) dst[x] = 0;
-        uint8_t* db = reinterpret_cast<uint8_t*>(dst);
-        int j = p;
-        for (int d = B.depth[p]; d < K; d++) {
+        const int D = B.depth[p];
+        for (int x = 0; x < (D >> 2); x++) dst[x] = 0;
+        uint32_t w = 0;                       // word being assembled (bytes < D of word D>>2 stay zero)
+        int j = p, d = D;
+        for (; d < K; d++) {
             uint64_t av = B.avail[j];
             int k = B.cbase[j];
             int chosen = 0, nxt = 0;
@@ -216,10 +232,14 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
                 if (rr < cc) { chosen = v; break; }
                 rr -= cc;
             }
-            db[d] = (uint8_t)chosen;
+            w |= (uint32_t)chosen << ((d & 3) * 8);
+            if ((d & 3) == 3) { dst[d >> 2] = w; w = 0; }
             j = nxt;
         }
-        for (int d = K; d < NW * 4; d++) db[d] = 0xFF;
+        for (; d < NW * 4; d++) {             // 0xFF padding behind the K nodes
+            w |= 0xFFu << ((d & 3) * 8);
+            if ((d & 3) == 3) { dst[d >> 2] = w; w = 0; }
+        }
     }
     g.sync();
     H.fits = 1; H.nB = (int32_t)nB; H.suf_words = (int32_t)suf_words; H.image_bytes = (int32_t)(4 * (dw + suf_words));

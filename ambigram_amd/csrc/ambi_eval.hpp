@@ -204,7 +204,8 @@ AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forwar
 // LGM.cpp:3661-3670: breakpoint pairs -> per-segment path (int16 local signed ids).  `offs` = scratch of
 // L/2+1 ints.  Returns P or a negative Status.
 template <class G>
-AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int pcap, int32_t* offs) {
+AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int pcap, int32_t* offs, int32_t* gpath = nullptr,
+                       int seg_base = 0) {
     int np = L / 2;
     int carry = 0;
     for (int base = 0; base < np; base += g.size()) {
@@ -224,15 +225,18 @@ AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int p
     if (g.tid() == 0) offs[np] = P;
     g.sync();
     if (P > pcap) return ST_ERR_PATH_CAPACITY;
-    for (int o = g.tid(); o < P; o += g.size()) {
-        int lo = 0, hi = np;   // last pair with offs[pair] <= o
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (offs[mid] <= o) lo = mid; else hi = mid; }
-        // pairs with zero length share an offset with their successor: take the last one that starts at <= o and
-        // actually covers o
-        while (lo + 1 < np && offs[lo + 1] <= o) lo++;
-        int a = bkp[2 * lo];
-        int k = o - offs[lo];
-        path[o] = (cell_t)(a > 0 ? a + k : a + k);   // '+' run counts up, '-' run: -(|a|-k) = a + k
+    // run-major: a sub-group of up to 64 threads (one wavefront on the GPU) writes the run of one pair; both the
+    // '+' run a, a+1, .. and the '-' run -|a|, -(|a|-1), .. are  a + k.  The absolute-id copy for the result blob
+    // (gpath, optional) leaves in the same pass.
+    const int lanes = g.size() < 64 ? g.size() : 64;
+    const int sub = g.tid() / lanes, nsub = g.size() / lanes, lane = g.tid() - sub * lanes;
+    for (int j = sub; j < np; j += nsub) {
+        const int a = bkp[2 * j], o0 = offs[j], len = offs[j + 1] - o0;
+        for (int k = lane; k < len; k += lanes) {
+            const int v = a + k;
+            path[o0 + k] = (cell_t)v;
+            if (gpath) gpath[o0 + k] = v > 0 ? v + seg_base : v - seg_base;
+        }
     }
     g.sync();
     return P;

@@ -101,20 +101,22 @@ AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const cell_t* path, int P,
 // "BFB path with insertion, deletion, or duplication:" caption (any qualifying SV exists), 0 otherwise,
 // negative Status on capacity errors.
 template <class G>
-AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* path, int* P_io, int pcap,
-                      const IndelScratch& S) {
+AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* path, int* P_io, int pcap,
+                      const IndelScratch& S, bool* edited = nullptr) {
     int P = *P_io;
+    if (edited) *edited = false;
     // -- qualifying SVs in junction order (LGM.cpp:3750-3759), compacted with a group scan
     int nsv = 0;
     for (int base = 0; base < m; base += g.size()) {
         int ji = base + g.tid();
         int q = 0;
         if (ji < m) {
-            const Junction& J = juncs[ji];
-            int s = J.src, t = J.tgt;
+            const JuncEnds E = ends[ji];
+            const int s = iabs(E.s), t = iabs(E.t);
+            const bool same = (E.s < 0) == (E.t < 0);
             bool in = !(s < 1 || s > n || t < 1 || t > n);
-            bool fbi = (J.sdir != J.tdir) && iabs(s - t) <= 2;
-            bool normal = (J.sdir == J.tdir) && ((J.sdir > 0 && t - s == 1) || (J.sdir < 0 && s - t == 1));
+            bool fbi = !same && iabs(s - t) <= 2;
+            bool normal = same && ((E.s > 0 && t - s == 1) || (E.s < 0 && s - t == 1));
             q = (in && !fbi && !normal) ? 1 : 0;
         }
         int tot;
@@ -125,16 +127,22 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
     g.sync();
     if (nsv == 0) return 0;
 
-    // -- which SVs could be chained onto by a LATER one (superset of what the deque chaining can do)
+    // -- which SVs could be chained onto by a LATER one (superset of what the deque chaining can do): SV j chains onto
+    // (front, back) when  a_tgt(j) == front, b_tgt(j) = -a_src(j) == front, a_src(j) == back or b_src(j) = -a_tgt(j)
+    // == back.  The occurrence tables (not yet in use) hold, per vertex, the LAST SV that has it as its a_src / a_tgt.
+    for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { S.first[i] = -1; S.last[i] = -1; }
+    g.sync();
     for (int i = g.tid(); i < nsv; i += g.size()) {
-        const Junction& Ji = juncs[S.sv[i]];
-        const int front = a_src(Ji), back = a_tgt(Ji);
-        int ext = 0;
-        for (int j = i + 1; j < nsv; j++) {
-            const Junction& J = juncs[S.sv[j]];
-            if (a_tgt(J) == front || b_tgt(J) == front || back == a_src(J) || back == b_src(J)) { ext = 1; break; }
-        }
-        S.has_ext[i] = (uint8_t)ext;
+        const JuncEnds E = ends[S.sv[i]];
+        atomic_max_i32(&S.first[E.s + n], i);   // by a_src
+        atomic_max_i32(&S.last[E.t + n], i);    // by a_tgt
+    }
+    g.sync();
+    for (int i = g.tid(); i < nsv; i += g.size()) {
+        const JuncEnds E = ends[S.sv[i]];
+        const int front = E.s, back = E.t;
+        const bool ext = S.last[front + n] > i || S.first[-front + n] > i || S.first[back + n] > i || S.last[-back + n] > i;
+        S.has_ext[i] = (uint8_t)(ext ? 1 : 0);
     }
     g.sync();
 
@@ -173,18 +181,19 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
         for (int i = f + g.tid(); i < nsv; i += g.size()) {
             if (S.taken[i]) continue;
             if (S.has_ext[i]) { stop = i; break; }
-            const Junction& J = juncs[S.sv[i]];
-            SingleEdit E = eval_single(a_src(J), a_tgt(J), n, path, P, S.first, S.last);
+            const JuncEnds J = ends[S.sv[i]];
+            SingleEdit E = eval_single(J.s, J.t, n, path, P, S.first, S.last);
             if (E.kind != 0) { stop = i; break; }
         }
         stop = g.min_i32(stop);
         if (stop == 0x7fffffff) break;
         if (!S.has_ext[stop]) {
-            const Junction& J = juncs[S.sv[stop]];
-            SingleEdit E = eval_single(a_src(J), a_tgt(J), n, path, P, S.first, S.last);   // uniform re-evaluation
+            const JuncEnds J = ends[S.sv[stop]];
+            SingleEdit E = eval_single(J.s, J.t, n, path, P, S.first, S.last);   // uniform re-evaluation
             g.sync();
             int rc = apply_single(E);
             if (rc < 0) { *P_io = P; return rc; }
+            if (edited) *edited = true;
             tables_ok = false;
             f = stop + 1;
             continue;
@@ -193,9 +202,9 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
         const int first = stop;
         int head = m + 2, tail = m + 2;
         {
-            const Junction& J = juncs[S.sv[first]];
+            const JuncEnds J = ends[S.sv[first]];
             g.sync();
-            if (g.tid() == 0) { S.grp[tail] = a_src(J); S.grp[tail + 1] = a_tgt(J); S.taken[first] = 1; }
+            if (g.tid() == 0) { S.grp[tail] = J.s; S.grp[tail + 1] = J.t; S.taken[first] = 1; }
             tail += 2;
             g.sync();
         }
@@ -205,18 +214,18 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
             int cand = 0x7fffffff;
             for (int i = cursor + g.tid(); i < nsv; i += g.size()) {
                 if (S.taken[i]) continue;
-                const Junction& J = juncs[S.sv[i]];
-                if (a_tgt(J) == front || b_tgt(J) == front || back == a_src(J) || back == b_src(J)) { cand = i; break; }
+                const JuncEnds J = ends[S.sv[i]];
+                if (J.t == front || -J.s == front || back == J.s || back == -J.t) { cand = i; break; }
             }
             cand = g.min_i32(cand);
             if (cand == 0x7fffffff) break;
-            const Junction& J = juncs[S.sv[cand]];
+            const JuncEnds J = ends[S.sv[cand]];
             int nf = head, nt = tail;
             int wpos = -1, wval = 0;
-            if (a_tgt(J) == front) { nf = head - 1; wpos = nf; wval = a_src(J); }
-            else if (b_tgt(J) == front) { nf = head - 1; wpos = nf; wval = b_src(J); }
-            else if (back == a_src(J)) { wpos = tail; wval = a_tgt(J); nt = tail + 1; }
-            else { wpos = tail; wval = b_tgt(J); nt = tail + 1; }
+            if (J.t == front) { nf = head - 1; wpos = nf; wval = J.s; }
+            else if (-J.s == front) { nf = head - 1; wpos = nf; wval = -J.t; }
+            else if (back == J.s) { wpos = tail; wval = J.t; nt = tail + 1; }
+            else { wpos = tail; wval = -J.s; nt = tail + 1; }
             g.sync();
             if (g.tid() == 0) { S.grp[wpos] = wval; S.taken[cand] = 1; }
             head = nf; tail = nt;
@@ -312,6 +321,7 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
             P += ins;
             g.sync();
         }
+        if (edited) *edited = true;   // reached only when the group was applied (the no-op exits `continue` above)
     }
     *P_io = P;
     return 1;
@@ -321,36 +331,67 @@ AMBI_HD int indel_bfb(const G& g, int n, const Junction* juncs, int m, cell_t* p
 // output junctions; a repeat (same edge or its complement edge) bumps the count.  First-appearance order.
 // cand = scratch of cand_cap ints.  Returns the number of output junctions or a negative Status.
 template <class G>
-AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out, int cap, int32_t* cand, int cand_cap) {
+AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out, int cap, int32_t* cand, int cand_cap, int seg_base) {
     if (P <= 0) return 0;
-    // each thread owns a contiguous slice of the path so that ONE group scan orders all junction steps
+    // every sub-group (wavefront) owns a contiguous slice of the path and walks it 64 cells at a time (conflict-free
+    // LDS reads, flags ranked by ballot without a barrier); ONE group scan over the sub-group totals orders all steps
     const int steps = P - 1;
-    const int per = (steps + g.size() - 1) / g.size();
-    const int lo = g.tid() * per, hi = lo + per < steps ? lo + per : steps;
+    const int ss = g.sub_size(), ns = g.n_subs(), lane = g.sub_lane();
+    const int per = ((steps + ns - 1) / ns + ss - 1) / ss * ss;
+    const int lo = g.sub_id() * per, hi = lo + per < steps ? lo + per : steps;
     auto is_step = [&](int i) {
         int u = path[i], v = path[i + 1];
         return !((iabs(iabs(u) - iabs(v)) == 1) && ((u > 0) == (v > 0)));
     };
-    int mine = 0;
-    for (int i = lo; i < hi; i++) mine += is_step(i) ? 1 : 0;
+    int mine = 0;   // steps of my sub-group's slice (the same number in all of its threads)
+    for (int i0 = lo; i0 < hi; i0 += ss) {
+        const int i = i0 + lane;
+        int cnt;
+        (void)g.flag_rank(i < hi && is_step(i), &cnt);
+        mine += cnt;
+    }
     int nc;
-    int at = g.exscan_i32(mine, &nc);
-    if (2 * nc > cand_cap) return ST_ERR_OUTJUNC_CAPACITY;
-    for (int i = lo; i < hi; i++) if (is_step(i)) cand[at++] = i;
+    int at = g.exscan_i32(lane == 0 ? mine : 0, &nc);
+    if (lane != 0) at -= mine;   // threads behind the sub-group's first one have its contribution in their prefix
+    if (3 * nc > cand_cap) return ST_ERR_OUTJUNC_CAPACITY;
+    for (int i0 = lo; i0 < hi; i0 += ss) {
+        const int i = i0 + lane;
+        const bool q = i < hi && is_step(i);
+        int cnt;
+        const int r = g.flag_rank(q, &cnt);
+        if (q) cand[at + r] = i;
+        at += cnt;
+    }
     g.sync();
     // A step joins the FIRST earlier step that is the same edge or its complement edge (the reference bumps that
     // entry's count, localhap.cpp:275-282); a record can never coexist with its complement, so classes are disjoint.
     int32_t* rep = cand + nc;      // [nc] representative (first occurrence) of every step, then its output slot
+    int32_t* key = cand + 2 * nc;  // [nc] canonical edge key: the smaller of (u,v) and its complement (-v,-u), packed
     for (int c = g.tid(); c < nc; c += g.size()) {
         const int u = path[cand[c]], v = path[cand[c] + 1];
+        const int32_t k1 = (int32_t)(((uint32_t)(u + 32768) << 16) | (uint32_t)(v + 32768));
+        const int32_t k2 = (int32_t)(((uint32_t)(-v + 32768) << 16) | (uint32_t)(-u + 32768));
+        key[c] = k1 < k2 ? k1 : k2;
+    }
+    g.sync();
+    for (int c = g.tid(); c < nc; c += g.size()) {
+        const int32_t mine_key = key[c];
         int r = c;
-        for (int k = 0; k < c; k++) {
-            const int a = path[cand[k]], b = path[cand[k] + 1];
-            if ((a == u && b == v) || (-b == u && -a == v)) { r = k; break; }
+        for (int k0 = 0; k0 < c; k0 += 8) {   // eight independent loads per round trip instead of one
+            int hit = c;
+#pragma unroll
+            for (int q = 7; q >= 0; q--) { const int k = k0 + q; if (k < c && key[k] == mine_key) hit = k; }
+            if (hit < c) { r = hit; break; }
         }
         rep[c] = r;
     }
     g.sync();
+    // class sizes in group memory (the key array is free now): every step bumps its representative's counter
+    for (int c = g.tid(); c < nc; c += g.size()) key[c] = 0;
+    g.sync();
+    for (int c = g.tid(); c < nc; c += g.size()) atomic_add_i32(&key[rep[c]], 1);
+    g.sync();
+    // leaders in first-appearance order -> finished records, one store each
     int nout = 0;
     for (int base = 0; base < nc; base += g.size()) {
         const int c = base + g.tid();
@@ -359,22 +400,12 @@ AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out,
         const int ex = g.exscan_i32(lead, &tot);
         if (lead && nout + ex < cap) {
             OutJunc& o = out[nout + ex];
-            o.u = path[cand[c]]; o.v = path[cand[c] + 1]; o.count = 1;
+            const int pu = path[cand[c]], pv = path[cand[c] + 1];   // local signed ids -> absolute
+            o.u = pu > 0 ? pu + seg_base : pu - seg_base; o.v = pv > 0 ? pv + seg_base : pv - seg_base; o.count = key[c];
         }
-        g.sync();
-        if (lead) rep[c] = -(nout + ex) - 1;   // leaders now carry their slot (encoded negative)
         nout += tot;
     }
-    g.sync();
     if (nout > cap) return ST_ERR_OUTJUNC_CAPACITY;
-    for (int c = g.tid(); c < nc; c += g.size()) {
-        const int r = rep[c];
-        if (r >= 0) {                       // follower: its leader's slot is stored in rep[r]
-            const int slot = -rep[r] - 1;
-            atomic_add_i32(&out[slot].count, 1);
-        }
-    }
-    g.sync();
     return nout;
 }
 

@@ -17,6 +17,15 @@
 
 namespace ambi {
 
+// atomic add on group or device memory, usable from both builds (the host simulation is single-threaded)
+AMBI_HD int atomic_add_i32(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    int old = *p; *p = old + v; return old;
+#endif
+}
+
 struct HostGroup {
     AMBI_HD int tid() const { return 0; }
     AMBI_HD int size() const { return 1; }
@@ -28,6 +37,13 @@ struct HostGroup {
     AMBI_HD int bcast_i32(int v, int /*src*/) const { return v; }
     // exclusive prefix sum over the group in thread order; total returned through *total
     AMBI_HD int exscan_i32(int v, int* total) const { *total = v; return 0; }
+    // sub-groups: runs of up to 64 consecutive threads (a wavefront on the GPU) that can rank flags without a barrier
+    AMBI_HD int sub_size() const { return 1; }
+    AMBI_HD int sub_id() const { return 0; }
+    AMBI_HD int n_subs() const { return 1; }
+    AMBI_HD int sub_lane() const { return 0; }
+    // number of set flags among the lower threads of my sub-group; *count = set flags in the whole sub-group
+    AMBI_HD int flag_rank(bool q, int* count) const { *count = q ? 1 : 0; return 0; }
 };
 
 #if defined(__HIPCC__)
@@ -52,19 +68,35 @@ struct WaveGroup {
         for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
         return v;
     }
-    __device__ inline int sum_i32(int v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+    // Inclusive prefix sum over the 64 lanes with DPP moves (VALU speed; the shuffle form costs six LDS-crossbar
+    // round trips): Hillis-Steele inside every row of 16 lanes (row_shr 1,2,4,8; lanes without a source add 0), then
+    // the last lane of row 0/2 into row 1/3 (row_bcast:15) and lane 31 into the upper half (row_bcast:31).
+    __device__ inline int incl_scan_i32(int v) const {
+        int x = v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+        return x;
     }
+    __device__ inline int sum_i32(int v) const { return __builtin_amdgcn_readlane(incl_scan_i32(v), 63); }
     __device__ inline bool any(bool p) const { return __ballot(p) != 0ull; }
     __device__ inline int bcast_i32(int v, int src) const { return __shfl(v, src, 64); }
     __device__ inline int exscan_i32(int v, int* total) const {
-        int x = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(x, o, 64); if (tid() >= o) x += t; }
-        *total = __shfl(x, 63, 64);
+        const int x = incl_scan_i32(v);
+        *total = __builtin_amdgcn_readlane(x, 63);
         return x - v;
+    }
+    __device__ inline int sub_size() const { return 64; }
+    __device__ inline int sub_id() const { return 0; }
+    __device__ inline int n_subs() const { return 1; }
+    __device__ inline int sub_lane() const { return tid(); }
+    __device__ inline int flag_rank(bool q, int* count) const {
+        const unsigned long long b = __ballot(q);
+        *count = __popcll(b);
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     }
 };
 
@@ -111,6 +143,11 @@ struct BlockGroup {
         *total = tot;
         return base + x;
     }
+    __device__ inline int sub_size() const { return 64; }
+    __device__ inline int sub_id() const { return (int)(threadIdx.x >> 6); }
+    __device__ inline int n_subs() const { return nwaves(); }
+    __device__ inline int sub_lane() const { return (int)(threadIdx.x & 63u); }
+    __device__ inline int flag_rank(bool q, int* count) const { WaveGroup w; return w.flag_rank(q, count); }
 };
 
 #endif  // __HIPCC__

@@ -38,27 +38,28 @@ AMBI_HD uint64_t atomic_cas_u64(uint64_t* p, uint64_t expected, uint64_t desired
     return old;
 #endif
 }
-AMBI_HD int atomic_add_i32(int* p, int v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(p, v);
-#else
-    int old = *p; *p = old + v; return old;
-#endif
-}
 
 AMBI_HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 AMBI_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
-// nodes that may be appended to the ideal I: not in I, all predecessors in I
+// nodes that may be appended to the ideal I: not in I, all predecessors in I.  Fixed trip count and addresses that do
+// not depend on the data, so the K loads of pred[] pipeline instead of forming a chain of dependent LDS round trips.
 AMBI_HD uint64_t avail_mask(const uint64_t* pred, int K, uint64_t I) {
-    uint64_t rem = ~I & (K >= 64 ? ~0ull : ((1ull << K) - 1));
-    uint64_t out = 0;
-    while (rem) {
-        int v = ctz64(rem);
-        rem &= rem - 1;
-        if ((pred[v] & ~I) == 0) out |= (1ull << v);
+    if (K <= 32) {
+        const uint32_t i32 = (uint32_t)I;
+        uint32_t o = 0;
+        int v = 0;
+        for (; v + 4 <= K; v += 4) {   // four loads in flight
+            const uint32_t p0 = (uint32_t)pred[v], p1 = (uint32_t)pred[v + 1], p2 = (uint32_t)pred[v + 2], p3 = (uint32_t)pred[v + 3];
+            o |= ((uint32_t)((p0 & ~i32) == 0) | ((uint32_t)((p1 & ~i32) == 0) << 1) | ((uint32_t)((p2 & ~i32) == 0) << 2) |
+                  ((uint32_t)((p3 & ~i32) == 0) << 3)) << v;
+        }
+        for (; v < K; v++) o |= (uint32_t)((((uint32_t)pred[v]) & ~i32) == 0) << v;
+        return (uint64_t)(o & ~i32);
     }
-    return out;
+    uint64_t out = 0;
+    for (int v = 0; v < K; v++) out |= (uint64_t)((pred[v] & ~I) == 0) << v;
+    return out & ~I;
 }
 
 AMBI_HD uint32_t hash_mask(uint64_t k) {
@@ -66,20 +67,28 @@ AMBI_HD uint32_t hash_mask(uint64_t k) {
     return (uint32_t)k;
 }
 
-// Ideal table of one unit (global memory).  Hash part: open addressing, capacity `cap` (power of two).
-// Automaton part: ideals numbered 0..nI-1 in discovery (level) order, 0 = empty ideal.
+// The frozen lattice of one unit (HBM): ideals numbered 0..nI-1 in discovery (level) order, 0 = empty ideal.
 struct IdealTable {
-    uint64_t* keys;      // [cap]    ideal masks, kEmptyKey = free
-    uint64_t* cnt;       // [cap]    completions of the ideal (by hash slot)
-    int32_t* pos;        // [cap]    hash slot -> ideal index
-    int32_t* lvl;        // [cap/2]  ideal index -> hash slot
-    int32_t* lvl_off;    // [kMaxNodes + 3]
+    int32_t* lvl_off;    // [kMaxNodes + 3]  first ideal index of every level (level = |ideal|)
     int32_t* counter;    // [2]      number of ideals, number of child links
     uint64_t* a_avail;   // [cap/2]  available-node mask per ideal index
     uint64_t* a_cnt;     // [cap/2]  completion count per ideal index
     int32_t* a_cbase;    // [cap/2+1] first child link per ideal index
     uint16_t* a_child;   // [child_cap] child ideal indices, ascending node order
     int cap, child_cap;
+};
+
+// Working memory of the lattice search (group-local memory for small lattices, HBM pools otherwise).
+struct LatticeWork {
+    uint64_t* keys;      // [cap]    open-addressing hash set of ideal masks, kEmptyKey = free
+    int32_t* pos;        // [cap]    hash slot -> ideal index
+    uint64_t* ikey;      // [cap/2]  ideal index -> mask
+    uint64_t* cnt;       // [cap/2]  completions by ideal index
+    int32_t* cbase;      // [cap/2+1]
+    uint32_t* link;      // [link_cap] child links: hash slots while searching, ideal indices afterwards
+    int32_t* lvl_off;    // [kMaxNodes + 3]
+    int32_t* counter;    // [2]
+    int cap, link_cap;
 };
 
 // read-only view of the automaton
@@ -92,134 +101,118 @@ struct AutoView {
 };
 AMBI_HD AutoView auto_view(const IdealTable& T) { return AutoView{T.a_avail, T.a_cnt, T.a_cbase, T.a_child, T.counter[0]}; }
 
-AMBI_HD int ideal_lookup(const IdealTable& T, uint64_t key) {
-    uint32_t h = hash_mask(key) & (uint32_t)(T.cap - 1);
-    for (int probe = 0; probe < T.cap; probe++) {
-        uint64_t k = T.keys[h];
-        if (k == key) return (int)h;
-        if (k == kEmptyKey) return -1;
-        h = (h + 1) & (uint32_t)(T.cap - 1);
-    }
-    return -1;
-}
-
 // returns slot; *fresh = true when this call inserted the key
-AMBI_HD int ideal_insert(const IdealTable& T, uint64_t key, bool* fresh) {
-    uint32_t h = hash_mask(key) & (uint32_t)(T.cap - 1);
+AMBI_HD int ideal_insert(const LatticeWork& W, uint64_t key, bool* fresh) {
+    uint32_t h = hash_mask(key) & (uint32_t)(W.cap - 1);
     *fresh = false;
-    for (int probe = 0; probe < T.cap; probe++) {
-        uint64_t k = T.keys[h];
+    for (int probe = 0; probe < W.cap; probe++) {
+        uint64_t k = W.keys[h];
         if (k == key) return (int)h;
         if (k == kEmptyKey) {
-            uint64_t old = atomic_cas_u64(&T.keys[h], kEmptyKey, key);
+            uint64_t old = atomic_cas_u64(&W.keys[h], kEmptyKey, key);
             if (old == kEmptyKey) { *fresh = true; return (int)h; }
             if (old == key) return (int)h;
         }
-        h = (h + 1) & (uint32_t)(T.cap - 1);
+        h = (h + 1) & (uint32_t)(W.cap - 1);
     }
     return -1;
 }
 
-// Level-synchronous frontier expansion over the ideal lattice + backward count + automaton.  SPMD over group g.
+// Level-synchronous search over the ideal lattice, backward count, frozen automaton.  SPMD over group g.
+//   search   : one thread per ideal of the current level: available nodes, one hash insert per child; the child's
+//              hash slot is parked in the link array (child links of the level are laid out by a group prefix sum,
+//              so link order = ideal order = the automaton's final order);
+//   resolve  : every link slot -> ideal index (one parallel pass once all indices are assigned);
+//   count    : cnt[I] = sum of cnt over I's links, deepest level first (no hashing);
+//   freeze   : counts, child bases and 16-bit child indices to the table in HBM.
 // Returns status; *R_out = number of topological orders (saturated at 2^62).
 template <class G>
-AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const IdealTable& T, uint64_t* R_out) {
-    const int maxIdeals = T.cap / 2;
-    for (int i = g.tid(); i < T.cap; i += g.size()) { T.keys[i] = kEmptyKey; T.cnt[i] = 0; }
+AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const LatticeWork& W, const IdealTable& T, uint64_t* R_out) {
+    int maxIdeals = W.cap / 2;
+    if (maxIdeals > 65535) maxIdeals = 65535;
+    for (int i = g.tid(); i < W.cap; i += g.size()) W.keys[i] = kEmptyKey;
     g.sync();
     if (g.tid() == 0) {
         bool fresh;
-        int s = ideal_insert(T, 0ull, &fresh);
-        T.lvl[0] = s; T.pos[s] = 0; T.lvl_off[0] = 0; T.lvl_off[1] = 1; T.counter[0] = 1; T.counter[1] = 0;
+        int s = ideal_insert(W, 0ull, &fresh);
+        W.pos[s] = 0; W.ikey[0] = 0ull; W.lvl_off[0] = 0; W.lvl_off[1] = 1; W.counter[0] = 1; W.counter[1] = 0;
     }
     g.sync();
-    int overflow = 0;
-    int last_level = 0;
-    for (int d = 0; d < K; d++) {
-        int lo = T.lvl_off[d], hi = T.lvl_off[d + 1];
+    int overflow = 0, last_level = 0, links = 0;
+    for (int d = 0; d <= K; d++) {
+        const int lo = W.lvl_off[d], hi = W.lvl_off[d + 1];
         if (hi == lo) break;
-        for (int idx = lo + g.tid(); idx < hi; idx += g.size()) {
-            uint64_t I = T.keys[T.lvl[idx]];
-            uint64_t av = avail_mask(pred, K, I);
-            while (av) {
-                int v = ctz64(av);
-                av &= av - 1;
-                bool fresh;
-                int s = ideal_insert(T, I | (1ull << v), &fresh);
-                if (s < 0) { overflow = 1; break; }
-                if (fresh) {
-                    int p = atomic_add_i32(T.counter, 1);
-                    if (p >= maxIdeals || p >= 65535) { overflow = 1; break; }
-                    T.lvl[p] = s;
-                    T.pos[s] = p;
+        for (int base = lo; base < hi; base += g.size()) {
+            const int idx = base + g.tid();
+            uint64_t I = 0, av = 0;
+            int nch = 0;
+            if (idx < hi) {
+                I = W.ikey[idx];
+                av = avail_mask(pred, K, I);
+                W.cnt[idx] = av;   // parked here until the search is over (no store to HBM inside the level loop)
+                nch = popc64(av);
+            }
+            int tot;
+            const int ex = g.exscan_i32(nch, &tot);
+            if (idx < hi) {
+                int k = links + ex;
+                W.cbase[idx] = k;
+                if (k + nch > W.link_cap) overflow = 1;
+                else {
+                    while (av) {
+                        const int v = ctz64(av);
+                        av &= av - 1;
+                        bool fresh;
+                        const uint64_t child = I | (1ull << v);
+                        const int s = ideal_insert(W, child, &fresh);
+                        if (s < 0) { overflow = 1; break; }
+                        if (fresh) {
+                            const int p = atomic_add_i32(W.counter, 1);
+                            if (p >= maxIdeals) { overflow = 1; break; }
+                            W.ikey[p] = child;
+                            W.pos[s] = p;
+                        }
+                        W.link[k++] = (uint32_t)s;
+                    }
                 }
             }
+            links += tot;
         }
         g.sync();
         if (g.any(overflow != 0)) return ST_ERR_IDEALS_CAPACITY;
-        if (g.tid() == 0) T.lvl_off[d + 2] = T.counter[0];
+        if (g.tid() == 0) W.lvl_off[d + 2] = W.counter[0];
         g.sync();
         last_level = d + 1;
     }
-    // backward count.  Level K holds the single full ideal when the relation is acyclic.
-    const uint64_t full = (K >= 64) ? ~0ull : ((1ull << K) - 1);
-    if (last_level == K) {
-        int sfull = ideal_lookup(T, full);
-        if (g.tid() == 0 && sfull >= 0) T.cnt[sfull] = 1;
-    }
+    const int nI = W.counter[0];
+    if (links > T.child_cap) return ST_ERR_IDEALS_CAPACITY;
+    if (g.tid() == 0) { W.cbase[nI] = links; W.counter[1] = links; }
+    for (int k = g.tid(); k < links; k += g.size()) W.link[k] = (uint32_t)W.pos[W.link[k]];
+    for (int p = g.tid(); p < nI; p += g.size()) T.a_avail[p] = W.cnt[p];
     g.sync();
+    // backward count.  The full ideal (level K, present when the relation is acyclic) has one completion: itself.
+    const uint64_t full = (K >= 64) ? ~0ull : ((1ull << K) - 1);
     for (int d = last_level - 1; d >= 0; d--) {
-        int lo = T.lvl_off[d], hi = T.lvl_off[d + 1];
+        const int lo = W.lvl_off[d], hi = W.lvl_off[d + 1];
         for (int idx = lo + g.tid(); idx < hi; idx += g.size()) {
-            int slot = T.lvl[idx];
-            uint64_t I = T.keys[slot];
-            if (I == full) continue;
-            uint64_t av = avail_mask(pred, K, I);
             uint64_t c = 0;
-            while (av) {
-                int v = ctz64(av);
-                av &= av - 1;
-                int s = ideal_lookup(T, I | (1ull << v));
-                if (s >= 0) { c += T.cnt[s]; if (c > kCountSat) c = kCountSat; }
+            if (W.ikey[idx] == full) c = 1;
+            else {
+                const int k1 = W.cbase[idx + 1];
+                for (int k = W.cbase[idx]; k < k1; k++) { c += W.cnt[W.link[k]]; if (c > kCountSat) c = kCountSat; }
             }
-            T.cnt[slot] = c;
+            W.cnt[idx] = c;
         }
         g.sync();
     }
-    // automaton: avail / count / child links per ideal index
-    const int nI = T.counter[0];
-    int carry = 0;
-    for (int base = 0; base < nI; base += g.size()) {
-        int p = base + g.tid();
-        int nch = 0;
-        if (p < nI) {
-            int slot = T.lvl[p];
-            uint64_t av = avail_mask(pred, K, T.keys[slot]);
-            T.a_avail[p] = av;
-            T.a_cnt[p] = T.cnt[slot];
-            nch = popc64(av);
-        }
-        int tot;
-        int ex = g.exscan_i32(nch, &tot);
-        if (p < nI) T.a_cbase[p] = carry + ex;
-        carry += tot;
-    }
-    if (g.tid() == 0) { T.a_cbase[nI] = carry; T.counter[1] = carry; }
+    // freeze
+    for (int p = g.tid(); p < nI; p += g.size()) T.a_cnt[p] = W.cnt[p];
+    if (T.a_cbase != W.cbase) for (int p = g.tid(); p <= nI; p += g.size()) T.a_cbase[p] = W.cbase[p];
+    for (int k = g.tid(); k < links; k += g.size()) T.a_child[k] = (uint16_t)W.link[k];
+    for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) T.lvl_off[d] = (d <= last_level + 1) ? W.lvl_off[d] : nI;
+    for (int t = g.tid(); t < 2; t += g.size()) T.counter[t] = t == 0 ? nI : links;
+    *R_out = W.cnt[0];
     g.sync();
-    if (carry > T.child_cap) return ST_ERR_IDEALS_CAPACITY;
-    for (int p = g.tid(); p < nI; p += g.size()) {
-        uint64_t I = T.keys[T.lvl[p]];
-        uint64_t av = T.a_avail[p];
-        int k = T.a_cbase[p];
-        while (av) {
-            int v = ctz64(av);
-            av &= av - 1;
-            int s = ideal_lookup(T, I | (1ull << v));
-            T.a_child[k++] = (uint16_t)(s >= 0 ? T.pos[s] : 0);
-        }
-    }
-    g.sync();
-    *R_out = T.a_cnt[0];
     return ST_OK;
 }
 

@@ -29,36 +29,6 @@ AMBI_HD int atomic_inc_i32(int* p) {
     int o = *p; *p = o + 1; return o;
 #endif
 }
-
-// ---- serial forms (one thread); the group forms below fall back to them where order matters ----
-
-// LGM.cpp:3989-4050  getJuncCN.  junc_cn is (n+1) x 2 (row 0 unused), inv_junc[n+1] = junction index or -1.
-AMBI_HD void get_junc_cn(int n, const Junction* juncs, int m, double* junc_cn, int32_t* inv_junc) {
-    for (int i = 0; i <= n; i++) { junc_cn[2 * i] = 0.0; junc_cn[2 * i + 1] = 0.0; inv_junc[i] = -1; }
-    for (int ji = 0; ji < m; ji++) {
-        const Junction& J = juncs[ji];
-        int s = J.src, t = J.tgt;
-        if (s < 1 || s > n || t < 1 || t > n) continue;
-        double cn = J.cn;
-        if (0.5 < cn && cn < 1) cn = 1;
-        if (J.sdir == J.tdir) {
-            if (s + 1 == t) junc_cn[2 * s] += cn;
-            else if (s - 1 == t) junc_cn[2 * t] += cn;
-        } else if (iabs(s - t) <= 2) {
-            if (inv_junc[s] < 0) { inv_junc[s] = ji; junc_cn[2 * s + 1] += cn; }
-            else if (inv_junc[t] < 0) { inv_junc[t] = ji; junc_cn[2 * t + 1] += cn; }
-        }
-    }
-    for (int ji = 0; ji < m; ji++) {   // LGM.cpp:4043-4049
-        const Junction& J = juncs[ji];
-        int s = J.src, t = J.tgt;
-        if (s < 1 || s > n || t < 1 || t > n) continue;
-        if (J.sdir == J.tdir || iabs(s - t) > 2) continue;
-        if (inv_junc[s] < 0) inv_junc[s] = ji;
-        if (inv_junc[t] < 0) inv_junc[t] = ji;
-    }
-}
-
 // localhap.cpp:150-153: sum of fold-back CN (the no-FBI shortcut test at :164), in the reference's order
 AMBI_HD double inversion_cn_sum(int n, const double* junc_cn) {
     double s = 0;
@@ -66,76 +36,83 @@ AMBI_HD double inversion_cn_sum(int n, const double* junc_cn) {
     return s;
 }
 
-// ---- group forms ----
+// the reference's rounding of junction copy numbers (LGM.cpp:4003-4004)
+AMBI_HD double junc_cn_round(double cn) { return (0.5 < cn && cn < 1) ? 1.0 : cn; }
 
-// getJuncCN.  slot_cnt: [n+1] ints, fb: [m] ints (fold-back junction list).
+// LGM.cpp:3989-4050 getJuncCN.  junc_cn is (n+1) x 2 (row 0 unused), inv_junc[n+1] = junction index or -1.
+// slot_cnt: [n+1] ints, fb: [m] ints (fold-back junction list).  Junction ends come from group memory, the copy
+// numbers from the records in HBM (each is read once, by the thread that owns the junction / the slot).
 template <class G>
-AMBI_HD void get_junc_cn_g(const G& g, int n, const Junction* juncs, int m, double* junc_cn, int32_t* inv_junc,
+AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* junc_cn, int32_t* inv_junc,
                            int32_t* slot_cnt, int32_t* fb) {
     for (int i = g.tid(); i <= n; i += g.size()) { junc_cn[2 * i] = 0.0; junc_cn[2 * i + 1] = 0.0; inv_junc[i] = -1; slot_cnt[i] = 0; }
     g.sync();
-    // normal (reference-adjacent) junctions: which slot, and does any slot get two of them?
-    for (int ji = g.tid(); ji < m; ji += g.size()) {
-        const Junction& J = juncs[ji];
-        int s = J.src, t = J.tgt;
-        if (s < 1 || s > n || t < 1 || t > n || J.sdir != J.tdir) continue;
-        if (s + 1 == t) atomic_inc_i32(&slot_cnt[s]);
-        else if (s - 1 == t) atomic_inc_i32(&slot_cnt[t]);
+    // one pass over the junctions: normal (reference-adjacent) ones count into their slot, fold-backs are compacted
+    // in junction order
+    int nfb = 0;
+    for (int base = 0; base < m; base += g.size()) {
+        const int ji = base + g.tid();
+        int q = 0;
+        if (ji < m) {
+            const JuncEnds E = J.e[ji];
+            const int s = iabs(E.s), t = iabs(E.t);
+            const bool same = (E.s < 0) == (E.t < 0);
+            if (!(s < 1 || s > n || t < 1 || t > n)) {
+                if (same) {
+                    if (s + 1 == t) atomic_inc_i32(&slot_cnt[s]);
+                    else if (s - 1 == t) atomic_inc_i32(&slot_cnt[t]);
+                } else if (iabs(s - t) <= 2) q = 1;
+            }
+        }
+        int tot;
+        const int ex = g.exscan_i32(q, &tot);
+        if (q) fb[nfb + ex] = ji;
+        nfb += tot;
     }
     g.sync();
+    // does any slot get two normal junctions?  (f64 accumulation order matters only then)
     int multi = 0;
     for (int i = g.tid(); i <= n; i += g.size()) multi |= (slot_cnt[i] > 1);
     const bool serial_normal = g.any(multi != 0);
     if (!serial_normal) {
         for (int ji = g.tid(); ji < m; ji += g.size()) {
-            const Junction& J = juncs[ji];
-            int s = J.src, t = J.tgt;
-            if (s < 1 || s > n || t < 1 || t > n || J.sdir != J.tdir) continue;
-            double cn = J.cn;
-            if (0.5 < cn && cn < 1) cn = 1;
-            if (s + 1 == t) junc_cn[2 * s] = 0.0 + cn;
-            else if (s - 1 == t) junc_cn[2 * t] = 0.0 + cn;
+            const JuncEnds E = J.e[ji];
+            const int s = iabs(E.s), t = iabs(E.t);
+            if (s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0)) continue;
+            if (s + 1 == t) junc_cn[2 * s] = 0.0 + junc_cn_round(J.full[ji].cn);
+            else if (s - 1 == t) junc_cn[2 * t] = 0.0 + junc_cn_round(J.full[ji].cn);
         }
     } else if (g.tid() == 0) {
         for (int ji = 0; ji < m; ji++) {
-            const Junction& J = juncs[ji];
-            int s = J.src, t = J.tgt;
-            if (s < 1 || s > n || t < 1 || t > n || J.sdir != J.tdir) continue;
-            double cn = J.cn;
-            if (0.5 < cn && cn < 1) cn = 1;
-            if (s + 1 == t) junc_cn[2 * s] += cn;
-            else if (s - 1 == t) junc_cn[2 * t] += cn;
+            const JuncEnds E = J.e[ji];
+            const int s = iabs(E.s), t = iabs(E.t);
+            if (s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0)) continue;
+            if (s + 1 == t) junc_cn[2 * s] += junc_cn_round(J.full[ji].cn);
+            else if (s - 1 == t) junc_cn[2 * t] += junc_cn_round(J.full[ji].cn);
         }
     }
-    // fold-back junctions, compacted in junction order; the first-come claims stay serial (LGM.cpp:4012-4049)
-    int nfb = 0;
-    for (int base = 0; base < m; base += g.size()) {
-        int ji = base + g.tid();
-        int q = 0;
-        if (ji < m) {
-            const Junction& J = juncs[ji];
-            int s = J.src, t = J.tgt;
-            q = (!(s < 1 || s > n || t < 1 || t > n) && J.sdir != J.tdir && iabs(s - t) <= 2) ? 1 : 0;
-        }
-        int tot;
-        int ex = g.exscan_i32(q, &tot);
-        if (q) fb[nfb + ex] = ji;
-        nfb += tot;
-    }
-    g.sync();
+    // fold-back claims are first come first served (LGM.cpp:4012-4041): serial over the compacted list.  A slot is
+    // claimed at most once, so its copy number is 0 + cn of the claiming junction: assigned in parallel afterwards.
     if (g.tid() == 0) {
         for (int k = 0; k < nfb; k++) {
-            const Junction& J = juncs[fb[k]];
-            int s = J.src, t = J.tgt;
-            double cn = J.cn;
-            if (0.5 < cn && cn < 1) cn = 1;
-            if (inv_junc[s] < 0) { inv_junc[s] = fb[k]; junc_cn[2 * s + 1] += cn; }
-            else if (inv_junc[t] < 0) { inv_junc[t] = fb[k]; junc_cn[2 * t + 1] += cn; }
+            const JuncEnds E = J.e[fb[k]];
+            const int s = iabs(E.s), t = iabs(E.t);
+            if (inv_junc[s] < 0) inv_junc[s] = fb[k];
+            else if (inv_junc[t] < 0) inv_junc[t] = fb[k];
         }
+    }
+    g.sync();
+    for (int i = g.tid(); i <= n; i += g.size()) {
+        const int ji = inv_junc[i];
+        if (ji >= 0) junc_cn[2 * i + 1] = 0.0 + junc_cn_round(J.full[ji].cn);
+    }
+    g.sync();
+    if (g.tid() == 0) {   // LGM.cpp:4043-4049: remaining ends point at their junction, no copy number
         for (int k = 0; k < nfb; k++) {
-            const Junction& J = juncs[fb[k]];
-            if (inv_junc[J.src] < 0) inv_junc[J.src] = fb[k];
-            if (inv_junc[J.tgt] < 0) inv_junc[J.tgt] = fb[k];
+            const JuncEnds E = J.e[fb[k]];
+            const int s = iabs(E.s), t = iabs(E.t);
+            if (inv_junc[s] < 0) inv_junc[s] = fb[k];
+            if (inv_junc[t] < 0) inv_junc[t] = fb[k];
         }
     }
     g.sync();
@@ -143,12 +120,12 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const Junction* juncs, int m, doub
 
 // localhap.cpp:141-146
 template <class G>
-AMBI_HD int compute_bias_g(const G& g, int n, const Junction* juncs, const double* junc_cn, const int32_t* inv_junc) {
+AMBI_HD int compute_bias_g(const G& g, int n, const JuncView& J, const double* junc_cn, const int32_t* inv_junc) {
     int part = 0;
     for (int i = 1 + g.tid(); i <= n; i += g.size()) {
         if (junc_cn[2 * i + 1] > 0) {
-            int ji = inv_junc[i];
-            if (ji >= 0 && juncs[ji].src != juncs[ji].tgt) part += int(junc_cn[2 * i + 1]) % 2;
+            const int ji = inv_junc[i];
+            if (ji >= 0) { const JuncEnds E = J.e[ji]; if (iabs(E.s) != iabs(E.t)) part += int(junc_cn[2 * i + 1]) % 2; }
         }
     }
     return 1 + g.sum_i32(part);
@@ -174,18 +151,19 @@ AMBI_HD bool no_foldback_g(const G& g, int n, const double* junc_cn, double* sum
 
 // LGM.cpp:3699-3744 getIndelBias.  sv: [m] ints, taken: [m] bytes, grp: [2m+4] ints.  Mutates seg_cn[1..n].
 template <class G>
-AMBI_HD void get_indel_bias_g(const G& g, int n, const Junction* juncs, int m, double* seg_cn, int32_t* sv, uint8_t* taken,
+AMBI_HD void get_indel_bias_g(const G& g, int n, const JuncView& J, int m, double* seg_cn, int32_t* sv, uint8_t* taken,
                               int32_t* grp) {
     int nsv = 0;
     for (int base = 0; base < m; base += g.size()) {
         int ji = base + g.tid();
         int q = 0;
         if (ji < m) {
-            const Junction& J = juncs[ji];
-            int s = J.src, t = J.tgt;
+            const JuncEnds E = J.e[ji];
+            const int s = iabs(E.s), t = iabs(E.t);
             bool in = !(s < 1 || s > n || t < 1 || t > n);
-            bool normal = (J.sdir > 0 && t - s == 1) || (J.sdir < 0 && s - t == 1);
-            q = (in && J.sdir == J.tdir && !normal) ? 1 : 0;
+            bool same = (E.s < 0) == (E.t < 0);
+            bool normal = (E.s > 0 && t - s == 1) || (E.s < 0 && s - t == 1);
+            q = (in && same && !normal) ? 1 : 0;
         }
         int tot;
         int ex = g.exscan_i32(q, &tot);
@@ -193,8 +171,8 @@ AMBI_HD void get_indel_bias_g(const G& g, int n, const Junction* juncs, int m, d
         nsv += tot;
     }
     g.sync();
-    auto vs = [&](int i) { const Junction& J = juncs[sv[i]]; return J.sdir < 0 ? -J.src : J.src; };
-    auto vt = [&](int i) { const Junction& J = juncs[sv[i]]; return J.tdir < 0 ? -J.tgt : J.tgt; };
+    auto vs = [&](int i) { return (int)J.e[sv[i]].s; };
+    auto vt = [&](int i) { return (int)J.e[sv[i]].t; };
     for (int first = 0; first < nsv; first++) {
         if (taken[first]) continue;
         int head = m + 2, tail = m + 2;
@@ -239,15 +217,32 @@ AMBI_HD void get_indel_bias_g(const G& g, int n, const Junction* juncs, int m, d
     }
 }
 
-// localhap.cpp:222-232.  target_cn[0..n] (local ids)
+// localhap.cpp:222-232.  target_cn[0..n] (local ids): integer adds, so a difference array + running sum gives the
+// reference's numbers in any order.  diff: [n+2] ints of group memory (may not alias target_cn).
 template <class G>
-AMBI_HD void target_cn_g(const G& g, const Element* el, int K, int n, int32_t* target_cn) {
-    for (int i = g.tid(); i <= n; i += g.size()) {
-        int acc = 0;
-        for (int e = 0; e < K; e++)
-            if (el[e].cn > 0 && i >= 1 && el[e].a <= i && i <= el[e].b) acc += el[e].is_loop ? el[e].cn * 2 : el[e].cn;
-        target_cn[i] = acc;
+AMBI_HD void target_cn_g(const G& g, const Element* el, int K, int n, int32_t* target_cn, int32_t* diff) {
+    for (int i = g.tid(); i <= n + 1; i += g.size()) diff[i] = 0;
+    g.sync();
+    for (int e = g.tid(); e < K; e += g.size()) {
+        const Element E = el[e];
+        if (E.cn <= 0) continue;
+        const int lo = E.a < 1 ? 1 : E.a, hi = E.b > n ? n : E.b;
+        if (lo > hi) continue;
+        const int w = E.is_loop ? E.cn * 2 : E.cn;
+        atomic_add_i32(&diff[lo], w);
+        atomic_add_i32(&diff[hi + 1], -w);
     }
+    g.sync();
+    int carry = 0;
+    for (int base = 0; base <= n; base += g.size()) {
+        const int i = base + g.tid();
+        const int v = i <= n ? diff[i] : 0;
+        int tot;
+        const int ex = g.exscan_i32(v, &tot);
+        if (i <= n) target_cn[i] = carry + ex + v;
+        carry += tot;
+    }
+    g.sync();
 }
 
 // ---- std::map<std::string,int> iteration order of the keys "p:A,B" / "l:A,B" (localhap.cpp:122-133) ----
@@ -261,6 +256,14 @@ AMBI_HD int dec_str_cmp(uint32_t x, uint32_t y) {   // <0, 0, >0
     for (int i = dy; i < dx; i++) b *= 10;
     if (a != b) return a < b ? -1 : 1;
     return dx - dy;
+}
+// the same order as one integer per number: the value zero-padded to ten digits, then the digit count
+AMBI_HD uint64_t dec_key(uint32_t x) {
+    const int d = 1 + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) +
+                  (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
+    uint64_t v = x;
+    for (int i = d; i < 10; i++) v *= 10;
+    return (v << 4) | (uint64_t)d;
 }
 // std::string operator< on the two keys (A,B are ABSOLUTE segment ids)
 AMBI_HD bool key_less(int l1, int A1, int B1, int l2, int A2, int B2) {
@@ -282,13 +285,26 @@ struct DagScratch {
 template <class G>
 AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, Dag& D, const DagScratch& W) {
     if (K > kMaxNodes) return ST_ERR_TOO_MANY_NODES;
-    // node numbering = rank of the key in std::map order
+    // node numbering = rank of the key in std::map order.  Every element's two decimal keys are computed once and
+    // parked in D.succ / D.pred (initialised further down); the K x K comparison loop then only compares integers.
     for (int i = g.tid(); i < K; i += g.size()) {
+        D.succ[i] = dec_key((uint32_t)(el[i].a + seg_base));
+        D.pred[i] = dec_key((uint32_t)(el[i].b + seg_base));
+    }
+    g.sync();
+    for (int i = g.tid(); i < K; i += g.size()) {
+        const int li = el[i].is_loop;
+        const uint64_t ka = D.succ[i], kb = D.pred[i];
         int r = 0;
-        for (int j = 0; j < K; j++)
-            if (j != i && key_less(el[j].is_loop, el[j].a + seg_base, el[j].b + seg_base, el[i].is_loop, el[i].a + seg_base, el[i].b + seg_base)) r++;
+        for (int j = 0; j < K; j++) {
+            const int lj = el[j].is_loop;
+            const uint64_t ja = D.succ[j], jb = D.pred[j];
+            const bool less = (lj != li) ? (lj > li) : ((ja != ka) ? (ja < ka) : (jb < kb));   // key_less(j, i)
+            r += (j != i && less) ? 1 : 0;
+        }
         W.idx[r] = i;
     }
+    g.sync();
     if (g.tid() == 0) D.K = K;
     g.sync();
     for (int i = g.tid(); i < K; i += g.size()) {
@@ -306,7 +322,7 @@ AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, 
     int ub = 0;
     if (g.tid() == 0) {
         bool u = false;
-        libstdcxx_sort_loops(W.loops, K, &u);   // LGM.cpp:3303
+        libstdcxx_sort_loops(W.loops, K, &u, reinterpret_cast<uint32_t*>(W.idx));   // LGM.cpp:3303 (idx is free by now)
         ub = u ? 1 : 0;
     }
     ub = g.bcast_i32(ub, 0);

@@ -142,21 +142,24 @@ AMBI_HD int floor_lg(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return 
 
 }  // namespace sortdetail
 
-// std::sort(a, a+n, compareLoops)
-AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub) {
+// std::sort(a, a+n, compareLoops), n <= 1023.  `stack`: kSortStack words of caller memory (group memory on the GPU: a
+// private array indexed at run time would live in scratch, i.e. in HBM) for the parked left parts: one packed word
+// { first : 10, last : 10, depth : 12 } each.  The parked parts have strictly increasing depth budgets from the top of
+// the stack down, so 2*floor(log2 n) + 1 <= 19 words suffice.
+constexpr int kSortStack = 24;
+AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub, uint32_t* stack) {
     using namespace sortdetail;
     SortCtx c{a, n, false};
+    if (n > 1023) { if (ub) *ub = true; return; }
     if (n > 0) {
         // __introsort_loop.  The library recurses on the RIGHT part [cut,last) first and afterwards loops on the
         // left part [first,cut) with the same (already decremented) depth; the explicit stack below keeps exactly
         // that processing order: the left part is parked, the right part is handled at once.
-        struct Frame { int first, last, depth; };
-        Frame stack[64];
         int sp = 0;
-        stack[sp++] = Frame{0, n, floor_lg(n) * 2};
+        stack[sp++] = 0u | ((uint32_t)n << 10) | ((uint32_t)(floor_lg(n) * 2) << 20);
         while (sp > 0 && !c.ub) {
-            Frame f = stack[--sp];
-            int first = f.first, last = f.last, depth = f.depth;
+            const uint32_t f = stack[--sp];
+            int first = (int)(f & 1023u), last = (int)((f >> 10) & 1023u), depth = (int)(f >> 20);
             while (last - first > 16) {
                 if (depth == 0) { heap_sort_range(c, first, last); break; }
                 --depth;
@@ -164,7 +167,7 @@ AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub) {
                 move_median_to_first(c, first, first + 1, mid, last - 1);
                 int cut = unguarded_partition(c, first + 1, last, first);
                 if (c.ub) break;
-                if (sp < 64) stack[sp++] = Frame{first, cut, depth};   // left part, resumed after the right part
+                if (sp < kSortStack) stack[sp++] = (uint32_t)first | ((uint32_t)cut << 10) | ((uint32_t)depth << 20);   // left part, resumed after the right part
                 first = cut;
             }
         }

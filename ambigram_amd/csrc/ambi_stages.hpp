@@ -21,49 +21,77 @@ namespace ambi {
 // ---------------------------------------------------------------------------------------------
 // stage_prepare
 // ---------------------------------------------------------------------------------------------
-struct PrepareWork {      // group-local memory (LDS on the GPU)
-    Junction* juncs;      // [m]
+// Group-local memory (LDS on the GPU).  The junction-phase arrays are dead once their results have been copied to
+// the result blob, so the lattice search re-uses their bytes: footprint = persistent part + max(junction phase, lattice).
+struct PrepareWork {
+    // persistent
+    Dag* dag;
+    Element* elems;       // [K]
+    int32_t* idx;         // [64]   node order
+    Rec3* loops;          // [64]   records permuted by the library sort
+    int32_t* target_cn;   // [n+1]
+    // junction phase
+    JuncEnds* ends;       // [m]    strand-signed junction ends (the 24-byte records stay in HBM)
     double* seg_cn;       // [n+1]
     double* junc_cn;      // [2(n+1)]
     int32_t* inv_junc;    // [n+1]
-    int32_t* target_cn;   // [n+1]
-    Element* elems;       // [K]
-    Dag* dag;
-    int32_t* slot_cnt;    // [n+1]  contributions per normal-junction slot
+    int32_t* slot_cnt;    // [n+2]  contributions per normal-junction slot; later the target-CN difference array
     int32_t* fb;          // [m]    fold-back junction list
     int32_t* sv;          // [m]    getIndelBias SV list
-    int32_t* idx;         // [64]   node order
-    Rec3* loops;          // [64]   records permuted by the library sort
     uint8_t* taken;       // [m]
-    uint8_t* hash_mem;    // [kPrepHashBytes] group-local order-ideal hash (fast path of the lattice build)
+    // lattice phase (same bytes as the junction phase)
+    uint8_t* lattice_mem; // [kPrepLatticeBytes]
 };
-// Group-local hash for the ideal lattice: kPrepHashSlots slots (keys u64, cnt u64, pos i32), a level list of
-// kPrepHashSlots/2 ideals, level offsets and the two counters.  Lattices with more ideals use the table in HBM.
-constexpr int kPrepHashSlots = 1024;
-constexpr int64_t kPrepHashBytes = 8ll * kPrepHashSlots * 2 + 4ll * kPrepHashSlots + 4ll * (kPrepHashSlots / 2) + 4ll * (kMaxNodes + 3) + 16;
+// Group-local lattice search: kPrepHashSlots hash slots (at most half as many ideals) and kPrepLinks child links;
+// lattices that need more use the pools in HBM.
+constexpr int kPrepHashSlots = 512;
+constexpr int kPrepLinks = 768;
+constexpr int64_t kPrepLatticeBytes = 8ll * kPrepHashSlots /*keys*/ + 4ll * kPrepHashSlots /*pos*/ + 8ll * (kPrepHashSlots / 2) /*ikey*/ +
+                                      8ll * (kPrepHashSlots / 2) /*cnt*/ + 4ll * (kPrepHashSlots / 2 + 2) /*cbase*/ + 4ll * kPrepLinks +
+                                      4ll * (kMaxNodes + 3) + 16;
+AMBI_HD int64_t prepare_persistent_bytes(int n, int K) {
+    return pad8(sizeof(Dag)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(4ll * (n + 1));
+}
+AMBI_HD int64_t prepare_junction_bytes(int n, int m) {
+    return pad8(int64_t(sizeof(JuncEnds)) * m) + pad8(8ll * (n + 1)) + pad8(16ll * (n + 1)) + pad8(4ll * (n + 1)) + pad8(4ll * (n + 2)) +
+           2 * pad8(4ll * m) + pad8(m);
+}
 AMBI_HD int64_t prepare_work_bytes(int n, int m, int K) {
-    return pad8(int64_t(sizeof(Junction)) * m) + pad8(8ll * (n + 1)) + pad8(16ll * (n + 1)) + pad8(4ll * (n + 1)) +
-           pad8(4ll * (n + 1)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(sizeof(Dag)) +
-           pad8(4ll * (n + 1)) + 2 * pad8(4ll * m) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(m) + kPrepHashBytes;
+    const int64_t a = prepare_junction_bytes(n, m), b = pad8(kPrepLatticeBytes);
+    return prepare_persistent_bytes(n, K) + (a > b ? a : b);
 }
 AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
     PrepareWork W;
     int64_t o = 0;
-    W.juncs = reinterpret_cast<Junction*>(base + o); o += pad8(int64_t(sizeof(Junction)) * m);
-    W.seg_cn = reinterpret_cast<double*>(base + o); o += pad8(8ll * (n + 1));
-    W.junc_cn = reinterpret_cast<double*>(base + o); o += pad8(16ll * (n + 1));
-    W.inv_junc = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
-    W.target_cn = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
-    W.elems = reinterpret_cast<Element*>(base + o); o += pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
     W.dag = reinterpret_cast<Dag*>(base + o); o += pad8(sizeof(Dag));
-    W.slot_cnt = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
-    W.fb = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
-    W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.elems = reinterpret_cast<Element*>(base + o); o += pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
     W.idx = reinterpret_cast<int32_t*>(base + o); o += pad8(4 * 64);
     W.loops = reinterpret_cast<Rec3*>(base + o); o += pad8(sizeof(Rec3) * 64);
-    W.taken = base + o; o += pad8(m);
-    W.hash_mem = base + o;
+    W.target_cn = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
+    W.lattice_mem = base + o;
+    W.seg_cn = reinterpret_cast<double*>(base + o); o += pad8(8ll * (n + 1));
+    W.junc_cn = reinterpret_cast<double*>(base + o); o += pad8(16ll * (n + 1));
+    W.ends = reinterpret_cast<JuncEnds*>(base + o); o += pad8(int64_t(sizeof(JuncEnds)) * m);
+    W.inv_junc = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
+    W.slot_cnt = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 2));
+    W.fb = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.taken = base + o;
     return W;
+}
+AMBI_HD LatticeWork carve_prepare_lattice(uint8_t* h) {
+    LatticeWork L;
+    L.keys = reinterpret_cast<uint64_t*>(h); h += 8ll * kPrepHashSlots;
+    L.ikey = reinterpret_cast<uint64_t*>(h); h += 8ll * (kPrepHashSlots / 2);
+    L.cnt = reinterpret_cast<uint64_t*>(h); h += 8ll * (kPrepHashSlots / 2);
+    L.pos = reinterpret_cast<int32_t*>(h); h += 4ll * kPrepHashSlots;
+    L.cbase = reinterpret_cast<int32_t*>(h); h += 4ll * (kPrepHashSlots / 2 + 2);
+    L.link = reinterpret_cast<uint32_t*>(h); h += 4ll * kPrepLinks;
+    L.lvl_off = reinterpret_cast<int32_t*>(h); h += 4ll * (kMaxNodes + 3);
+    L.counter = reinterpret_cast<int32_t*>(h);
+    L.cap = kPrepHashSlots;
+    L.link_cap = kPrepLinks;
+    return L;
 }
 
 template <class G, class T>
@@ -74,10 +102,6 @@ AMBI_HD void copy_words(const G& g, T* dst, const T* src, int64_t count) {
 AMBI_HD IdealTable unit_ideal_table(const BatchArgs& A, int u) {
     const UnitIn& U = A.units[u];
     IdealTable T;
-    T.keys = A.ideal_keys + U.ideal_off;
-    T.cnt = A.ideal_cnt + U.ideal_off;
-    T.pos = A.ideal_pos + U.ideal_off;
-    T.lvl = A.ideal_lvl + U.ideal_off / 2;
     T.lvl_off = A.ideal_lvl_off + int64_t(u) * (kMaxNodes + 3);
     T.counter = A.ideal_counter + 2 * int64_t(u);
     T.a_avail = A.auto_avail + U.ideal_off / 2;
@@ -87,6 +111,23 @@ AMBI_HD IdealTable unit_ideal_table(const BatchArgs& A, int u) {
     T.cap = U.ideal_cap;
     T.child_cap = 4 * U.ideal_cap;
     return T;
+}
+// lattice-search work areas in the HBM pools (large lattices); the level offsets, counters and child bases are the
+// table's own arrays
+AMBI_HD LatticeWork unit_lattice_work(const BatchArgs& A, int u, const IdealTable& T) {
+    const UnitIn& U = A.units[u];
+    LatticeWork W;
+    W.keys = A.ideal_keys + U.ideal_off;
+    W.pos = A.ideal_pos + U.ideal_off;
+    W.ikey = A.ideal_cnt + U.ideal_off;
+    W.cnt = A.ideal_cnt + U.ideal_off + U.ideal_cap / 2;
+    W.cbase = T.a_cbase;
+    W.link = A.ideal_link + 4 * U.ideal_off;
+    W.lvl_off = T.lvl_off;
+    W.counter = T.counter;
+    W.cap = U.ideal_cap;
+    W.link_cap = 4 * U.ideal_cap;
+    return W;
 }
 
 template <class G>
@@ -99,9 +140,9 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     UnitOut* out = unit_out(A.results, u);
     AMBI_MARK(A, g, u, 0);
 
-    // coalesced staging of the unit's records (as 32-bit words) into the group's memory
-    copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
-               int64_t(sizeof(Junction) / 4) * m);
+    // staging: junction ends (4 of the 24 bytes of a record), segment CN and the solution elements
+    const JuncView J{W.ends, A.juncs + U.junc_off};
+    for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(J.full[j]);
     copy_words(g, reinterpret_cast<uint32_t*>(W.seg_cn), reinterpret_cast<const uint32_t*>(A.seg_cn + U.seg_off),
                2ll * (n + 1));
     copy_words(g, reinterpret_cast<uint32_t*>(W.elems), reinterpret_cast<const uint32_t*>(A.elems + U.elem_off),
@@ -112,18 +153,18 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
 
     int status = ST_OK;
     double inv_sum = 0;
-    get_junc_cn_g(g, n, W.juncs, m, W.junc_cn, W.inv_junc, W.slot_cnt, W.fb);            // localhap.cpp:136-139
+    get_junc_cn_g(g, n, J, m, W.junc_cn, W.inv_junc, W.slot_cnt, W.fb);                  // localhap.cpp:136-139
     AMBI_MARK(A, g, u, 2);
-    const int bias = compute_bias_g(g, n, W.juncs, W.junc_cn, W.inv_junc);                // :141-146
+    const int bias = compute_bias_g(g, n, J, W.junc_cn, W.inv_junc);                      // :141-146
     AMBI_MARK(A, g, u, 3);
-    get_indel_bias_g(g, n, W.juncs, m, W.seg_cn, W.sv, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
+    get_indel_bias_g(g, n, J, m, W.seg_cn, W.sv, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
     AMBI_MARK(A, g, u, 4);
     const bool no_fbi = no_foldback_g(g, n, W.junc_cn, &inv_sum);                         // :150-153
     if (no_fbi && !U.has_components) status = ST_SHORTCUT;                                // :164
     else if (U.infeasible) status = ST_INFEASIBLE;                                        // :213
     else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
     else {
-        target_cn_g(g, W.elems, K, n, W.target_cn);                                       // :222-232
+        target_cn_g(g, W.elems, K, n, W.target_cn, W.slot_cnt);                           // :222-232
         AMBI_MARK(A, g, u, 5);
         DagScratch DS{W.idx, W.loops};
         status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS);                  // :236
@@ -131,34 +172,8 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     g.sync();
     AMBI_MARK(A, g, u, 6);
 
-    uint64_t R = 0;
-    if (status == ST_OK) {
-        IdealTable T = unit_ideal_table(A, u);
-        // fast path: hash set, level list and counters in group memory (the automaton itself always goes to HBM)
-        IdealTable TL = T;
-        {
-            uint8_t* h = W.hash_mem;
-            TL.keys = reinterpret_cast<uint64_t*>(h); h += 8ll * kPrepHashSlots;
-            TL.cnt = reinterpret_cast<uint64_t*>(h); h += 8ll * kPrepHashSlots;
-            TL.pos = reinterpret_cast<int32_t*>(h); h += 4ll * kPrepHashSlots;
-            TL.lvl = reinterpret_cast<int32_t*>(h); h += 4ll * (kPrepHashSlots / 2);
-            TL.lvl_off = reinterpret_cast<int32_t*>(h); h += 4ll * (kMaxNodes + 3);
-            TL.counter = reinterpret_cast<int32_t*>(h);
-            TL.cap = kPrepHashSlots;
-        }
-        int st = ideal_build_and_count(g, W.dag->pred, K, TL, &R);
-        if (st == ST_OK) {
-            // consumers read the level offsets and the counters from the table in HBM
-            for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) T.lvl_off[d] = TL.lvl_off[d];
-            for (int t = g.tid(); t < 2; t += g.size()) T.counter[t] = TL.counter[t];
-        } else if (st == ST_ERR_IDEALS_CAPACITY) {
-            st = ideal_build_and_count(g, W.dag->pred, K, T, &R);   // large lattice: hash set in HBM
-        }
-        if (st != ST_OK) status = st;
-    }
-
-    AMBI_MARK(A, g, u, 7);
-    // results: junc_cn, seg_cn (after indel bias), target_cn, fold-back map
+    // results: junc_cn, seg_cn (after indel bias), target_cn, fold-back map -- before the lattice search takes over
+    // the junction-phase memory
     copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.junc_cn), reinterpret_cast<const uint32_t*>(W.junc_cn), 4ll * (n + 1));
     copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.seg_cn), reinterpret_cast<const uint32_t*>(W.seg_cn), 2ll * (n + 1));
     copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.target_cn), reinterpret_cast<const uint32_t*>(W.target_cn), int64_t(n + 1));
@@ -167,19 +182,30 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
         int16_t* isrc = reinterpret_cast<int16_t*>(res + Lay.inv_src);
         int16_t* itgt = reinterpret_cast<int16_t*>(res + Lay.inv_tgt);
         for (int i = g.tid(); i <= n; i += g.size()) {
-            int ji = W.inv_junc[i];
-            isrc[i] = (int16_t)(ji >= 0 ? W.juncs[ji].src : 0);
-            itgt[i] = (int16_t)(ji >= 0 ? W.juncs[ji].tgt : 0);
+            const int ji = W.inv_junc[i];
+            isrc[i] = (int16_t)(ji >= 0 ? iabs(W.ends[ji].s) : 0);
+            itgt[i] = (int16_t)(ji >= 0 ? iabs(W.ends[ji].t) : 0);
         }
     }
-    if (status == ST_OK || status == ST_ERR_IDEALS_CAPACITY)
+    if (status == ST_OK)
         copy_words(g, reinterpret_cast<uint32_t*>(A.dags + u), reinterpret_cast<const uint32_t*>(W.dag), int64_t(sizeof(Dag) / 4));
+    g.sync();
+    AMBI_MARK(A, g, u, 7);
+
+    uint64_t R = 0;
+    if (status == ST_OK) {
+        const IdealTable T = unit_ideal_table(A, u);
+        // fast path: search state in group memory (the frozen automaton itself always goes to HBM)
+        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R);
+        if (st == ST_ERR_IDEALS_CAPACITY) st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R);   // large lattice
+        if (st != ST_OK) status = st;
+    }
     if (g.tid() == 0) {
         out->status = status;
         out->bias = bias;
         out->K = K;
         out->bkp_len = 0; out->path_len = 0; out->path_indel_len = 0; out->indel_printed = 0; out->n_out_junc = 0;
-        out->first_forward = -1; out->evaluated = 0;
+        out->first_forward = -1; out->evaluated = 0; out->path_ind_stored = 0; out->reserved = 0;
         out->num_orders = (int64_t)R;
         out->first_valid = -1;
         out->order_off = -1;
@@ -406,18 +432,19 @@ struct FinishWork {
     cell_t* path;       // [path_cap]
     cell_t* bkp;        // [bkp_cap]
     int32_t* offs;      // [bkp_cap/2 + 2]
-    Junction* juncs;    // [m]
+    JuncEnds* ends;     // [m]   strand-signed junction ends
     int32_t* sv;        // [m]
-    int32_t* grp;       // [2m+4]
-    int32_t* cand;      // [out_cap + bkp_cap]  candidate junction steps
+    int32_t* cand;      // [finish_cand_cap]  candidate junction steps, their representatives and edge keys
     int32_t* first;     // [2n+1] first occurrence of every vertex in the path
     int32_t* last;      // [2n+1] last occurrence
     uint8_t* taken;     // [m]
     uint8_t* has_ext;   // [m]
 };
+// (the deque of the general indelBFB path, 2m+4 ints, lives in the unit's HBM scratch: it is touched only when SVs chain)
+AMBI_HD int finish_cand_cap(int bkp_cap, int out_cap) { return out_cap + 2 * bkp_cap + 32; }
 AMBI_HD int64_t finish_work_bytes(int n, int m, int bkp_cap, int path_cap, int out_cap) {
-    return pad8(2ll * path_cap) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(Junction)) * m) +
-           pad8(4ll * m) + pad8(4ll * (2 * m + 4)) + pad8(4ll * (out_cap + bkp_cap)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
+    return pad8(2ll * path_cap) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(JuncEnds)) * m) +
+           pad8(4ll * m) + pad8(4ll * finish_cand_cap(bkp_cap, out_cap)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
 }
 AMBI_HD FinishWork carve_finish(uint8_t* base, int n, int m, int bkp_cap, int path_cap, int out_cap) {
     FinishWork W;
@@ -425,10 +452,9 @@ AMBI_HD FinishWork carve_finish(uint8_t* base, int n, int m, int bkp_cap, int pa
     W.path = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * path_cap);
     W.bkp = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * bkp_cap);
     W.offs = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (bkp_cap / 2 + 2));
-    W.juncs = reinterpret_cast<Junction*>(base + o); o += pad8(int64_t(sizeof(Junction)) * m);
+    W.ends = reinterpret_cast<JuncEnds*>(base + o); o += pad8(int64_t(sizeof(JuncEnds)) * m);
     W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
-    W.grp = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * m + 4));
-    W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (out_cap + bkp_cap));
+    W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * finish_cand_cap(bkp_cap, out_cap));
     W.first = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
     W.last = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
     W.taken = base + o; o += pad8(m);
@@ -451,9 +477,9 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
         // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
         int P = n <= U.path_cap ? n : U.path_cap;
-        for (int i = g.tid(); i < P; i += g.size()) { gpath[i] = i + 1 + base; gpath2[i] = i + 1 + base; }
+        for (int i = g.tid(); i < P; i += g.size()) gpath[i] = i + 1 + base;
         if (g.tid() == 0) {
-            out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0;
+            out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
             if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
         }
         g.sync();
@@ -464,33 +490,28 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     const int L = out->bkp_len;
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
-    copy_words(g, reinterpret_cast<uint32_t*>(W.juncs), reinterpret_cast<const uint32_t*>(A.juncs + U.junc_off),
-               int64_t(sizeof(Junction) / 4) * m);
+    {
+        const Junction* gj = A.juncs + U.junc_off;
+        for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(gj[j]);
+    }
     g.sync();
     AMBI_MARK(A, g, u, 17);
-    int P = expand_bkp(g, W.bkp, L, W.path, U.path_cap, W.offs);
+    int P = expand_bkp(g, W.bkp, L, W.path, U.path_cap, W.offs, gpath, base);
     if (P < 0) { if (g.tid() == 0) out->status = P; g.sync(); return; }
-    for (int i = g.tid(); i < P; i += g.size()) { int v = W.path[i]; gpath[i] = v > 0 ? v + base : v - base; }
     int P2 = P;
     AMBI_MARK(A, g, u, 18);
-    IndelScratch S{W.sv, W.taken, W.has_ext, W.grp, W.first, W.last};
-    int printed = indel_bfb(g, n, W.juncs, m, W.path, &P2, U.path_cap, S);
+    IndelScratch S{W.sv, W.taken, W.has_ext, A.scratch_i32 + A.scratch_off[u], W.first, W.last};
+    bool edited = false;
+    int printed = indel_bfb(g, n, W.ends, m, W.path, &P2, U.path_cap, S, &edited);
     if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
     AMBI_MARK(A, g, u, 19);
-    for (int i = g.tid(); i < P2; i += g.size()) { int v = W.path[i]; gpath2[i] = v > 0 ? v + base : v - base; }
-    // output junctions of the final path; records are produced in LDS-free form straight into the blob
-    int nout = synth_out_juncs(g, W.path, P2, gout, U.out_cap, W.cand, U.out_cap + U.bkp_cap);
+    // the edited path is materialised only when indelBFB changed something; otherwise readers take `path`
+    if (edited) for (int i = g.tid(); i < P2; i += g.size()) { int v = W.path[i]; gpath2[i] = v > 0 ? v + base : v - base; }
+    // output junctions of the final path; records go straight into the blob (absolute ids)
+    int nout = synth_out_juncs(g, W.path, P2, gout, U.out_cap, W.cand, finish_cand_cap(U.bkp_cap, U.out_cap), base);
     AMBI_MARK(A, g, u, 20);
-    if (nout >= 0) {
-        g.sync();
-        for (int k = g.tid(); k < nout; k += g.size()) {
-            int a = gout[k].u, b = gout[k].v;
-            gout[k].u = a > 0 ? a + base : a - base;
-            gout[k].v = b > 0 ? b + base : b - base;
-        }
-    }
     if (g.tid() == 0) {
-        out->path_len = P; out->path_indel_len = P2; out->indel_printed = printed;
+        out->path_len = P; out->path_indel_len = P2; out->indel_printed = printed; out->path_ind_stored = edited ? 1 : 0;
         out->n_out_junc = nout >= 0 ? nout : 0;
         if (nout < 0) out->status = nout;
     }

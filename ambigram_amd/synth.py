@@ -169,8 +169,8 @@ def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperf
             els = planted_wide(rng, s, e, (K - 1) // 2, cn_choices)
         elif tier == "mixed":
             els = planted_mixed(rng, s, e, K, cn_choices)
-        elif tier == "skew":
-            els = planted_skew(rng, s, e, K, cn_choices)
+        elif tier.startswith("skew"):   # "skew" or "skew<k2>", e.g. skew5 -> R = C(K-1, 5)
+            els = planted_skew(rng, s, e, K, cn_choices, k2=int(tier[4:] or 3))
         else:
             raise ValueError(tier)
         all_elements.append(els)

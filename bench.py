@@ -144,7 +144,8 @@ def main():
         per_kernel["ambi_plan_kernel"] += 64
         per_kernel["ambi_enumerate_kernel"] += R * K                 # every order written once
         per_kernel["ambi_first_kernel"] += E * K + 2 * E * L         # orders read until the first valid one, bkp written
-        per_kernel["ambi_finish_kernel"] += 2 * L + 4 * P + 4 * P2   # bkp read, path + edited path written
+        # bkp read, path written; the path after indelBFB is written only when indelBFB changed it
+        per_kernel["ambi_finish_kernel"] += 2 * L + 4 * P + (4 * P2 if r["path_indel_stored"] else 0)
         formula += 8 * n + 24 * mj + 16 * K + 2 * R * K + 4 * E * L + 4 * P
     dom = max(ktimes, key=lambda k: ktimes[k]) if ktimes else "ambi_enumerate_kernel"
     dom_ms = ktimes.get(dom, float("nan"))

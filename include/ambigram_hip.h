@@ -143,6 +143,8 @@ typedef struct {
     int64_t num_orders;       /* R */
     int64_t first_valid;      /* index of the first valid order, -1 if none */
     double inv_cn_sum;        /* localhap.cpp:150-153 */
+    int32_t path_indel_stored; /* 1: indelBFB changed the path (a second path is held); 0: it equals the getBFB path */
+    int32_t reserved;
 } ambi_unit_result_t;
 int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result_t* out);
 /* which: 0 = getBFB path (LocalGenomicMap.cpp:3660-3671), 1 = after indelBFB (:3746-3837). Returns length or <0. */

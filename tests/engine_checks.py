@@ -191,3 +191,31 @@ def check_enumerate_variants(lib, oracle, workdir, big=False):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def check_large_lattice(lib, oracle, workdir, K=50, k2=5):
+    """A lattice with more ideals than the group-local search holds (256): (K-k2)(k2+1)+1 ideals take the HBM path of
+    the lattice search.  R = C(K-1,k2) rows; the table is checked against the oracle's order count, by sampling rows
+    (permutation, DAG-respecting, lexicographically increasing) and through the reconstructed path."""
+    from ambigram_amd import synth
+    s = synth.make_sample(128, 256, "skew%d" % k2, K, seed=7300 + K)
+    lh, sols = s.write(workdir, "ll%d" % K)
+    oc = oracle.run_bfb(lh, sols)["chr"][0]
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sols[0])
+    b.upload(); b.run(0); b.download()
+    r = b.unit_result(0)
+    assert r["status"] == 0 and r["num_orders"] == oc["num_orders"], (r, oc["num_orders"])
+    assert (K - k2) * (k2 + 1) + 1 > 256
+    R = r["num_orders"]
+    for first in (0, R // 3, R - 5000):
+        rows = b.unit_orders(0, first, 5000, K)
+        assert np.array_equal(np.sort(rows, axis=1), np.tile(np.arange(K, dtype=np.uint8), (len(rows), 1)))
+        a, bb = rows[:-1].astype(np.int16), rows[1:].astype(np.int16)
+        neq = a != bb
+        fi = neq.argmax(axis=1)
+        ii = np.arange(len(a))
+        assert neq.any(axis=1).all() and (a[ii, fi] < bb[ii, fi]).all()
+    assert b.unit_path(0, 0).tolist() == oc["path"] and b.unit_path(0, 1).tolist() == oc["path_indel"]
+    b.close(); g.close()

@@ -20,7 +20,8 @@ class HostSimBackend : public Backend {
     std::vector<uint8_t> results_, arena_;
     std::vector<uint64_t> ikeys_, icnt_, aavail_, acnt_;
     std::vector<uint16_t> achild_;
-    std::vector<int32_t> ilvl_, ilvl_off_, icounter_, ipos_, acbase_, rows_per_lane_, scratch_;
+    std::vector<uint32_t> ilink_;
+    std::vector<int32_t> ilvl_off_, icounter_, ipos_, acbase_, rows_per_lane_, scratch_;
     std::vector<int64_t> blk_off_;
     int32_t n_pending_ = 0;
     int64_t orders_needed_ = 0;
@@ -40,7 +41,7 @@ class HostSimBackend : public Backend {
         results_.assign((size_t)hb.result_bytes, 0);
         ikeys_.assign((size_t)hb.ideal_slots, 0); icnt_.assign((size_t)hb.ideal_slots, 0);
         ipos_.assign((size_t)hb.ideal_slots, 0);
-        ilvl_.assign((size_t)hb.ideal_slots / 2 + 1, 0);
+        ilink_.assign((size_t)hb.ideal_slots * 4 + 8, 0);
         ilvl_off_.assign(U * (kMaxNodes + 3), 0); icounter_.assign(2 * U, 0);
         aavail_.assign((size_t)hb.ideal_slots / 2 + 1, 0); acnt_.assign((size_t)hb.ideal_slots / 2 + 1, 0);
         acbase_.assign((size_t)hb.ideal_slots / 2 + U + 1, 0); achild_.assign((size_t)hb.ideal_slots * 4 + 8, 0);
@@ -57,7 +58,7 @@ class HostSimBackend : public Backend {
         A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data();
         A_.units = units_.data(); A_.seg_cn = hb_.seg_cn.data(); A_.juncs = hb_.juncs.data(); A_.elems = hb_.elems.data();
         A_.dags = dags_.data(); A_.results = results_.data();
-        A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_lvl = ilvl_.data();
+        A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_link = ilink_.data();
         A_.ideal_lvl_off = ilvl_off_.data(); A_.ideal_counter = icounter_.data();
         A_.order_arena = arena_.data(); A_.order_arena_bytes = (int64_t)arena_.size();
         A_.blk_off = blk_off_.data(); A_.rows_per_lane = rows_per_lane_.data();
@@ -184,7 +185,7 @@ class HostSimBackend : public Backend {
             const UnitIn& U = units_[u];
             UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
             int len = which ? h->path_indel_len : h->path_len;
-            const int32_t* src = reinterpret_cast<const int32_t*>(results_.data() + U.res_off + (which ? L.path_ind : L.path));
+            const int32_t* src = reinterpret_cast<const int32_t*>(results_.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
             lengths[u] = len;
             for (int i = 0; i < len && off + i < cap; i++) cells[off + i] = src[i];
             off += len;

@@ -151,3 +151,7 @@ def test_cli_on_gpu(hip_lib, oracle, tmp_path):
     t.check_readme(exe, str(d1), oracle)
     t.check_trx(exe, str(d2), oracle)
     t.check_errors(exe, str(d3))
+
+
+def test_large_lattice(hip_lib, oracle, workdir):
+    ec.check_large_lattice(hip_lib, oracle, workdir, K=50, k2=5)

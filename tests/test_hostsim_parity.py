@@ -34,3 +34,7 @@ def test_batch_many_units(hostsim_lib, oracle, workdir):
 
 def test_enumerate_variants(hostsim_lib, oracle, workdir):
     ec.check_enumerate_variants(hostsim_lib, oracle, workdir)
+
+
+def test_large_lattice(hostsim_lib, oracle, workdir):
+    ec.check_large_lattice(hostsim_lib, oracle, workdir, K=50, k2=5)
