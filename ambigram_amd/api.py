@@ -80,6 +80,7 @@ def _declare(L):
         "ambi_batch_set_timing": (C.c_int, [vp, i32]),
         "ambi_batch_kernel_count": (C.c_int, [vp]),
         "ambi_batch_kernel_time": (C.c_int, [vp, i32, _P(C.c_char_p), _P(C.c_float)]),
+        "ambi_batch_slices": (C.c_int, [vp]),
         "ambi_batch_traffic": (C.c_int, [vp, pi64, pi64, pi64]),
         "ambi_format_path": (i64, [vp, pi32, i32, C.c_char_p, i64]),
         "ambi_translocation_bfb": (C.c_int, [vp, pi32, pi64, i32, pi32, i32]),
@@ -356,6 +357,9 @@ class Batch:
 
     def set_timing(self, on=True):
         self.lib.ambi_batch_set_timing(self.h, 1 if on else 0)
+
+    def slices(self):
+        return int(self.lib.ambi_batch_slices(self.h))
 
     def kernel_times(self):
         out = {}

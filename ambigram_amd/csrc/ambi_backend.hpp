@@ -17,6 +17,7 @@ struct EngineConfig {
     int32_t block_scratch_lds = 16384;   // LDS of the image-build kernel (automaton copy; env AMBI_BLOCK_SCRATCH_LDS overrides)
     int32_t block_max = 256;         // largest suffix block in rows (env AMBI_BLOCK_MAX overrides)
     int32_t target_lanes = 524288;   // enumerate kernel: rows of the batch are spread over about this many lanes
+    int32_t slices = 0;              // unit ranges run on separate streams (0: automatic; env AMBI_SLICES overrides)
 };
 
 struct KernelTime { const char* name; float ms; };
@@ -39,6 +40,7 @@ class Backend {
     virtual void set_timing(bool on) = 0;
     virtual const std::vector<KernelTime>& kernel_times() = 0;
     virtual int64_t order_bytes_written() const = 0;
+    virtual int slice_count() const { return 1; }   // launches of every kernel per run
 };
 
 Backend* make_backend();   // defined by the linked backend

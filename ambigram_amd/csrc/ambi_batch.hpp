@@ -84,8 +84,13 @@ AMBI_HD UnitLayout unit_layout(int n, int bkp_cap, int path_cap, int out_cap) {
 }
 
 // kernel argument block (device pointers)
+// A batch is run as one or more SLICES (contiguous unit ranges) whose kernel chains are issued on different HIP streams,
+// so that the HBM-bound enumerate kernel of one slice overlaps the latency-bound kernels of the others.  Per-unit
+// arrays are indexed by the GLOBAL unit index  unit_base + local index; blk_off / orders_needed are per slice.
 struct BatchArgs {
-    int32_t n_units;
+    int32_t n_units;             // units of this slice
+    int32_t unit_base;           // first unit of this slice
+    int64_t arena_base;          // byte offset of this slice's region inside the order arena
     uint32_t flags;
     int32_t first_budget;        // orders the first-valid kernel tries per orientation before declaring PENDING
     int32_t target_lanes;        // enumerate kernel: lanes to spread the rows of the batch over (sets rows per lane)
@@ -116,11 +121,11 @@ struct BatchArgs {
     uint16_t* auto_child;        // [U * 4 * ideal_cap]
     // order table
     uint8_t* order_arena;
-    int64_t order_arena_bytes;
-    int64_t* blk_off;            // [U+1] enumerate work-block prefix
-    int32_t* rows_per_lane;      // [U]   T of the unit
-    int32_t* n_pending;          // [1]
-    int64_t* orders_needed;      // [1] bytes the order table of the whole batch needs (for arena sizing)
+    int64_t order_arena_bytes;   // bytes of this slice's region
+    int64_t* blk_off;            // [n_units+1] enumerate work-block prefix of this slice (local index)
+    int32_t* rows_per_lane;      // [U]   T of the unit (global index)
+    int32_t* n_pending;          // [1]   whole batch
+    int64_t* orders_needed;      // [1] bytes the order tables of this slice need (for arena sizing)
     // scratch for indel grouping (per unit: sv[m], grp[2m+4] ints, taken[m] bytes)
     int32_t* scratch_i32;
     int64_t* scratch_off;        // [U] offset (ints) into scratch_i32

@@ -308,6 +308,7 @@ int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t
     return b->be->copy_orders(unit, first, count, out);
 }
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on) { if (!b) return AMBI_ERR_ARG; b->be->set_timing(on != 0); return 0; }
+int ambi_batch_slices(const ambi_batch_t* b) { return b ? b->be->slice_count() : AMBI_ERR_ARG; }
 int ambi_batch_kernel_count(const ambi_batch_t* b) { return b ? (int)b->be->kernel_times().size() : AMBI_ERR_ARG; }
 int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms) {
     if (!b) return AMBI_ERR_ARG;

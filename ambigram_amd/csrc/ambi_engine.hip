@@ -38,7 +38,7 @@ extern __shared__ __align__(16) uint8_t ambi_lds[];
 
 __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
-    stage_prepare(g, A, (int)blockIdx.x, ambi_lds);
+    stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
 __device__ inline int64_t wave_incl_scan_i64(int64_t v) {
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     __shared__ int64_t sh[17];
     // pass 1: rows of the whole batch -> rows per lane of the enumerate kernel
     int64_t my_rows = 0;
-    for (int u = threadIdx.x; u < A.n_units; u += blockDim.x) {
-        const UnitOut* o = unit_out(A.results, u);
+    for (int i = threadIdx.x; i < A.n_units; i += blockDim.x) {
+        const UnitOut* o = unit_out(A.results, A.unit_base + i);
         if (o->status == ST_OK && o->num_orders < (int64_t)kCountSat) my_rows += o->num_orders;
     }
     int64_t total_rows;
@@ -78,12 +78,13 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     const int TL = rows_per_lane_for(total_rows, A.target_lanes);
     int64_t off_carry = 0, blk_carry = 0;
     for (int base = 0; base < A.n_units; base += blockDim.x) {
-        const int u = base + (int)threadIdx.x;
+        const int i = base + (int)threadIdx.x;     // local index inside the slice
+        const int u = A.unit_base + i;              // global unit
         int64_t bytes = 0, blocks = 0;
         const int T = TL;
         bool live = false, toobig = false;
         UnitOut* out = nullptr;
-        if (u < A.n_units) {
+        if (i < A.n_units) {
             out = unit_out(A.results, u);
             if (out->status == ST_OK) {
                 const int K = out->K;
@@ -101,12 +102,12 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
         // a unit that does not fit contributes no work blocks
         bool fits = live && (off + bytes <= A.order_arena_bytes);
         int64_t blk = blk_carry + block_exscan_i64(fits ? blocks : 0, &tot_k, sh);
-        if (u < A.n_units) {
-            A.blk_off[u] = blk;
+        if (i < A.n_units) {
+            A.blk_off[i] = blk;
             A.rows_per_lane[u] = T;
             if (toobig) out->status = ST_ERR_ORDERS_CAPACITY;
             else if (live) {
-                if (fits) out->order_off = off;
+                if (fits) out->order_off = A.arena_base + off;
                 else out->status = ST_ERR_ORDERS_CAPACITY;
             }
         }
@@ -139,13 +140,13 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
-        const int u = lo;
+        const int u = A.unit_base + lo;
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
         if (enum_class_of(K) != CLS) continue;   // rows of this width belong to another instantiation
         if (!A.unit_fallback[u]) continue;
         const int64_t R = out->num_orders;
-        const int64_t base_rank = (b - A.blk_off[u]) * 256ll * T + (int64_t)wave * 64 * T;
+        const int64_t base_rank = (b - A.blk_off[lo]) * 256ll * T + (int64_t)wave * 64 * T;
         const IdealTable tbl = unit_ideal_table(A, u);
         const AutoView V = auto_view(tbl);
         const int nI = V.nI, nC = tbl.counter[1];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
 __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
-    const int u = blockIdx.x;
+    const int u = A.unit_base + (int)blockIdx.x;
     const UnitOut* out = unit_out(A.results, u);
     if (out->status != ST_OK || out->order_off < 0) return;
     const IdealTable tbl = unit_ideal_table(A, u);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
-        const int u = lo;
+        const int u = A.unit_base + lo;
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
         if (enum_class_of(K) != CLS) continue;
@@ -241,10 +242,17 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         }
         if (!fits) continue;
         const int64_t R = out->num_orders;   // < 2^32 for every unit that has an image
-        const int64_t wlo = (b - A.blk_off[u]) * 256ll * T + (int64_t)wave * 64 * T;
-        int64_t whi = wlo + 64ll * T;
-        if (whi > R) whi = R;
-        if (wlo < R)
+        // the rows of this work block, split evenly over the workgroup's waves (any row boundary will do: emission
+        // handles unaligned heads and tails)
+        const int64_t blo = (b - A.blk_off[lo]) * 256ll * T;
+        int64_t bhi = blo + 256ll * T;
+        if (bhi > R) bhi = R;
+        const int nwave = (int)(blockDim.x >> 6);
+        const int64_t per = (bhi - blo + nwave - 1) / nwave;
+        const int64_t wlo = blo + (int64_t)wave * per;
+        int64_t whi = wlo + per;
+        if (whi > bhi) whi = bhi;
+        if (wlo < whi)
             emit_blocks_dispatch<CLS>(reinterpret_cast<const uint32_t*>(tmem), nB, K, (uint32_t)wlo, (uint32_t)whi,
                                       A.order_arena + out->order_off, lane, lane + 1);
     }
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
 
 __global__ __launch_bounds__(64) void ambi_first_kernel(BatchArgs A) {
     WaveGroup g;
-    stage_first(g, A, (int)blockIdx.x, ambi_lds);
+    stage_first(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
 // Slow path: units whose first-valid scan ran out of budget.  One wave per chunk of `chunk` consecutive orders.
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(64) void ambi_resolve_kernel(BatchArgs A, SearchArg
 __global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
-    const int u = unit_list ? unit_list[blockIdx.x] : (int)blockIdx.x;
+    const int u = unit_list ? unit_list[blockIdx.x] : A.unit_base + (int)blockIdx.x;
     stage_finish(g, A, u, ambi_lds);
 }
 
@@ -380,6 +388,16 @@ class HipBackend : public Backend {
     std::vector<Ev> evs_;
     int64_t last_needed_ = 0;
     long timed_runs_ = 0;
+    // slices: contiguous unit ranges whose kernel chains run on different streams (see BatchArgs)
+    static constexpr int kMaxSlices = 16;
+    int n_slices_ = 1;
+    std::vector<int> slice_lo_;                        // [n_slices_+1]
+    std::vector<int64_t> slice_base_, slice_bytes_;    // arena regions
+    std::vector<hipStream_t> side_;                    // n_slices_-1 internal streams (slice 0 runs on the caller's)
+    hipEvent_t ev_fork_ = nullptr;
+    std::vector<hipEvent_t> ev_join_, ev_stage_;
+    bool stagger_ = true;
+    int enum_grid_ = 2048;
 
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
@@ -390,6 +408,13 @@ class HipBackend : public Backend {
         if (h_needed_) (void)hipHostFree(h_needed_);
         for (auto& e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         evs_.clear();
+        for (auto st : side_) (void)hipStreamDestroy(st);
+        side_.clear();
+        if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+        for (auto e : ev_join_) (void)hipEventDestroy(e);
+        ev_join_.clear();
+        for (auto e : ev_stage_) (void)hipEventDestroy(e);
+        ev_stage_.clear();
     }
 
   public:
@@ -431,17 +456,17 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_acnt_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
         if ((rc = dalloc(&d_acbase_, (size_t)hb.ideal_slots / 2 + U + 1))) return rc;
         if ((rc = dalloc(&d_achild_, (size_t)hb.ideal_slots * 4 + 8))) return rc;
-        if ((rc = dalloc(&d_blk_off_, U + 1))) return rc;
+        if ((rc = dalloc(&d_blk_off_, U + kMaxSlices + 1))) return rc;
         if ((rc = dalloc(&d_rows_, U))) return rc;
         if ((rc = dalloc(&d_npending_, 1))) return rc;
-        if ((rc = dalloc(&d_needed_, 1))) return rc;
+        if ((rc = dalloc(&d_needed_, kMaxSlices))) return rc;
         if ((rc = dalloc(&d_scratch_, (size_t)hb.scratch_ints + 8))) return rc;
         if ((rc = dalloc(&d_scratch_off_, U))) return rc;
         if ((rc = dalloc(&d_pack_off_, U + 1))) return rc;
         if ((rc = dalloc(&d_fallback_, U))) return rc;
         if (getenv("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
         HIP_CK(hipHostMalloc((void**)&h_npending_, sizeof(int32_t)));
-        HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t)));
+        HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t) * kMaxSlices));
         arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
         HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
         HIP_CK(hipMemcpy(d_units_, hb.units.data(), U * sizeof(UnitIn), hipMemcpyHostToDevice));
@@ -483,12 +508,35 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
         enum_classes_ = 0;
         for (const UnitIn& un : hb.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
+        // slices: env AMBI_SLICES or the configuration; 0 = automatic (4 when the batch is large enough to fill the
+        // chip four times over, else 1)
+        {
+            const char* env = getenv("AMBI_SLICES");
+            int want = env ? atoi(env) : cfg.slices;
+            // Measured on MI355X (profiles/r01_slices.md): the per-unit kernels already fill the issue slots of the chip,
+            // so slicing brings nothing on this workload (2 slices: +3 %, 4 staggered slices: -17 %); default 1.
+            if (want <= 0) want = 1;
+            if (want > kMaxSlices) want = kMaxSlices;
+            if (want > (int)U) want = (int)U > 0 ? (int)U : 1;
+            n_slices_ = want;
+            slice_lo_.assign(n_slices_ + 1, 0);
+            for (int s = 0; s <= n_slices_; s++) slice_lo_[s] = (int)((int64_t)U * s / n_slices_);
+            slice_base_.assign(n_slices_, 0); slice_bytes_.assign(n_slices_, 0);
+            for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(15); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(15); }
+            for (int s = 1; s < n_slices_; s++) { hipStream_t st; HIP_CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); side_.push_back(st); }
+            HIP_CK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+            for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_join_.push_back(e); }
+            for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_stage_.push_back(e); }
+            { const char* e2 = getenv("AMBI_STAGGER"); stagger_ = e2 ? atoi(e2) != 0 : true; }
+            { const char* e3 = getenv("AMBI_ENUM_GRID"); enum_grid_ = e3 ? atoi(e3) : 16384; if (enum_grid_ < 1) enum_grid_ = 1; }   // >= work blocks: one block per workgroup, the rest exit (measured: 2048 -> 16384 workgroups = -8 % kernel time)
+        }
         uploaded_ = true; arena_checked_ = false;
         return 0;
     }
 
+    // whole-batch argument block (pack kernels, slow path); slice_args() narrows it to one slice
     void bind(uint32_t flags) {
-        A_.n_units = (int32_t)hb_.units.size();
+        A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
         A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
@@ -500,78 +548,126 @@ class HipBackend : public Backend {
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
     }
+    BatchArgs slice_args(int s) const {
+        BatchArgs A = A_;
+        A.unit_base = slice_lo_[s]; A.n_units = slice_lo_[s + 1] - slice_lo_[s];
+        A.arena_base = slice_base_[s]; A.order_arena_bytes = slice_bytes_[s];
+        A.blk_off = d_blk_off_ + slice_lo_[s] + s;        // n_units + 1 private entries
+        A.orders_needed = d_needed_ + s;
+        // the rows of the WHOLE batch are spread over target_lanes lanes: a slice gets its share
+        A.target_lanes = cfg_.target_lanes / n_slices_ > 0 ? cfg_.target_lanes / n_slices_ : 1;
+        return A;
+    }
+    hipStream_t slice_stream(int s) const { return s == 0 ? stream_ : side_[s - 1]; }
 
-    // Per-kernel HIP events on the run's stream.  A ring of kTimingSlots event sets lets a timed region of many runs be
-    // averaged without a host sync per run: run r records into slot r % kTimingSlots.
+    // Per-kernel HIP events on the stream of the slice.  A ring of kTimingSlots event sets lets a timed region of many
+    // runs be averaged without a host sync per run: run r records into slot r % kTimingSlots.
     static constexpr int kTimingSlots = 64, kTimedKernels = 6;
-    void tick(const char* name, size_t idx, bool begin) {
+    void tick(const char* name, int slice, size_t idx, bool begin) {
         if (!timing_) return;
         const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
-        const size_t at = slot * kTimedKernels + idx;
+        const size_t at = (slot * n_slices_ + slice) * kTimedKernels + idx;
         while (evs_.size() <= at) {
             Ev e{name, nullptr, nullptr};
             (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
             evs_.push_back(e);
         }
         evs_[at].name = name;
-        (void)hipEventRecord(begin ? evs_[at].a : evs_[at].b, stream_);
+        (void)hipEventRecord(begin ? evs_[at].a : evs_[at].b, slice_stream(slice));
     }
 
-    int launch_front() {   // prepare + plan
-        const int U = A_.n_units;
-        tick("ambi_prepare_kernel", 0, true);
-        hipLaunchKernelGGL(ambi_prepare_kernel, dim3(U), dim3(64), lds_prepare_, stream_, A_);
-        tick("ambi_prepare_kernel", 0, false);
-        tick("ambi_plan_kernel", 1, true);
-        hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, stream_, A_);
-        tick("ambi_plan_kernel", 1, false);
-        HIP_CK(hipGetLastError());
-        return 0;
+    void fork() {   // the side streams start behind everything already queued on the caller's stream
+        if (n_slices_ <= 1) return;
+        (void)hipEventRecord(ev_fork_, stream_);
+        for (auto st : side_) (void)hipStreamWaitEvent(st, ev_fork_, 0);
+    }
+    void join() {   // the caller's stream continues after all side streams
+        for (int s = 1; s < n_slices_; s++) {
+            (void)hipEventRecord(ev_join_[s - 1], side_[s - 1]);
+            (void)hipStreamWaitEvent(stream_, ev_join_[s - 1], 0);
+        }
+    }
+
+    void launch_front(int s, const BatchArgs& A) {   // prepare + plan of one slice
+        hipStream_t st = slice_stream(s);
+        tick("ambi_prepare_kernel", s, 0, true);
+        hipLaunchKernelGGL(ambi_prepare_kernel, dim3(A.n_units), dim3(64), lds_prepare_, st, A);
+        tick("ambi_prepare_kernel", s, 0, false);
+        tick("ambi_plan_kernel", s, 1, true);
+        hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
+        tick("ambi_plan_kernel", s, 1, false);
+    }
+    void launch_build(int s, const BatchArgs& A) {   // block-emission images
+        hipStream_t st = slice_stream(s);
+        tick("ambi_blocks_build_kernel", s, 2, true);
+        hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(A.n_units), dim3(256), lds_build_, st, A);
+        tick("ambi_blocks_build_kernel", s, 2, false);
+    }
+    void launch_back(int s, const BatchArgs& A) {    // enumerate, first valid order, finish
+        hipStream_t st = slice_stream(s);
+        const int U = A.n_units;
+        const int grid = enum_grid_;
+        tick("ambi_enumerate_kernel", s, 3, true);
+        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(256), lds_blocks_, st, A);
+        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(256), lds_blocks_, st, A);
+        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(256), lds_blocks_, st, A);
+        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, st, A);
+        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
+        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
+        tick("ambi_enumerate_kernel", s, 3, false);
+        tick("ambi_first_kernel", s, 4, true);
+        hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, st, A);
+        tick("ambi_first_kernel", s, 4, false);
+        tick("ambi_finish_kernel", s, 5, true);
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, st, A, (const int32_t*)nullptr);
+        tick("ambi_finish_kernel", s, 5, false);
     }
 
     int run(uint32_t flags, void* stream) override {
         if (!uploaded_) return -32;
         stream_ = (hipStream_t)stream;
         bind(flags);
+        const int U = A_.n_units;
         HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
-        int rc = launch_front();
-        if (rc) return rc;
+        (void)hipMemsetAsync(d_fallback_, 0, sizeof(int32_t) * (size_t)U, stream_);
         if (!arena_checked_) {
-            // first run of this batch: make sure the order table fits, growing the arena once if needed
-            HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+            // first run of this batch: size the arena regions of the slices from what their order tables need
+            for (int s = 0; s < n_slices_; s++) launch_front(0, slice_args(s));   // all on the caller's stream
+            HIP_CK(hipGetLastError());
+            HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
             HIP_CK(hipStreamSynchronize(stream_));
-            if (*h_needed_ > arena_bytes_) {
+            int64_t total = 0;
+            for (int s = 0; s < n_slices_; s++) {
+                slice_base_[s] = total;
+                slice_bytes_[s] = (h_needed_[s] + (h_needed_[s] >> 4) + 4096 + 15) & ~int64_t(15);
+                total += slice_bytes_[s];
+            }
+            if (total > arena_bytes_) {
                 HIP_CK(hipFree(d_arena_));
                 d_arena_ = nullptr;
-                arena_bytes_ = *h_needed_ + (*h_needed_ >> 3) + 4096;
+                arena_bytes_ = total;
                 HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
                 bind(flags);
-                if ((rc = launch_front())) return rc;
             }
             arena_checked_ = true;
         }
-        const int U = A_.n_units;
-        (void)hipMemsetAsync(d_fallback_, 0, sizeof(int32_t) * (size_t)U, stream_);
-        tick("ambi_blocks_build_kernel", 2, true);
-        hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(U), dim3(256), lds_build_, stream_, A_);
-        tick("ambi_blocks_build_kernel", 2, false);
-        tick("ambi_enumerate_kernel", 3, true);
-        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
-        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
-        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(2048), dim3(256), lds_blocks_, stream_, A_);
-        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
-        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
-        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(2048), dim3(256), lds_enum_, stream_, A_);
-        tick("ambi_enumerate_kernel", 3, false);
-        tick("ambi_first_kernel", 4, true);
-        hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, stream_, A_);
-        tick("ambi_first_kernel", 4, false);
-        tick("ambi_finish_kernel", 5, true);
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, stream_, A_, (const int32_t*)nullptr);
-        tick("ambi_finish_kernel", 5, false);
+        // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
+        // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
+        // share the chip instead of alternating.
+        fork();
+        for (int s = 0; s < n_slices_; s++) {
+            const BatchArgs A = slice_args(s);
+            if (A.n_units <= 0) continue;
+            if (s > 0 && stagger_) (void)hipStreamWaitEvent(slice_stream(s), ev_stage_[s - 1], 0);
+            launch_front(s, A);
+            launch_build(s, A);
+            if (s + 1 < n_slices_) (void)hipEventRecord(ev_stage_[s], slice_stream(s));
+            launch_back(s, A);
+        }
         HIP_CK(hipGetLastError());
+        join();
         HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
         ran_ = true;
         if (timing_) timed_runs_++;
         return 0;
@@ -622,23 +718,27 @@ class HipBackend : public Backend {
     int wait() override {
         if (!ran_) return 0;
         HIP_CK(hipStreamSynchronize(stream_));
-        last_needed_ = *h_needed_;
+        last_needed_ = 0;
+        for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s];
         if (*h_npending_ > 0) {
             int rc = slow_path();
             if (rc) return rc;
             *h_npending_ = 0;
         }
         if (timing_ && timed_runs_ > 0) {
-            // average per kernel over the slots filled since timing was switched on
+            // average duration of ONE launch of every kernel over the slices and the slots filled since timing was
+            // switched on (every run launches each kernel once per slice)
             const long filled = timed_runs_ < kTimingSlots ? timed_runs_ : kTimingSlots;
             times_.clear();
             for (int k = 0; k < kTimedKernels; k++) {
                 double sum = 0; int cnt = 0; const char* nm = "";
-                for (long s = 0; s < filled; s++) {
-                    size_t at = (size_t)s * kTimedKernels + k;
-                    if (at >= evs_.size()) continue;
-                    float ms = 0;
-                    if (hipEventElapsedTime(&ms, evs_[at].a, evs_[at].b) == hipSuccess) { sum += ms; cnt++; nm = evs_[at].name; }
+                for (long sl = 0; sl < filled; sl++) {
+                    for (int sc = 0; sc < n_slices_; sc++) {
+                        size_t at = ((size_t)sl * n_slices_ + sc) * kTimedKernels + k;
+                        if (at >= evs_.size() || !evs_[at].a) continue;
+                        float ms = 0;
+                        if (hipEventElapsedTime(&ms, evs_[at].a, evs_[at].b) == hipSuccess) { sum += ms; cnt++; nm = evs_[at].name; }
+                    }
                 }
                 times_.push_back({nm, cnt ? (float)(sum / cnt) : -1.0f});
             }
@@ -700,6 +800,7 @@ class HipBackend : public Backend {
     void set_timing(bool on) override { timing_ = on; timed_runs_ = 0; }
     const std::vector<KernelTime>& kernel_times() override { return times_; }
     int64_t order_bytes_written() const override { return last_needed_; }
+    int slice_count() const override { return n_slices_; }
 };
 
 Backend* make_backend() { return new HipBackend(); }

@@ -335,32 +335,44 @@ AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out,
     if (P <= 0) return 0;
     // every sub-group (wavefront) owns a contiguous slice of the path and walks it 64 cells at a time (conflict-free
     // LDS reads, flags ranked by ballot without a barrier); ONE group scan over the sub-group totals orders all steps
+    // Vertices are non-zero, so "same strand and ids one apart" is simply |v - u| == 1.  ONE pass over the path, eight
+    // cells per thread and step (one 16-byte read of group memory): the rare junction steps are appended to a list
+    // through a counter, then put in path order by rank (the list is short: a few per breakpoint pair).
     const int steps = P - 1;
-    const int ss = g.sub_size(), ns = g.n_subs(), lane = g.sub_lane();
-    const int per = ((steps + ns - 1) / ns + ss - 1) / ss * ss;
-    const int lo = g.sub_id() * per, hi = lo + per < steps ? lo + per : steps;
-    auto is_step = [&](int i) {
-        int u = path[i], v = path[i + 1];
-        return !((iabs(iabs(u) - iabs(v)) == 1) && ((u > 0) == (v > 0)));
-    };
-    int mine = 0;   // steps of my sub-group's slice (the same number in all of its threads)
-    for (int i0 = lo; i0 < hi; i0 += ss) {
-        const int i = i0 + lane;
-        int cnt;
-        (void)g.flag_rank(i < hi && is_step(i), &cnt);
-        mine += cnt;
+    int32_t* count = cand + cand_cap - 1;                 // the list counter lives in the last scratch word
+    int32_t* unsorted = cand + 2 * ((cand_cap - 1) / 3);  // [<= (cand_cap-1)/3] appended positions
+    const int list_cap = (cand_cap - 1) / 3;
+    if (g.tid() == 0) *count = 0;
+    g.sync();
+    for (int i0 = 8 * g.tid(); i0 < steps; i0 += 8 * g.size()) {
+        cell_t c[9];
+        // the path is 16-byte aligned and padded by 16 bytes, so the four words and the ninth cell are always readable
+        const uint32_t* w4 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(path, 16)) + (i0 >> 1);
+        const uint32_t qx = w4[0], qy = w4[1], qz = w4[2], qw = w4[3];
+        c[0] = (cell_t)(qx & 0xFFFF); c[1] = (cell_t)(qx >> 16); c[2] = (cell_t)(qy & 0xFFFF); c[3] = (cell_t)(qy >> 16);
+        c[4] = (cell_t)(qz & 0xFFFF); c[5] = (cell_t)(qz >> 16); c[6] = (cell_t)(qw & 0xFFFF); c[7] = (cell_t)(qw >> 16);
+        c[8] = path[i0 + 8];
+        uint32_t flags = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int d = (int)c[k + 1] - (int)c[k];
+            flags |= (uint32_t)((d != 1 && d != -1) && (i0 + k < steps)) << k;
+        }
+        while (flags) {
+            const int k = __builtin_ctz(flags);
+            flags &= flags - 1;
+            const int at = atomic_add_i32(count, 1);
+            if (at < list_cap) unsorted[at] = i0 + k;
+        }
     }
-    int nc;
-    int at = g.exscan_i32(lane == 0 ? mine : 0, &nc);
-    if (lane != 0) at -= mine;   // threads behind the sub-group's first one have its contribution in their prefix
-    if (3 * nc > cand_cap) return ST_ERR_OUTJUNC_CAPACITY;
-    for (int i0 = lo; i0 < hi; i0 += ss) {
-        const int i = i0 + lane;
-        const bool q = i < hi && is_step(i);
-        int cnt;
-        const int r = g.flag_rank(q, &cnt);
-        if (q) cand[at + r] = i;
-        at += cnt;
+    g.sync();
+    const int nc = *count;
+    if (nc > list_cap || 3 * nc > cand_cap - 1) return ST_ERR_OUTJUNC_CAPACITY;
+    for (int c = g.tid(); c < nc; c += g.size()) {
+        const int pos = unsorted[c];
+        int r = 0;
+        for (int k = 0; k < nc; k++) r += unsorted[k] < pos ? 1 : 0;
+        cand[r] = pos;   // cand [0, nc) never overlaps the unsorted list: nc <= list_cap and the list starts at 2*list_cap
     }
     g.sync();
     // A step joins the FIRST earlier step that is the same edge or its complement edge (the reference bumps that

