@@ -81,6 +81,9 @@ def _declare(L):
         "ambi_batch_kernel_count": (C.c_int, [vp]),
         "ambi_batch_kernel_time": (C.c_int, [vp, i32, _P(C.c_char_p), _P(C.c_float)]),
         "ambi_batch_slices": (C.c_int, [vp]),
+        "ambi_batch_all_count": (C.c_int, [vp, i32, i32, _P(C.c_int64)]),
+        "ambi_batch_all_orders": (C.c_int, [vp, i32, i32, i64, i64, _P(C.c_int64)]),
+        "ambi_batch_all_paths": (C.c_int, [vp, i32, i32, i64, i64, _P(C.c_int32), _P(C.c_int32), i64]),
         "ambi_batch_traffic": (C.c_int, [vp, pi64, pi64, pi64]),
         "ambi_format_path": (i64, [vp, pi32, i32, C.c_char_p, i64]),
         "ambi_translocation_bfb": (C.c_int, [vp, pi32, pi64, i32, pi32, i32]),
@@ -358,6 +361,28 @@ class Batch:
     def set_timing(self, on=True):
         self.lib.ambi_batch_set_timing(self.h, 1 if on else 0)
 
+    def all_orders(self, u, pass_):
+        """--all: indices of the valid orders of pass 0 (first orientation) / 1 (flipped), in print order."""
+        n = C.c_int64()
+        self._ck(self.lib.ambi_batch_all_count(self.h, u, pass_, C.byref(n)), "all_count")
+        out = np.zeros(max(n.value, 1), np.int64)
+        if n.value:
+            self._ck(self.lib.ambi_batch_all_orders(self.h, u, pass_, 0, n.value, out.ctypes.data_as(_P(C.c_int64))), "all_orders")
+        return out[:n.value]
+
+    def all_paths(self, u, pass_, first, count, stride):
+        """--all: the paths of valid orders [first, first+count) of the pass (list of int32 arrays)."""
+        lengths = np.zeros(max(count, 1), np.int32)
+        cells = np.zeros(max(count * stride, 1), np.int32)
+        self._ck(self.lib.ambi_batch_all_paths(self.h, u, pass_, first, count, lengths.ctypes.data_as(_P(C.c_int32)),
+                                               cells.ctypes.data_as(_P(C.c_int32)), stride), "all_paths")
+        out = []
+        for j in range(count):
+            if lengths[j] < 0:
+                raise AmbiError(self.lib, int(lengths[j]), "all_paths")
+            out.append(cells[j * stride: j * stride + lengths[j]].copy())
+        return out
+
     def slices(self):
         return int(self.lib.ambi_batch_slices(self.h))
 
@@ -473,7 +498,17 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
             log.append(g.format_path(path))
         else:
             log += ["Declare done", "ILP formula done", "Variable constrains done"]   # BFB_ILP progress lines
-            log.append(g.format_path(path))
+            if all_ and r["status"] == ST_OK:
+                # --all: one line per valid order, first orientation then (if it was run) the flipped one (LGM.cpp:3672-3695)
+                st["all_paths"] = []
+                for pass_ in (0, 1):
+                    idx = b.all_orders(c, pass_)
+                    for lo in range(0, len(idx), 64):
+                        for p_all in b.all_paths(c, pass_, lo, min(64, len(idx) - lo), 2 * len(path) + 64):
+                            st["all_paths"].append(p_all.tolist())
+                            log.append(g.format_path(p_all))
+            else:
+                log.append(g.format_path(path))
             if r["status"] == ST_INFEASIBLE:
                 log.append("ILP is unsolvable.")
             elif r["indel_printed"]:

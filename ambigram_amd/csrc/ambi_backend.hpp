@@ -41,6 +41,11 @@ class Backend {
     virtual const std::vector<KernelTime>& kernel_times() = 0;
     virtual int64_t order_bytes_written() const = 0;
     virtual int slice_count() const { return 1; }   // launches of every kernel per run
+    // --all (run with FLAG_ALL, after wait): valid orders of pass 0 (first orientation) / pass 1 (flipped orientation,
+    // empty unless the last order of pass 0 is invalid), and the paths of a range of them (cells: count x stride int32)
+    virtual int all_count(int unit, int pass, int64_t* count) = 0;
+    virtual int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) = 0;
+    virtual int all_paths(int unit, int pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells, int64_t stride) = 0;
 };
 
 Backend* make_backend();   // defined by the linked backend

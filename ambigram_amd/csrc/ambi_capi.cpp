@@ -199,7 +199,6 @@ int ambi_batch_upload(ambi_batch_t* b) {
 int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream) {
     if (!b) return AMBI_ERR_ARG;
     if (!b->uploaded) return AMBI_ERR_STATE;
-    if (flags & AMBI_FLAG_ALL) return AMBI_ERR_UNSUPPORTED;   // --all (every valid order) is not on the device yet: refuse, never guess
     b->downloaded = false;
     return b->be->run(flags, hip_stream);
 }
@@ -306,6 +305,19 @@ int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, i
 int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out) {
     if (!b || !b->uploaded || !out) return AMBI_ERR_ARG;
     return b->be->copy_orders(unit, first, count, out);
+}
+int ambi_batch_all_count(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t* count) {
+    if (!b || !b->uploaded || !count) return AMBI_ERR_ARG;
+    return b->be->all_count(unit, pass, count);
+}
+int ambi_batch_all_orders(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int64_t* order_idx) {
+    if (!b || !b->uploaded || (!order_idx && count > 0)) return AMBI_ERR_ARG;
+    return b->be->all_orders(unit, pass, first, count, order_idx);
+}
+int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells,
+                         int64_t stride) {
+    if (!b || !b->uploaded || !lengths || !cells) return AMBI_ERR_ARG;
+    return b->be->all_paths(unit, pass, first, count, lengths, cells, stride);
 }
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on) { if (!b) return AMBI_ERR_ARG; b->be->set_timing(on != 0); return 0; }
 int ambi_batch_slices(const ambi_batch_t* b) { return b ? b->be->slice_count() : AMBI_ERR_ARG; }

@@ -1,18 +1,22 @@
 // ambi_engine.hip -- the HIP (gfx950 / MI355X) backend: kernels + stream orchestration.
 //
-// Kernels (all integer / index work, no MFMA; bound by HBM traffic of the order table and by LDS latency):
-//   ambi_prepare_kernel    1 wave  / unit   junction records staged into LDS by coalesced loads; getJuncCN, bias,
-//                                           getIndelBias, targetCN, constructDAG; order-ideal lattice by
-//                                           level-synchronous frontier expansion; R
-//   ambi_plan_kernel       1 block / batch  64-bit scans: order-table offsets, enumerate work blocks
-//   ambi_enumerate_kernel  1 wave  / block of 64*T ranks: unrank + lexicographic successor per lane, rows staged in an
-//                                           LDS tile, written to HBM with 16-byte coalesced stores   <- HBM-bound
-//   ambi_first_kernel      1 wave  / unit   getBFB scan for the first valid order, bkp in LDS
-//   ambi_search_kernel     1 wave  / chunk of orders (only for units whose scan budget ran out)
-//   ambi_finish_kernel     1 block / unit   bkp -> path (LDS int16), indelBFB, output junctions
-//   ambi_pack_*            end-of-batch packing of the paths for the RCCL gather
+// Kernels (all integer / index work, no MFMA; bound by HBM writes of the order table and by LDS latency / issue):
+//   ambi_prepare_kernel           1 wave  / unit   junction ends staged into LDS; getJuncCN, bias, getIndelBias,
+//                                                  targetCN, constructDAG; order-ideal lattice (level-synchronous
+//                                                  search in LDS), completion counts, frozen automaton; R
+//   ambi_plan_kernel              1 block / slice  64-bit scans: order-table offsets, enumerate work blocks
+//   ambi_blocks_build_kernel      1 block / unit   block-emission image (block directory + suffix rows) -> HBM
+//   ambi_enumerate_blocks_kernel  1 block / work block: image -> LDS, rows streamed block by block with fully
+//                                                  coalesced 16-byte stores                       <- HBM-bound
+//   ambi_enumerate_kernel         general path (per-lane unrank + lexicographic successor) for units whose image
+//                                                  does not fit the LDS budget
+//   ambi_first_kernel             1 wave  / unit   getBFB scan for the first valid order, bkp in LDS
+//   ambi_search/resolve_kernel    1 wave  / chunk of orders (only for units whose scan budget ran out)
+//   ambi_finish_kernel            1 block / unit   bkp -> path (LDS int16), indelBFB, output junctions
+//   ambi_pack_*                   optional end-of-batch packing of the paths for an RCCL gather
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -325,6 +329,42 @@ __global__ __launch_bounds__(64) void ambi_resolve_kernel(BatchArgs A, SearchArg
     }
 }
 
+// --all (LGM.cpp:3672-3685): every order of one unit is evaluated in one orientation; valid[n] = 1 valid, 0 not,
+// 2 = the reference's behaviour is undefined on this order.  One wave per chunk of orders.
+__global__ __launch_bounds__(256) void ambi_valid_kernel(BatchArgs A, int u, int forward, int chunk, int wave_lds, uint8_t* valid) {
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint8_t* work = ambi_lds + (size_t)wave * wave_lds;
+    WaveGroup g;
+    const UnitIn& U = A.units[u];
+    const int64_t R = unit_out(A.results, u)->num_orders;
+    const int64_t first = ((int64_t)blockIdx.x * wpb + wave) * chunk;
+    if (first >= R) return;
+    FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+    load_first_work(g, A, u, W);
+    for (int64_t n = first; n < first + chunk && n < R; n++) {
+        int L = 0;
+        const int v = eval_indexed(g, A, u, W, n, forward != 0, &L);
+        if (g.tid() == 0) valid[n] = (uint8_t)(v == 1 ? 1 : (v == 0 ? 0 : 2));
+        g.sync();
+    }
+}
+// Paths of a list of orders of one unit (the valid ones, in print order): one wave per order, breakpoints in LDS,
+// the expanded path (absolute signed ids) straight to cells[j * stride ...], its length to lengths[j].
+__global__ __launch_bounds__(64) void ambi_order_paths_kernel(BatchArgs A, int u, int forward, const int64_t* order_idx, int32_t* lengths,
+                                                              int32_t* cells, int64_t stride) {
+    WaveGroup g;
+    const UnitIn& U = A.units[u];
+    const int j = blockIdx.x;
+    FirstWork W = carve_first(ambi_lds, U.n_seg, U.bkp_cap);
+    int32_t* offs = reinterpret_cast<int32_t*>(ambi_lds + first_work_bytes(U.n_seg, U.bkp_cap));
+    load_first_work(g, A, u, W);
+    int L = 0;
+    const int v = eval_indexed(g, A, u, W, order_idx[j], forward != 0, &L);
+    int P = -1;
+    if (v == 1) P = expand_bkp(g, W.bkp, L, (cell_t*)nullptr, (int)(stride < U.path_cap ? stride : U.path_cap), offs, cells + (int64_t)j * stride, U.seg_base);
+    if (g.tid() == 0) lengths[j] = P;
+}
+
 __global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
@@ -397,6 +437,8 @@ class HipBackend : public Backend {
     hipEvent_t ev_fork_ = nullptr;
     std::vector<hipEvent_t> ev_join_, ev_stage_;
     bool stagger_ = true;
+    std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit
+    bool all_done_ = false;
     int enum_grid_ = 2048;
 
     void free_all() {
@@ -627,6 +669,7 @@ class HipBackend : public Backend {
         if (!uploaded_) return -32;
         stream_ = (hipStream_t)stream;
         bind(flags);
+        all_done_ = false;
         const int U = A_.n_units;
         HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
         (void)hipMemsetAsync(d_fallback_, 0, sizeof(int32_t) * (size_t)U, stream_);
@@ -725,6 +768,11 @@ class HipBackend : public Backend {
             if (rc) return rc;
             *h_npending_ = 0;
         }
+        if ((A_.flags & FLAG_ALL) && !all_done_) {
+            int rc = compute_all();
+            if (rc) return rc;
+            all_done_ = true;
+        }
         if (timing_ && timed_runs_ > 0) {
             // average duration of ONE launch of every kernel over the slices and the slots filled since timing was
             // switched on (every run launches each kernel once per slice)
@@ -801,6 +849,87 @@ class HipBackend : public Backend {
     const std::vector<KernelTime>& kernel_times() override { return times_; }
     int64_t order_bytes_written() const override { return last_needed_; }
     int slice_count() const override { return n_slices_; }
+
+    // ---- --all (LGM.cpp:3672-3695): every valid order of every unit, in the reference's print order ----
+    // pass 0 = the first orientation (forward unless --reversed), pass 1 = the flipped one, run only when the LAST
+    // order of pass 0 is invalid (LGM.cpp:3691-3695).  Host-driven, at wait(): validity map per pass, index lists kept
+    // on the host; the paths are produced on demand by all_paths().
+    int compute_all() {
+        const int U = (int)hb_.units.size();
+        std::vector<UnitOut> hdr(U);
+        HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));
+        all_idx_[0].assign(U, {}); all_idx_[1].assign(U, {});
+        const bool fwd0 = !(A_.flags & FLAG_REVERSED);
+        const int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1, chunk = 16;
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_valid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, waves * lds_first_));
+        for (int u = 0; u < U; u++) {
+            if (hdr[u].status != ST_OK) continue;   // (no valid order: both passes were scanned already, the lists stay empty)
+            const int64_t R = hdr[u].num_orders;
+            if (R <= 0 || hdr[u].order_off < 0) continue;
+            uint8_t* d_valid = nullptr;
+            HIP_CK(hipMalloc((void**)&d_valid, (size_t)R));
+            std::vector<uint8_t> v((size_t)R);
+            int evaluated = 0, status = hdr[u].status;
+            for (int pass = 0; pass < 2; pass++) {
+                const bool fwd = pass == 0 ? fwd0 : !fwd0;
+                int64_t nblk = (R + (int64_t)waves * chunk - 1) / ((int64_t)waves * chunk);
+                hipLaunchKernelGGL(ambi_valid_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * lds_first_, stream_, A_, u, fwd ? 1 : 0, chunk,
+                                   lds_first_, d_valid);
+                HIP_CK(hipGetLastError());
+                HIP_CK(hipMemcpyAsync(v.data(), d_valid, (size_t)R, hipMemcpyDeviceToHost, stream_));
+                HIP_CK(hipStreamSynchronize(stream_));
+                evaluated += (int)R;
+                for (int64_t n = 0; n < R; n++) {
+                    if (v[n] == 1) all_idx_[pass][u].push_back(n);
+                    else if (v[n] == 2) status = ST_ERR_REF_UB;   // the reference reads out of bounds here: refuse
+                }
+                if (v[R - 1] == 1) break;   // the flip happens only when the last order is invalid
+            }
+            (void)hipFree(d_valid);
+            // header: all orders of the executed passes were evaluated
+            HIP_CK(hipMemcpy(reinterpret_cast<uint8_t*>(d_results_) + sizeof(UnitOut) * (size_t)u + offsetof(UnitOut, evaluated), &evaluated,
+                             sizeof(int32_t), hipMemcpyHostToDevice));
+            if (status != hdr[u].status)
+                HIP_CK(hipMemcpy(reinterpret_cast<uint8_t*>(d_results_) + sizeof(UnitOut) * (size_t)u + offsetof(UnitOut, status), &status,
+                                 sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+    int all_count(int unit, int pass, int64_t* count) override {
+        if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) { if (count) *count = 0; return unit < 0 || pass < 0 || pass > 1 ? ST_ERR_BAD_INPUT : 0; }
+        if (count) *count = (int64_t)all_idx_[pass][unit].size();
+        return 0;
+    }
+    int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) override {
+        if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
+        const auto& v = all_idx_[pass][unit];
+        if (first < 0 || count < 0 || first + count > (int64_t)v.size()) return ST_ERR_BAD_INPUT;
+        for (int64_t i = 0; i < count; i++) idx[i] = v[first + i];
+        return 0;
+    }
+    int all_paths(int unit, int pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells, int64_t stride) override {
+        if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
+        const auto& v = all_idx_[pass][unit];
+        if (first < 0 || count < 0 || first + count > (int64_t)v.size() || stride <= 0) return ST_ERR_BAD_INPUT;
+        if (count == 0) return 0;
+        const UnitIn& Uin = hb_.units[unit];
+        const bool fwd0 = !(A_.flags & FLAG_REVERSED), fwd = pass == 0 ? fwd0 : !fwd0;
+        int64_t* d_idx = nullptr; int32_t* d_len = nullptr; int32_t* d_cells = nullptr;
+        HIP_CK(hipMalloc((void**)&d_idx, (size_t)count * sizeof(int64_t)));
+        HIP_CK(hipMalloc((void**)&d_len, (size_t)count * sizeof(int32_t)));
+        HIP_CK(hipMalloc((void**)&d_cells, (size_t)count * (size_t)stride * sizeof(int32_t)));
+        HIP_CK(hipMemcpy(d_idx, v.data() + first, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice));
+        const int lds = (int)(first_work_bytes(Uin.n_seg, Uin.bkp_cap) + 4ll * (Uin.bkp_cap / 2 + 2) + 16);
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_order_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(ambi_order_paths_kernel, dim3((unsigned)count), dim3(64), lds, stream_, A_, unit, fwd ? 1 : 0, (const int64_t*)d_idx, d_len,
+                           d_cells, stride);
+        HIP_CK(hipGetLastError());
+        HIP_CK(hipMemcpyAsync(lengths, d_len, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CK(hipMemcpyAsync(cells, d_cells, (size_t)count * (size_t)stride * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CK(hipStreamSynchronize(stream_));
+        (void)hipFree(d_idx); (void)hipFree(d_len); (void)hipFree(d_cells);
+        return 0;
+    }
 };
 
 Backend* make_backend() { return new HipBackend(); }

@@ -234,7 +234,7 @@ AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int p
         const int a = bkp[2 * j], o0 = offs[j], len = offs[j + 1] - o0;
         for (int k = lane; k < len; k += lanes) {
             const int v = a + k;
-            path[o0 + k] = (cell_t)v;
+            if (path) path[o0 + k] = (cell_t)v;
             if (gpath) gpath[o0 + k] = v > 0 ? v + seg_base : v - seg_base;
         }
     }

@@ -80,7 +80,6 @@ int main(int argc, char** argv) {
     auto t_begin = std::chrono::steady_clock::now();
     const std::string lh = A.kv["in_lh"], prefix = A.kv["lp_prefix"], juncs = A.kv.count("juncdb") ? A.kv["juncdb"] : "";
     const bool junc_info = truthy(A.kv["junc_info"]), reversed = truthy(A.kv["reversed"]), all = truthy(A.kv["all"]);
-    if (all) return die("--all is not supported by the MI355X engine yet");
 
     ambi_graph_t* g = nullptr;
     int rc = ambi_graph_read_lh(lh.c_str(), &g);
@@ -133,7 +132,8 @@ int main(int argc, char** argv) {
             if (rc < 0) return die(ambi_error_string(rc));
         }
         ambi_batch_destroy(probe);
-        if ((rc = ambi_batch_upload(b)) != 0 || (rc = ambi_batch_run(b, reversed ? AMBI_FLAG_REVERSED : 0, nullptr)) != 0 ||
+        if ((rc = ambi_batch_upload(b)) != 0 ||
+            (rc = ambi_batch_run(b, (reversed ? AMBI_FLAG_REVERSED : 0u) | (all ? AMBI_FLAG_ALL : 0u), nullptr)) != 0 ||
             (rc = ambi_batch_download(b)) != 0)
             return die(std::string("engine: ") + ambi_error_string(rc));
         ambi_unit_result_t r; ambi_batch_unit_result(b, 0, &r);
@@ -141,7 +141,26 @@ int main(int argc, char** argv) {
         std::vector<int32_t> p(r.path_len), q(r.path_indel_len);
         ambi_batch_unit_path(b, 0, 0, p.data(), r.path_len);
         ambi_batch_unit_path(b, 0, 1, q.data(), r.path_indel_len);
-        std::cout << path_text(g, p) << std::endl;                                   // printBFB (LGM.cpp:3411-3429)
+        if (all && r.status == AMBI_ST_OK) {
+            // --all: one line per valid order; the flipped orientation only if the last order was invalid (LGM.cpp:3672-3695)
+            const int64_t stride = 2ll * r.path_len + 64;
+            for (int pass = 0; pass < 2; pass++) {
+                int64_t nv = 0;
+                ambi_batch_all_count(b, 0, pass, &nv);
+                for (int64_t lo = 0; lo < nv; lo += 64) {
+                    const int64_t cnt = nv - lo < 64 ? nv - lo : 64;
+                    std::vector<int32_t> len((size_t)cnt), cells((size_t)(cnt * stride));
+                    if ((rc = ambi_batch_all_paths(b, 0, pass, lo, cnt, len.data(), cells.data(), stride)) != 0)
+                        return die(std::string("bfb --all: ") + ambi_error_string(rc));
+                    for (int64_t j = 0; j < cnt; j++) {
+                        if (len[j] < 0) return die(std::string("bfb --all: ") + ambi_error_string(len[j]));
+                        std::vector<int32_t> pj(cells.begin() + j * stride, cells.begin() + j * stride + len[j]);
+                        std::cout << path_text(g, pj) << std::endl;
+                    }
+                }
+            }
+        } else
+            std::cout << path_text(g, p) << std::endl;                               // printBFB (LGM.cpp:3411-3429)
         if (r.status == AMBI_ST_INFEASIBLE) std::cout << "ILP is unsolvable.\n";    // localhap.cpp:217
         else if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(g, q) << std::endl;
         paths[c] = q;

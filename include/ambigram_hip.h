@@ -156,6 +156,17 @@ int ambi_batch_unit_prepare(const ambi_batch_t* b, int32_t unit, double* junc_cn
 /* DAG of the unit: node2pat / node2loop as [K][3] (absolute ids; a==0 empty), successor bit masks [K] */
 int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, int32_t* node2loop, uint64_t* succ);
 int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap);
+/* --all (localhap.cpp:38, LocalGenomicMap.cpp:3672-3695): after ambi_batch_run(b, AMBI_FLAG_ALL, ...) + wait, every
+ * valid order of a unit in the reference's print order.  pass 0 = the first orientation (forward unless
+ * AMBI_FLAG_REVERSED), pass 1 = the flipped orientation, which the reference runs only when the LAST order of pass 0
+ * is invalid (count 0 otherwise).  all_orders: indices into the order table; all_paths: the expanded paths (absolute
+ * signed ids) of valid orders [first, first+count) of the pass, cells[j*stride ...], lengths[j] (negative: capacity).
+ * The unit's ordinary results (first valid order, path, indelBFB, output junctions) are those of the default mode;
+ * ambi_unit_result_t.evaluated counts every order of the executed passes. */
+int ambi_batch_all_count(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t* count);
+int ambi_batch_all_orders(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int64_t* order_idx);
+int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells,
+                         int64_t stride);
 /* Copies rows [first,first+count) of the unit's order table (count x K uint8) from the device. */
 int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out);
 

@@ -219,3 +219,34 @@ def check_large_lattice(lib, oracle, workdir, K=50, k2=5):
         assert neq.any(axis=1).all() and (a[ii, fi] < bb[ii, fi]).all()
     assert b.unit_path(0, 0).tolist() == oc["path"] and b.unit_path(0, 1).tolist() == oc["path_indel"]
     b.close(); g.close()
+
+
+def check_all_mode(lib, oracle, workdir, seeds=range(40)):
+    """--all (LGM.cpp:3672-3695): every valid order is reported, in the reference's print order, with the orientation
+    flip only when the last order of the first pass is invalid; `evaluated` counts every order of the executed passes."""
+    bad = {}
+    for name, lh, sols in cases.fixed_cases() + cases.synthetic_cases(workdir, small_only=True)[:8]:
+        for rev in (False, True):
+            d = parity.compare(lib, oracle, lh, sols, reversed_=rev, all_=True, keep_orders=False)
+            if d:
+                bad[name + ("/reversed" if rev else "")] = d
+    stats = dict(flipped=0, multi=0, none=0)
+    for seed in seeds:
+        lh, sols = cases.random_decomposition(workdir, seed)
+        for rev in (False, True):
+            o = oracle.run_bfb(lh, sols, reversed_=rev, all_=True)
+            assert o["ok"], o["err"]
+            oc = o["chr"][0]
+            if oc["shortcut"] or oc["ub"]:
+                continue
+            d = parity.compare(lib, oracle, lh, sols, reversed_=rev, all_=True, keep_orders=False)
+            if oc["first_valid"] < 0:
+                # no valid order: the engine reports the status, the oracle an empty path
+                stats["none"] += 1
+                continue
+            if d:
+                bad["random%d%s" % (seed, "/reversed" if rev else "")] = d
+            stats["multi"] += len(oc["all_paths"]) > 1
+            stats["flipped"] += oc["evaluated"] > oc["num_orders"]
+    assert not bad, bad
+    return stats

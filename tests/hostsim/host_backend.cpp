@@ -169,6 +169,71 @@ class HostSimBackend : public Backend {
             std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, U.path_cap, U.out_cap));
             stage_finish(g, A_, u, work.data());
         }
+        if (flags & FLAG_ALL) compute_all();
+        return 0;
+    }
+    // --all: same protocol as the HIP backend (validity of every order per pass, lists on the host)
+    std::vector<std::vector<int64_t>> all_idx_[2];
+    void compute_all() {
+        HostGroup g;
+        const int Un = (int)units_.size();
+        all_idx_[0].assign(Un, {}); all_idx_[1].assign(Un, {});
+        const bool fwd0 = !(A_.flags & FLAG_REVERSED);
+        for (int u = 0; u < Un; u++) {
+            UnitOut* out = unit_out(A_.results, u);
+            if (out->status != ST_OK || out->num_orders <= 0 || out->order_off < 0) continue;
+            const UnitIn& U = units_[u];
+            std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
+            FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+            load_first_work(g, A_, u, W);
+            const int64_t R = out->num_orders;
+            int evaluated = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                const bool fwd = pass == 0 ? fwd0 : !fwd0;
+                int last = 0;
+                for (int64_t n = 0; n < R; n++) {
+                    int L = 0;
+                    const int v = eval_indexed(g, A_, u, W, n, fwd, &L);
+                    if (v == 1) all_idx_[pass][u].push_back(n);
+                    else if (v < 0) out->status = ST_ERR_REF_UB;
+                    last = v;
+                }
+                evaluated += (int)R;
+                if (last == 1) break;
+            }
+            out->evaluated = evaluated;
+        }
+    }
+    int all_count(int unit, int pass, int64_t* count) override {
+        if (pass < 0 || pass > 1 || unit < 0) return ST_ERR_BAD_INPUT;
+        if (count) *count = unit < (int)all_idx_[pass].size() ? (int64_t)all_idx_[pass][unit].size() : 0;
+        return 0;
+    }
+    int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) override {
+        if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
+        const auto& v = all_idx_[pass][unit];
+        if (first < 0 || count < 0 || first + count > (int64_t)v.size()) return ST_ERR_BAD_INPUT;
+        for (int64_t i = 0; i < count; i++) idx[i] = v[first + i];
+        return 0;
+    }
+    int all_paths(int unit, int pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells, int64_t stride) override {
+        if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
+        const auto& v = all_idx_[pass][unit];
+        if (first < 0 || count < 0 || first + count > (int64_t)v.size() || stride <= 0) return ST_ERR_BAD_INPUT;
+        HostGroup g;
+        const UnitIn& U = units_[unit];
+        std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
+        std::vector<int32_t> offs((size_t)U.bkp_cap / 2 + 2);
+        FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+        load_first_work(g, A_, unit, W);
+        const bool fwd0 = !(A_.flags & FLAG_REVERSED), fwd = pass == 0 ? fwd0 : !fwd0;
+        for (int64_t j = 0; j < count; j++) {
+            int L = 0;
+            const int ok = eval_indexed(g, A_, unit, W, v[first + j], fwd, &L);
+            lengths[j] = ok == 1 ? expand_bkp(g, W.bkp, L, (cell_t*)nullptr, (int)(stride < U.path_cap ? stride : U.path_cap), offs.data(),
+                                              cells + j * stride, U.seg_base)
+                                 : -1;
+        }
         return 0;
     }
     int wait() override { return 0; }

@@ -53,6 +53,8 @@ def compare(lib, oracle, lh, sols, juncs="", reversed_=False, all_=False, keep_o
         for k in ["bkp", "path", "path_indel"]:
             if oc[k] != ec[k]:
                 diffs.append("chr %d %s differs (len %d vs %d)" % (c, k, len(oc[k]), len(ec[k])))
+        if all_ and oc["all_paths"] != ec.get("all_paths"):
+            diffs.append("chr %d --all paths differ (%d vs %d valid orders)" % (c, len(oc["all_paths"]), len(ec.get("all_paths") or [])))
         if oc["indel_printed"] != ec["indel_printed"]:
             diffs.append("chr %d indel_printed differs" % c)
     if [tuple(x) for x in o["out_juncs"]] != e["out_juncs"]:

@@ -61,6 +61,14 @@ def check_readme(exe, cwd, oracle):
     fake_cbc(bindir, [os.path.join(DATA, "readme6.sol")])
     r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "readme", "--reversed", "true")
     assert r.stdout.splitlines()[-1] == "6-5-4-3-2-1-|1+2+3+4+5+6+|6-5-4-3-2-|2+3+4+|4-3-|3+4+|4-3-2-|2+3+4+5+6+"
+    # --all: one line per valid order, the oracle's stdout line for line
+    for extra in ([], ["--reversed", "true"]):
+        fake_cbc(bindir, [os.path.join(DATA, "readme6.sol")])
+        r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "readme", "--all", "true", *extra)
+        assert r.returncode == 0, r.stderr
+        want = oracle.run_bfb(lh, [os.path.join(DATA, "readme6.sol")], all_=True, reversed_=bool(extra))["log"]
+        got = [l for l in r.stdout.splitlines() if not l.startswith("fake cbc")]
+        assert got == want and len(got) > 5
 
 
 def check_trx(exe, cwd, oracle):

@@ -155,3 +155,8 @@ def test_cli_on_gpu(hip_lib, oracle, tmp_path):
 
 def test_large_lattice(hip_lib, oracle, workdir):
     ec.check_large_lattice(hip_lib, oracle, workdir, K=50, k2=5)
+
+
+def test_all_mode(hip_lib, oracle, workdir):
+    st = ec.check_all_mode(hip_lib, oracle, workdir, seeds=range(60))
+    assert st["multi"] > 0, st

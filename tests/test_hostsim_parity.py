@@ -38,3 +38,8 @@ def test_enumerate_variants(hostsim_lib, oracle, workdir):
 
 def test_large_lattice(hostsim_lib, oracle, workdir):
     ec.check_large_lattice(hostsim_lib, oracle, workdir, K=50, k2=5)
+
+
+def test_all_mode(hostsim_lib, oracle, workdir):
+    st = ec.check_all_mode(hostsim_lib, oracle, workdir)
+    assert st["multi"] > 0, st
