@@ -88,6 +88,7 @@ def _declare(L):
         "ambi_format_path": (i64, [vp, pi32, i32, C.c_char_p, i64]),
         "ambi_translocation_bfb": (C.c_int, [vp, pi32, pi64, i32, pi32, i32]),
         "ambi_ilp_build": (C.c_int, [vp, i32, pd, pd, i32, C.c_double, i32, _P(vp)]),
+        "ambi_ilp_build_device": (C.c_int, [vp, i32, pd, pd, i32, C.c_double, i32, _P(C.c_float), _P(vp)]),
         "ambi_ilp_destroy": (None, [vp]),
         "ambi_ilp_sizes": (C.c_int, [vp, pi64, pi64, pi32, pi32]),
         "ambi_ilp_copy": (C.c_int, [vp, pi64, pi32, pd, pd, pd, pd, pd, pd]),
@@ -544,13 +545,21 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
 class IlpModel:
     """ILP of one chromosome (BFB_ILP, LGM.cpp:4397-4752) built on the host in closed form."""
 
-    def __init__(self, lib, graph, chr_, seg_cn, junc_cn, bias, max_cn_total, juncs_info=False):
+    def __init__(self, lib, graph, chr_, seg_cn, junc_cn, bias, max_cn_total, juncs_info=False, device=False):
+        """device=True: the entries are written by ambi_ilp_fill_kernel on the GPU (kernel_ms = its mean device time)."""
         self.lib = lib
         self.h = C.c_void_p()
+        self.kernel_ms = None
         sc = np.ascontiguousarray(seg_cn, np.float64)
         jc = np.ascontiguousarray(np.asarray(junc_cn, np.float64).reshape(-1))
-        rc = lib.ambi_ilp_build(graph.h, chr_, sc.ctypes.data_as(_P(C.c_double)), jc.ctypes.data_as(_P(C.c_double)), int(bias),
-                                float(max_cn_total), 1 if juncs_info else 0, C.byref(self.h))
+        if device:
+            ms = C.c_float()
+            rc = lib.ambi_ilp_build_device(graph.h, chr_, sc.ctypes.data_as(_P(C.c_double)), jc.ctypes.data_as(_P(C.c_double)), int(bias),
+                                           float(max_cn_total), 1 if juncs_info else 0, C.byref(ms), C.byref(self.h))
+            self.kernel_ms = ms.value
+        else:
+            rc = lib.ambi_ilp_build(graph.h, chr_, sc.ctypes.data_as(_P(C.c_double)), jc.ctypes.data_as(_P(C.c_double)), int(bias),
+                                    float(max_cn_total), 1 if juncs_info else 0, C.byref(self.h))
         if rc != 0:
             raise AmbiError(lib, rc, "ilp_build")
         r, z, c, i = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()

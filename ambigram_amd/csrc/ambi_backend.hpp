@@ -50,4 +50,10 @@ class Backend {
 
 Backend* make_backend();   // defined by the linked backend
 
+// ILP entries (ambi_ilp_rows.hpp) written by the linked backend: the HIP engine launches ambi_ilp_fill_kernel and copies
+// col/val back, the host simulation runs the same entry function on the CPU.  kernel_ms: device time of the fill (0 on the host).
+struct IlpRowDesc;
+int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_ptr, int start_id, int end_id, const int32_t* lit_col,
+                     const double* lit_val, int64_t n_lit, int32_t* col, double* val, float* kernel_ms);
+
 }  // namespace ambi

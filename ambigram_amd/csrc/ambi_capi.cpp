@@ -360,6 +360,7 @@ int ambi_translocation_bfb(const ambi_graph_t* g, int32_t* paths, const int64_t*
 
 // ---- ILP model of one chromosome (host; LocalGenomicMap::BFB_ILP, LGM.cpp:4397-4752) ----
 #include "ambi_ilp.hpp"
+#include "ambi_ilp_rows.hpp"
 struct ambi_ilp { ambi::IlpModel m; };
 
 extern "C" {
@@ -376,6 +377,24 @@ int ambi_ilp_build(const ambi_graph_t* g, int32_t chr, const double* seg_cn, con
     ambi_ilp* p = new ambi_ilp();
     ambi::build_bfb_ilp(s, e, cn.data(), fold.data(), bias, max_cn_total, comps, juncs_info != 0, p->m);
     *out = p;
+    return 0;
+}
+int ambi_ilp_build_device(const ambi_graph_t* g, int32_t chr, const double* seg_cn, const double* junc_cn, int32_t bias,
+                          double max_cn_total, int32_t juncs_info, float* kernel_ms, ambi_ilp_t** out) {
+    if (!g || !seg_cn || !junc_cn || !out || chr < 0 || chr >= g->g.n_chr()) return AMBI_ERR_ARG;
+    const int s = g->g.source_ids[chr], e = g->g.sink_ids[chr], n = e - s + 1;
+    std::vector<double> cn(n), fold(n);
+    for (int i = 0; i < n; i++) { cn[i] = seg_cn[i + 1]; fold[i] = junc_cn[2 * (i + 1) + 1]; }
+    std::vector<std::vector<int32_t>> comps;
+    for (auto& c : g->g.components)
+        if (!c.empty() && c[0] >= 1 && c[0] <= g->g.n_seg() && g->g.seg_partition[c[0] - 1] == chr) comps.push_back(c);
+    std::unique_ptr<ambi_ilp> p(new ambi_ilp());
+    std::vector<ambi::IlpRowDesc> rows; std::vector<int32_t> lc; std::vector<double> lv;
+    ambi::build_bfb_ilp_rows(s, e, cn.data(), fold.data(), bias, max_cn_total, comps, juncs_info != 0, p->m, rows, lc, lv);
+    int rc = ambi::backend_ilp_fill(rows.data(), (int64_t)rows.size(), p->m.row_ptr.data(), s, e, lc.data(), lv.data(), (int64_t)lc.size(),
+                                    p->m.col.data(), p->m.val.data(), kernel_ms);
+    if (rc) return rc;
+    *out = p.release();
     return 0;
 }
 void ambi_ilp_destroy(ambi_ilp_t* p) { delete p; }

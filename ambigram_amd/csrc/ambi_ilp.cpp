@@ -1,5 +1,6 @@
 // ambi_ilp.cpp -- see ambi_ilp.hpp
 #include "ambi_ilp.hpp"
+#include "ambi_ilp_rows.hpp"
 
 #include <cfloat>
 #include <cstdio>
@@ -107,6 +108,62 @@ void build_bfb_ilp(int s, int e, const double* seg_cn, const double* fold_cn, in
         end_row(0, 5);
     }
     // -- bounds, objective (LGM.cpp:4708-4747)
+    m.col_lo.assign(num_var, 0); m.col_up.assign(num_var, INF); m.obj.assign(num_var, 0);
+    for (int c = 0; c < num_pat; c++) m.col_up[c] = 1;
+    for (int c = num_pat; c < num_el; c++) m.col_up[c] = max_cn_total;
+    for (int c = num_el; c < num_var - 1; c++) m.obj[c] = 1;
+    m.col_lo[num_var - 1] = m.col_up[num_var - 1] = bias;
+    m.obj[num_var - 1] = -1;
+}
+
+// The same model as ROW DESCRIPTORS (ambi_ilp_rows.hpp): everything except col/val, which the caller fills entry by
+// entry with ilp_row_entry -- on the GPU with one thread per non-zero.  O(rows) on the host.
+void build_bfb_ilp_rows(int s, int e, const double* seg_cn, const double* fold_cn, int bias, double max_cn_total,
+                        const std::vector<std::vector<int32_t>>& components, bool juncs_info, IlpModel& m,
+                        std::vector<IlpRowDesc>& rows, std::vector<int32_t>& lit_col, std::vector<double>& lit_val) {
+    const double INF = DBL_MAX;
+    const IlpGeom G = ilp_geom(s, e);
+    const int n = G.n, num_pat = G.num_pat, num_el = G.num_el, num_var = num_el + 2 * n + 1;
+    m = IlpModel();
+    m.n_cols = num_var;
+    m.n_int = num_el;
+    rows.clear(); lit_col.clear(); lit_val.clear();
+    m.row_ptr.push_back(0);
+    auto row = [&](int family, int a, int b, int rep, double lo, double up) {
+        IlpRowDesc d{family, a, b, rep};
+        rows.push_back(d);
+        m.row_ptr.push_back(m.row_ptr.back() + ilp_row_len(d, G));
+        m.row_lo.push_back(lo); m.row_up.push_back(up);
+    };
+    for (int i = s; i <= e; i++) {
+        const int k = i - s;
+        row(ILP_CN, i, 0, 0, seg_cn[k], INF); row(ILP_CN, i, 0, 1, -INF, seg_cn[k]);
+        row(ILP_FB, i, 0, 0, fold_cn[k], INF); row(ILP_FB, i, 0, 1, -INF, fold_cn[k]);
+    }
+    row(ILP_BIAS, 0, 0, 0, bias, bias);
+    for (int a = s; a <= e; a++) for (int b = a; b <= e; b++) {
+        if (a > s || b < e) row(ILP_PA, a, b, 0, 0, INF);
+        if (a < b) row(ILP_PB, a, b, 0, 0, 2);
+    }
+    for (int a = s; a <= e; a++) for (int b = a; b <= e; b++)
+        if (a > s || b < e) row(ILP_LA, a, b, 0, 0, INF);
+    for (int a = s; a <= e; a++) for (int b = a + 1; b <= e; b++) { row(ILP_LL, a, b, 0, 0, 2); row(ILP_LL, a, b, 1, 0, 2); }
+    for (int a = s; a <= e; a++) for (int b = a + 1; b <= e; b++) { row(ILP_PC, a, b, 0, 0, 2); row(ILP_PC, a, b, 1, 0, 2); }
+    if (!components.empty() && juncs_info) {
+        std::set<std::pair<int, int>> seen;
+        for (auto& c : components) {
+            if (c.empty()) continue;
+            int lo = c.front() < c.back() ? c.front() : c.back(), hi = c.front() < c.back() ? c.back() : c.front();
+            if (lo == s && hi == e) continue;
+            if (!seen.insert({lo, hi}).second) continue;
+            bool in = lo >= s && hi <= e;
+            lit_col.push_back(in ? G.L(lo, hi) : 0); lit_val.push_back(1);
+            lit_col.push_back(in ? G.P(lo, hi) : 0); lit_val.push_back(1);
+        }
+        row(ILP_LIT, 0, (int)lit_col.size(), 0, 0, 5);
+    }
+    m.col.assign((size_t)m.row_ptr.back(), 0);
+    m.val.assign((size_t)m.row_ptr.back(), 0.0);
     m.col_lo.assign(num_var, 0); m.col_up.assign(num_var, INF); m.obj.assign(num_var, 0);
     for (int c = 0; c < num_pat; c++) m.col_up[c] = 1;
     for (int c = num_pat; c < num_el; c++) m.col_up[c] = max_cn_total;

@@ -29,6 +29,13 @@ void build_bfb_ilp(int start_id, int end_id, const double* seg_cn, const double*
                    int bias, double max_cn_total, const std::vector<std::vector<int32_t>>& components, bool juncs_info,
                    IlpModel& m);
 
+// Row-descriptor form of the same model (ambi_ilp_rows.hpp): fills everything of `m` except the entries (col/val are
+// sized and zeroed); entry j of row r is ilp_row_entry(rows[r], ...), written by the device kernel or the host loop.
+struct IlpRowDesc;
+void build_bfb_ilp_rows(int start_id, int end_id, const double* seg_cn, const double* junc_cn_fold, int bias, double max_cn_total,
+                        const std::vector<std::vector<int32_t>>& components, bool juncs_info, IlpModel& m,
+                        std::vector<IlpRowDesc>& rows, std::vector<int32_t>& lit_col, std::vector<double>& lit_val);
+
 // CPLEX-LP text readable by `cbc <file>.lp solve solu <file>.sol`; columns are named x<j> as CoinUtils names them
 // (the .sol parser relies on it, localhap.cpp:204-205).  Rows whose lower bound 0 is implied (non-negative variables and
 // coefficients) are written one-sided.

@@ -200,6 +200,12 @@ int ambi_translocation_bfb(const ambi_graph_t* g, int32_t* paths, const int64_t*
 typedef struct ambi_ilp ambi_ilp_t;
 int ambi_ilp_build(const ambi_graph_t* g, int32_t chr, const double* seg_cn, const double* junc_cn, int32_t bias,
                    double max_cn_total, int32_t juncs_info, ambi_ilp_t** out);
+/* The same model with its entries written ON THE DEVICE: the host lists the rows (O(rows)),
+ * ambi_ilp_fill_kernel writes the 12 bytes per non-zero (int32 column + f64 coefficient) with one thread per entry,
+ * the arrays come back to the host.  Bit-identical to ambi_ilp_build.  kernel_ms (optional): mean device time of the
+ * fill kernel, for the roofline (algorithmic bytes = 12 * nnz). */
+int ambi_ilp_build_device(const ambi_graph_t* g, int32_t chr, const double* seg_cn, const double* junc_cn, int32_t bias,
+                          double max_cn_total, int32_t juncs_info, float* kernel_ms, ambi_ilp_t** out);
 void ambi_ilp_destroy(ambi_ilp_t* p);
 int ambi_ilp_sizes(const ambi_ilp_t* p, int64_t* n_rows, int64_t* nnz, int32_t* n_cols, int32_t* n_int);
 /* CSR copy-out; infinity is +-DBL_MAX (OsiClp getInfinity()); any pointer may be NULL */

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../ambigram_amd/csrc/ambi_backend.hpp"
+#include "../../ambigram_amd/csrc/ambi_ilp_rows.hpp"
 #include "../../ambigram_amd/csrc/ambi_stages.hpp"
 
 namespace ambi {
@@ -273,5 +274,12 @@ class HostSimBackend : public Backend {
 };
 
 Backend* make_backend() { return new HostSimBackend(); }
+
+int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_ptr, int s, int e, const int32_t* lit_col, const double* lit_val,
+                     int64_t, int32_t* col, double* val, float* kernel_ms) {
+    ilp_fill_rows(rows, row_ptr, 0, n_rows, 1, ilp_geom(s, e), lit_col, lit_val, 0, 1, col, val);
+    if (kernel_ms) *kernel_ms = 0;
+    return 0;
+}
 
 }  // namespace ambi

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "tests", "data")
 
 
-def _model_from_engine(lib, lh, chr_, juncs, junc_info, run_lib):
+def _model_from_engine(lib, lh, chr_, juncs, junc_info, run_lib, device=False):
     g = api.Graph(lib, lh)
     if juncs:
         g.read_juncs(juncs)
@@ -33,8 +33,15 @@ def _model_from_engine(lib, lh, chr_, juncs, junc_info, run_lib):
     s, e = g.chromosome(chr_)
     prep = b.unit_prepare(chr_, e - s + 1)
     bias = b.unit_result(chr_)["bias"]
-    m = api.IlpModel(lib, g, chr_, prep["seg_cn"], prep["junc_cn"], bias, float(cn_all.sum()), juncs_info=junc_info)
+    m = api.IlpModel(lib, g, chr_, prep["seg_cn"], prep["junc_cn"], bias, float(cn_all.sum()), juncs_info=junc_info, device=device)
     return m
+
+
+def _same_models(a, b):
+    x, y = a.arrays(), b.arrays()
+    assert (a.n_cols, a.n_int, a.n_rows, a.nnz) == (b.n_cols, b.n_int, b.n_rows, b.nnz)
+    for k in x:
+        assert np.array_equal(x[k], y[k]), k
 
 
 def _same(m, o):
@@ -83,3 +90,41 @@ def test_lp_text_is_written(hostsim_lib, workdir):
     text = open(p).read()
     assert "Minimize" in text and "Subject To" in text and "Integers" in text and text.rstrip().endswith("End")
     assert text.count("\nR") >= 140
+
+
+def _row_form_cases(workdir):
+    out = [(os.path.join(DATA, "readme6.lh"), 0, "", False), (os.path.join(DATA, "trx_c2.lh"), 1, "", False)]
+    j = os.path.join(workdir, "r6b.juncs")
+    with open(j, "w") as f:
+        f.write("6+ 6- 5- 4- 3- 2- 2+\n2- 2+ 3+ 4+ 5+ 6+ 6-\n6+ 6- 5- 4- 3-\n")
+    out.append((os.path.join(DATA, "readme6.lh"), 0, j, True))
+    for n, seed in [(1, 7), (2, 8), (9, 1), (33, 3), (64, 5)]:
+        s = synth.make_sample(n, 2 * n + 4, "chain", min(4, n), seed) if n >= 9 else None
+        if s is not None:
+            lh, _ = s.write(workdir, "ilpr%d" % n)
+            out.append((lh, 0, "", False))
+    return out
+
+
+def test_row_descriptor_form_equals_loop_generator(hostsim_lib, workdir):
+    """ambi_ilp_rows.hpp (row list + closed-form entry function, the code the device kernel runs) == the O(nnz) loops."""
+    for lh, c, juncs, ji in _row_form_cases(workdir):
+        _same_models(_model_from_engine(hostsim_lib, lh, c, juncs, ji, hostsim_lib, device=True),
+                     _model_from_engine(hostsim_lib, lh, c, juncs, ji, hostsim_lib))
+
+
+@pytest.mark.gpu
+def test_ilp_entries_written_on_the_device(hip_lib, workdir):
+    """ambi_ilp_fill_kernel: bit-identical to the host generator, incl. config 2 (n = 256:
+    230 015 rows, 56.5 M non-zeros = 0.68 GB written)."""
+    for lh, c, juncs, ji in _row_form_cases(workdir):
+        _same_models(_model_from_engine(hip_lib, lh, c, juncs, ji, hip_lib, device=True), _model_from_engine(hip_lib, lh, c, juncs, ji, hip_lib))
+    s = synth.make_sample(256, 512, "wide", 19, seed=2000)
+    lh, _ = s.write(workdir, "ilp256")
+    d = _model_from_engine(hip_lib, lh, 0, "", False, hip_lib, device=True)
+    h = _model_from_engine(hip_lib, lh, 0, "", False, hip_lib)
+    assert (d.n_cols, d.n_rows) == (66305, 230015) and d.nnz > 56_000_000      # SURVEY.md section 6
+    _same_models(d, h)
+    gbps = 12.0 * d.nnz / (d.kernel_ms * 1e-3) / 1e9
+    print("ambi_ilp_fill_kernel: %.3f ms for %d non-zeros = %.0f GB/s of 12-byte entries" % (d.kernel_ms, d.nnz, gbps))
+    assert d.kernel_ms > 0
