@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     BlockGroup g(scratch);
     const int u = A.unit_base + (int)blockIdx.x;
     const UnitOut* out = unit_out(A.results, u);
-    if (out->status != ST_OK || out->order_off < 0) return;
+    if (out->status != ST_OK || out->order_off < 0) { if (threadIdx.x == 0) A.unit_fallback[u] = 0; return; }   // no rows to write
     const IdealTable tbl = unit_ideal_table(A, u);
     const int K = out->K;
     BlockImageHeader H;
@@ -674,7 +674,6 @@ class HipBackend : public Backend {
         all_done_ = false;
         const int U = A_.n_units;
         HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
-        (void)hipMemsetAsync(d_fallback_, 0, sizeof(int32_t) * (size_t)U, stream_);
         if (!arena_checked_) {
             // first run of this batch: size the arena regions of the slices from what their order tables need
             for (int s = 0; s < n_slices_; s++) launch_front(0, slice_args(s));   // all on the caller's stream

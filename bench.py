@@ -4,9 +4,10 @@
 A "step" is one pass of the whole post-.sol reconstruction pipeline (SURVEY.md 8a #7,#8,#11-#16,#20: getJuncCN,
 bias, getIndelBias, targetCN, constructDAG, allTopologicalOrders, getBFB+imperfectFBI, indelBFB, output junctions)
 over one batch of synthetic units that is already resident in HBM; the results (paths, breakpoints, output junctions)
-stay in the HBM of the GPU that produced them.  Samples are independent, so N GPUs run N batches (weak scaling); for
-N > 1 every step ends with the single exchange the north star names: the paths are packed on the device and sent to
-rank 0 with one RCCL gather (`--gather 0` leaves them in each GPU's HBM, `--gather 1` forces the packing at N = 1).
+stay in the HBM of the GPU that produced them.  Samples are independent, so N GPUs run N batches (weak scaling) with
+no collective inside a step; for N > 1 the timed region ends with the single exchange the north star names ("a single
+RCCL gather over xGMI at the end"): the final paths are packed on the device and sent to rank 0 with one RCCL gather
+(`--gather 0`: leave them in each GPU's HBM, `--gather 2`: gather at the end of every step).
 
 Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted on: synthetic
 256-segment / 512-junction .lh samples, wide DAG tier K=19 (R = C(18,9) = 48 620 topological orders per sample),
@@ -43,9 +44,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
     ap.add_argument("--target-lanes", type=int, default=0)
     ap.add_argument("--slices", type=int, default=0, help="unit ranges run on separate HIP streams (0: engine default)")
-    ap.add_argument("--gather", type=int, default=-1, help="1: every step ends with the packing of the paths + ONE RCCL gather to rank 0 "
-                    "(north star: 'a single RCCL gather over xGMI at the end'); 0: results stay in each GPU's HBM; "
-                    "-1 (default): 1 when N > 1, 0 at N = 1 where there is nothing to exchange")
+    ap.add_argument("--gather", type=int, default=-1, help="1: the timed region ends with the packing of the paths + ONE RCCL gather to "
+                    "rank 0 (north star: 'a single RCCL gather over xGMI at the end'); 2: at the end of EVERY step; 0: results stay in "
+                    "each GPU's HBM; -1 (default): 1 when N > 1, 0 at N = 1 where there is nothing to exchange")
     return ap.parse_args()
 
 
@@ -98,7 +99,7 @@ def main():
     px = PathExchange(B, total_cells, "cuda", world=world, rank=rank)
     lengths, cells, tot, cell_cap = px.lengths, px.cells, px.total, px.cell_cap
 
-    do_gather = (world > 1) if args.gather < 0 else bool(args.gather)
+    gather_mode = (1 if world > 1 else 0) if args.gather < 0 else args.gather
 
     def gather():
         # the single end-of-batch exchange of the north star: pack the final paths on the device, all-gather the path
@@ -109,7 +110,7 @@ def main():
 
     def step():
         batch.run(0, stream)
-        if do_gather:
+        if gather_mode == 2:
             gather()
 
     def barrier():
@@ -125,6 +126,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gather_mode == 1:
+        gather()                           # the single exchange at the end of the job, inside the timed region
     batch.wait()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
@@ -217,7 +220,7 @@ def main():
         "dtype": "u8/int16 (order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
         "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, default CLI mode; %d samples per GPU resident in HBM"
                                % (args.segs, args.juncs, args.tier, args.K, B),
-                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, "; + one RCCL gather of the paths to rank 0 at the end of every step" if do_gather else " (no data-path collective)")},
+                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths to rank 0 at the end of the timed steps", 2: "; one RCCL gather of the paths to rank 0 at the end of every step"}[gather_mode])},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
