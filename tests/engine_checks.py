@@ -250,3 +250,86 @@ def check_all_mode(lib, oracle, workdir, seeds=range(40)):
             stats["flipped"] += oc["evaluated"] > oc["num_orders"]
     assert not bad, bad
     return stats
+
+
+def check_mixed_batch(lib, oracle, workdir, big=False):
+    """ONE batch with every kind of unit side by side: all three row-width classes of the enumerate kernels (K <= 20,
+    <= 32, <= 63), units whose block image does not fit next to units whose image does (small AMBI_BLOCK_LDS budget),
+    a chromosome without fold-backs (shortcut), an infeasible .sol, units without any valid order and units whose first
+    valid order lies behind the scan budget.  Every unit equals its own oracle run."""
+    import os
+    from ambigram_amd import synth
+    specs = [("chain", 9, 48, 100), ("wide", 11, 48, 100), ("mixed", 12, 48, 100), ("skew", 23, 64, 128), ("skew", 27, 64, 128),
+             ("skew", 34, 96, 200), ("skew", 45, 128, 256), ("wide", 13, 64, 128), ("chain", 25, 128, 256)]
+    if big:
+        specs += [("wide", 15, 96, 200), ("skew", 50, 128, 256), ("wide", 19, 256, 512)]
+    items = []
+    for i, (tier, K, nseg, njunc) in enumerate(specs):
+        s = synth.make_sample(nseg, njunc, tier, K, seed=7600 + i, imperfect=i % 2, n_del=i % 3)
+        lh, sols = s.write(workdir, "mb%d" % i)
+        items.append((lh, sols[0]))
+    for seed in (3, 5, 8, 13, 21, 34):
+        lh, sols = cases.random_decomposition(workdir, 900 + seed)
+        items.append((lh, sols[0]))
+    # shortcut (no fold-back) and infeasible
+    nofbi = os.path.join(workdir, "mb_nofbi.lh")
+    with open(nofbi, "w") as f:
+        f.write("SAMPLE_NAME nofbi\nAVG_CHR_SEG_DP 30\nAVG_WHOLE_HOST_DP 30\nAVG_JUNC_DP 30\nPURITY 1\nAVG_TUMOR_PLOIDY 2\n"
+                "PLOIDY 2m1\nVIRUS_START 5\nSOURCE 1\nSINK 4\n"
+                "SEG H:1:chr1:1:10 30.0 1.0\nSEG H:2:chr1:11:20 30.0 1.0\nSEG H:3:chr1:21:30 30.0 1.0\nSEG H:4:chr1:31:40 30.0 1.0\n"
+                "JUNC H:1:+ H:2:+ 30.0 1.0 U B\nJUNC H:2:+ H:3:+ 30.0 1.0 U B\nJUNC H:1:+ H:4:+ 30.0 1.0 U B\n")
+    infeasible = os.path.join(workdir, "mb_infeasible.sol")
+    with open(infeasible, "w") as f:
+        f.write("Infeasible - objective value 0.00000000\n")
+    items.append((nofbi, None))
+    items.append((os.path.join(cases.DATA, "readme6.lh"), infeasible))
+    expect = []
+    for lh, sol in items:
+        o = oracle.run_bfb(lh, [sol] if sol else [], keep_orders=True)
+        assert o["ok"], o["err"]
+        expect.append(o["chr"][0])
+    saved = {k: os.environ.get(k) for k in ("AMBI_BLOCK_LDS",)}
+    try:
+        for lds in (None, "6000"):          # 6000 bytes: only the smallest images fit, the rest take the general path
+            os.environ.pop("AMBI_BLOCK_LDS", None)
+            if lds:
+                os.environ["AMBI_BLOCK_LDS"] = lds
+            graphs, b = [], api.Batch(lib)
+            b.configure(first_budget=3)
+            for lh, sol in items:
+                g = api.Graph(lib, lh)
+                graphs.append(g)
+                if sol:
+                    b.add_chromosome_sol(g, 0, sol)
+                else:
+                    b.add_chromosome(g, 0, [], [])
+            b.upload(); b.run(0); b.download()
+            for u, oc in enumerate(expect):
+                r = b.unit_result(u)
+                tag = (lds, u, items[u][0])
+                if oc["shortcut"] or oc["infeasible"]:
+                    assert r["status"] == (api.ST_SHORTCUT if oc["shortcut"] else api.ST_INFEASIBLE), tag
+                    want = oc["path_indel"] or oc["path"]      # the reference path 1+ .. n+ (no indelBFB on this branch)
+                    assert b.unit_path(u, 1).tolist() == want or not want, tag
+                    continue
+                if oc["ub"]:
+                    assert r["status"] in (-12, 3, 0), tag
+                    continue
+                assert r["num_orders"] == oc["num_orders"], tag
+                if oc["orders"]:
+                    assert b.unit_orders(u, 0, r["num_orders"], r["n_nodes"]).tolist() == oc["orders"], tag
+                if oc["first_valid"] < 0:
+                    assert r["status"] == api.ST_NO_VALID_ORDER and r["evaluated"] == oc["evaluated"], tag
+                    continue
+                assert r["status"] == 0, (tag, r)
+                assert (r["first_valid"], r["first_forward"], r["evaluated"]) == (oc["first_valid"], oc["first_forward"], oc["evaluated"]), tag
+                assert b.unit_bkp(u).tolist() == oc["bkp"], tag
+                assert b.unit_path(u, 0).tolist() == oc["path"] and b.unit_path(u, 1).tolist() == oc["path_indel"], tag
+            b.close()
+            for g in graphs:
+                g.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -160,3 +160,7 @@ def test_large_lattice(hip_lib, oracle, workdir):
 def test_all_mode(hip_lib, oracle, workdir):
     st = ec.check_all_mode(hip_lib, oracle, workdir, seeds=range(60))
     assert st["multi"] > 0, st
+
+
+def test_mixed_batch(hip_lib, oracle, workdir):
+    ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)

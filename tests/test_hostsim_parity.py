@@ -43,3 +43,7 @@ def test_large_lattice(hostsim_lib, oracle, workdir):
 def test_all_mode(hostsim_lib, oracle, workdir):
     st = ec.check_all_mode(hostsim_lib, oracle, workdir)
     assert st["multi"] > 0, st
+
+
+def test_mixed_batch(hostsim_lib, oracle, workdir):
+    ec.check_mixed_batch(hostsim_lib, oracle, workdir)
