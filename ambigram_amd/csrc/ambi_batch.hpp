@@ -120,6 +120,7 @@ struct BatchArgs {
     int32_t* auto_cbase;         // [slots/2 + U]
     uint16_t* auto_child;        // [U * 4 * ideal_cap]
     // order table
+    uint8_t* first_rows;         // [U][first_budget][kFirstRowStride] the first orders of every unit, unranked by the prepare stage (nullptr: the scan reads the order table)
     uint8_t* order_arena;
     int64_t order_arena_bytes;   // bytes of this slice's region
     int64_t* blk_off;            // [n_units+1] enumerate work-block prefix of this slice (local index)

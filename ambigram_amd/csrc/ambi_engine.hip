@@ -439,6 +439,11 @@ class HipBackend : public Backend {
     hipEvent_t ev_fork_ = nullptr;
     std::vector<hipEvent_t> ev_join_, ev_stage_;
     bool stagger_ = true;
+    // overlap of [first valid order, finish] with the enumerate kernel (one slice, arena sized): own stream + two events
+    bool overlap_back_ = false, want_overlap_ = true;
+    hipStream_t back_stream_ = nullptr;
+    hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr;
+    uint8_t* d_first_rows_ = nullptr;
     std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit
     bool all_done_ = false;
     int enum_grid_ = 2048;
@@ -446,7 +451,7 @@ class HipBackend : public Backend {
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
-                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_};
+                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
@@ -459,6 +464,10 @@ class HipBackend : public Backend {
         ev_join_.clear();
         for (auto e : ev_stage_) (void)hipEventDestroy(e);
         ev_stage_.clear();
+        if (back_stream_) (void)hipStreamDestroy(back_stream_);
+        if (ev_prep_) (void)hipEventDestroy(ev_prep_);
+        if (ev_back_) (void)hipEventDestroy(ev_back_);
+        back_stream_ = nullptr; ev_prep_ = ev_back_ = nullptr;
     }
 
   public:
@@ -574,6 +583,21 @@ class HipBackend : public Backend {
             { const char* e2 = getenv("AMBI_STAGGER"); stagger_ = e2 ? atoi(e2) != 0 : true; }
             { const char* e3 = getenv("AMBI_ENUM_GRID"); enum_grid_ = e3 ? atoi(e3) : 16384; if (enum_grid_ < 1) enum_grid_ = 1; }   // >= work blocks: one block per workgroup, the rest exit (measured: 2048 -> 16384 workgroups = -8 % kernel time)
         }
+        // first orders of every unit, written by the prepare stage (takes the enumerate kernel off the critical path of the scan)
+        if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
+        { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
+        if (want_overlap_ && n_slices_ == 1) {
+            HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
+            HIP_CK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
+            HIP_CK(hipEventCreateWithFlags(&ev_back_, hipEventDisableTiming));
+            // AMBI_ENUM_LDS_FLOOR (experiments): make the enumerate kernel ask for more LDS than its image needs, i.e. fewer
+            // of its workgroups per CU.  Measured (profiles/r01_slices.md): no floor is best -- the scan / finish
+            // workgroups slip in as enumerate workgroups retire.
+            { const char* e6 = getenv("AMBI_ENUM_LDS_FLOOR"); const int floor_lds = e6 ? atoi(e6) : 0; if (lds_blocks_ < floor_lds && floor_lds <= kLdsLimit) lds_blocks_ = floor_lds; }
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+        }
         uploaded_ = true; arena_checked_ = false;
         return 0;
     }
@@ -588,6 +612,7 @@ class HipBackend : public Backend {
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
         A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_link = d_ilink_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
+        A_.first_rows = d_first_rows_;
         A_.order_arena = d_arena_; A_.order_arena_bytes = arena_bytes_;
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
@@ -607,7 +632,7 @@ class HipBackend : public Backend {
     // Per-kernel HIP events on the stream of the slice.  A ring of kTimingSlots event sets lets a timed region of many
     // runs be averaged without a host sync per run: run r records into slot r % kTimingSlots.
     static constexpr int kTimingSlots = 64, kTimedKernels = 6;
-    void tick(const char* name, int slice, size_t idx, bool begin) {
+    void tick(const char* name, int slice, size_t idx, bool begin, hipStream_t on = (hipStream_t)-1) {
         if (!timing_) return;
         const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
         const size_t at = (slot * n_slices_ + slice) * kTimedKernels + idx;
@@ -617,7 +642,7 @@ class HipBackend : public Backend {
             evs_.push_back(e);
         }
         evs_[at].name = name;
-        (void)hipEventRecord(begin ? evs_[at].a : evs_[at].b, slice_stream(slice));
+        (void)hipEventRecord(begin ? evs_[at].a : evs_[at].b, on == (hipStream_t)-1 ? slice_stream(slice) : on);
     }
 
     void fork() {   // the side streams start behind everything already queued on the caller's stream
@@ -637,6 +662,7 @@ class HipBackend : public Backend {
         tick("ambi_prepare_kernel", s, 0, true);
         hipLaunchKernelGGL(ambi_prepare_kernel, dim3(A.n_units), dim3(64), lds_prepare_, st, A);
         tick("ambi_prepare_kernel", s, 0, false);
+        if (overlap_back_) (void)hipEventRecord(ev_prep_, st);   // the scan for the first valid order needs nothing later than this
         tick("ambi_plan_kernel", s, 1, true);
         hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
         tick("ambi_plan_kernel", s, 1, false);
@@ -659,12 +685,17 @@ class HipBackend : public Backend {
         if ((enum_classes_ & 2) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 4) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
         tick("ambi_enumerate_kernel", s, 3, false);
-        tick("ambi_first_kernel", s, 4, true);
-        hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, st, A);
-        tick("ambi_first_kernel", s, 4, false);
-        tick("ambi_finish_kernel", s, 5, true);
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, st, A, (const int32_t*)nullptr);
-        tick("ambi_finish_kernel", s, 5, false);
+        // first valid order + finish: beside the enumerate kernel on their own stream when the first orders come from the
+        // prepare stage (they do not read the table then), else behind it
+        hipStream_t sb = st;
+        if (overlap_back_) { sb = back_stream_; (void)hipStreamWaitEvent(sb, ev_prep_, 0); }
+        tick("ambi_first_kernel", s, 4, true, sb);
+        hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, sb, A);
+        tick("ambi_first_kernel", s, 4, false, sb);
+        tick("ambi_finish_kernel", s, 5, true, sb);
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr);
+        tick("ambi_finish_kernel", s, 5, false, sb);
+        if (overlap_back_) { (void)hipEventRecord(ev_back_, sb); (void)hipStreamWaitEvent(st, ev_back_, 0); }
     }
 
     int run(uint32_t flags, void* stream) override {
@@ -695,6 +726,7 @@ class HipBackend : public Backend {
             }
             arena_checked_ = true;
         }
+        overlap_back_ = want_overlap_ && back_stream_ != nullptr && arena_checked_ && n_slices_ == 1;
         // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
         // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
         // share the chip instead of alternating.

@@ -23,6 +23,7 @@ namespace ambi {
 
 constexpr uint64_t kEmptyKey = ~0ull;     // K <= 63, so no ideal mask equals this
 constexpr uint64_t kCountSat = 1ull << 62;
+constexpr int kFirstRowStride = 64;       // bytes between the pre-unranked first orders of a unit (K <= 63)
 
 // Kpad: bytes per row of the order table (a multiple of 4; coarser buckets above 32 nodes keep the number of
 // enumerate-kernel instantiations small)
@@ -127,7 +128,8 @@ AMBI_HD int ideal_insert(const LatticeWork& W, uint64_t key, bool* fresh) {
 //   freeze   : counts, child bases and 16-bit child indices to the table in HBM.
 // Returns status; *R_out = number of topological orders (saturated at 2^62).
 template <class G>
-AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const LatticeWork& W, const IdealTable& T, uint64_t* R_out) {
+AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const LatticeWork& W, const IdealTable& T, uint64_t* R_out,
+                                  uint8_t* first_rows = nullptr, int first_count = 0) {
     int maxIdeals = W.cap / 2;
     if (maxIdeals > 65535) maxIdeals = 65535;
     for (int i = g.tid(); i < W.cap; i += g.size()) W.keys[i] = kEmptyKey;
@@ -212,6 +214,30 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
     for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) T.lvl_off[d] = (d <= last_level + 1) ? W.lvl_off[d] : nI;
     for (int t = g.tid(); t < 2; t += g.size()) T.counter[t] = t == 0 ? nI : links;
     *R_out = W.cnt[0];
+    // The first `first_count` orders (rows 0.. of the table, kFirstRowStride bytes apart), unranked here while the lattice
+    // is still in group memory: the scan for the first valid order reads them instead of the order table, which takes
+    // the enumerate kernel off its critical path.  Descent by counts over the links; the node of a step is the one bit
+    // by which the child's mask exceeds the parent's.
+    if (first_rows && first_count > 0 && W.cnt[0] > 0) {
+        const uint64_t nfirst = W.cnt[0] < (uint64_t)first_count ? W.cnt[0] : (uint64_t)first_count;
+        for (uint64_t n = g.tid(); n < nfirst; n += g.size()) {
+            uint8_t* row = first_rows + n * kFirstRowStride;
+            int i = 0;
+            uint64_t r = n;
+            for (int d = 0; d < K; d++) {
+                int c = i;
+                const int k1 = W.cbase[i + 1];
+                for (int k = W.cbase[i]; k < k1; k++) {
+                    c = (int)W.link[k];
+                    const uint64_t cc = W.cnt[c];
+                    if (r < cc) break;
+                    r -= cc;
+                }
+                row[d] = (uint8_t)ctz64(W.ikey[c] & ~W.ikey[i]);
+                i = c;
+            }
+        }
+    }
     g.sync();
     return ST_OK;
 }

@@ -196,9 +196,12 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     if (status == ST_OK) {
         const IdealTable T = unit_ideal_table(A, u);
         // fast path: search state in group memory (the frozen automaton itself always goes to HBM)
-        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R);
-        if (st == ST_ERR_IDEALS_CAPACITY) st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R);   // large lattice
+        uint8_t* first_rows = A.first_rows ? A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride : nullptr;
+        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R, first_rows, A.first_budget);
+        if (st == ST_ERR_IDEALS_CAPACITY)   // large lattice
+            st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R, first_rows, A.first_budget);
         if (st != ST_OK) status = st;
+        else if (R >= kCountSat) status = ST_ERR_ORDERS_CAPACITY;   // no table of 2^62 rows: decided here, not by the plan kernel
     }
     if (g.tid() == 0) {
         out->status = status;
@@ -372,7 +375,10 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     uint8_t* res = A.results + U.res_off;
     const int K = out->K;
     const int64_t R = out->num_orders;
-    const uint8_t* rows = A.order_arena + out->order_off;
+    // the first `first_budget` orders come from the rows the prepare stage unranked (when present): this scan then does
+    // not depend on the order table and runs beside the enumerate kernel
+    const uint8_t* rows = A.first_rows ? A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride : A.order_arena + out->order_off;
+    const int rstride = A.first_rows ? kFirstRowStride : row_stride(K);
     InvMap inv{W.inv_src, W.inv_tgt};
     const bool isReversed = (A.flags & FLAG_REVERSED) != 0;
     bool forwardDir = !isReversed;
@@ -383,7 +389,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     for (int pass = 0; pass < 2 && found < 0; pass++) {
         int64_t lim = R < A.first_budget ? R : A.first_budget;
         for (int64_t nidx = 0; nidx < lim; nidx++) {
-            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * row_stride(K) + d];
+            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * rstride + d];
             g.sync();
             int Lo = 0;
             int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo);

@@ -18,7 +18,7 @@ class HostSimBackend : public Backend {
     EngineConfig cfg_;
     std::vector<UnitIn> units_;
     std::vector<Dag> dags_;
-    std::vector<uint8_t> results_, arena_;
+    std::vector<uint8_t> results_, arena_, first_rows_;
     std::vector<uint64_t> ikeys_, icnt_, aavail_, acnt_;
     std::vector<uint16_t> achild_;
     std::vector<uint32_t> ilink_;
@@ -48,6 +48,9 @@ class HostSimBackend : public Backend {
         acbase_.assign((size_t)hb.ideal_slots / 2 + U + 1, 0); achild_.assign((size_t)hb.ideal_slots * 4 + 8, 0);
         rows_per_lane_.assign(U, 1); blk_off_.assign(U + 1, 0);
         scratch_.assign((size_t)hb.scratch_ints + 8, 0);
+        // env AMBI_HOSTSIM_TABLE_SCAN=1: the scan for the first valid order reads the order table (the other supported source)
+        if (!getenv("AMBI_HOSTSIM_TABLE_SCAN")) first_rows_.assign(U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride, 0);
+        else first_rows_.clear();
         arena_.assign((size_t)(cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : 0), 0);
         return 0;
     }
@@ -61,6 +64,7 @@ class HostSimBackend : public Backend {
         A_.dags = dags_.data(); A_.results = results_.data();
         A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_link = ilink_.data();
         A_.ideal_lvl_off = ilvl_off_.data(); A_.ideal_counter = icounter_.data();
+        A_.first_rows = first_rows_.empty() ? nullptr : first_rows_.data();
         A_.order_arena = arena_.data(); A_.order_arena_bytes = (int64_t)arena_.size();
         A_.blk_off = blk_off_.data(); A_.rows_per_lane = rows_per_lane_.data();
         A_.n_pending = &n_pending_; A_.orders_needed = &orders_needed_;
