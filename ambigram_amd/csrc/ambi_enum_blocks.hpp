@@ -72,6 +72,7 @@ AMBI_HD int64_t dir_words(int nB, int NW) { return ((int64_t)nB * dir_stride(NW)
 struct BuildTables {
     uint64_t* avail;    // [nI]
     uint32_t* nblk;     // [nI]  blocks below the ideal (1 for ideals with cnt <= block_max), saturated
+    uint32_t* link;     // [nC]  child link with the child's (saturated) count: child | cnt16 << 16 -- one read per sibling
     uint16_t* cbase;    // [nI]
     uint16_t* child;    // [nC]
     uint16_t* cnt16;    // [nI]  completion counts saturated at 65535
@@ -85,6 +86,7 @@ AMBI_HD int64_t carve_build_tables(uint8_t* mem, int nI, int nC, BuildTables& B)
     int64_t o = 0;
     B.avail = reinterpret_cast<uint64_t*>(mem + o); o += 8ll * nI;
     B.nblk = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * nI;
+    B.link = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * nC;
     B.root_row = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * (nI + 1);
     B.misc = reinterpret_cast<int32_t*>(mem + o); o += 16;
     B.cbase = reinterpret_cast<uint16_t*>(mem + o); o += 2ll * nI;
@@ -122,6 +124,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     for (int d = 0; d <= K; d++)
         for (int p = T.lvl_off[d] + g.tid(); p < T.lvl_off[d + 1] && p < nI; p += g.size()) B.depth[p] = (uint8_t)d;
     g.sync();
+    for (int i = g.tid(); i < nC; i += g.size()) { const uint32_t c = B.child[i]; B.link[i] = c | ((uint32_t)B.cnt16[c] << 16); }
     // possible block roots: small ideals with a large parent (marked through the parents' child links), or the empty ideal
     for (int q = g.tid(); q < nI; q += g.size()) {
         if (B.cnt16[q] <= block_max) continue;
@@ -220,6 +223,26 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         for (int x = 0; x < (D >> 2); x++) dst[x] = 0;
         uint32_t w = 0;                       // word being assembled (bytes < D of word D>>2 stay zero)
         int j = p, d = D;
+        if (K <= 32) {   // 32-bit masks (low halves of the 64-bit ones), one packed read per sibling
+            const uint32_t* av32 = reinterpret_cast<const uint32_t*>(B.avail);
+            for (; d < K; d++) {
+                uint32_t av = av32[2 * j];
+                int k = B.cbase[j];
+                int chosen = 0, nxt = 0;
+                while (av) {
+                    const int v = __builtin_ctz(av);
+                    av &= av - 1;
+                    const uint32_t lk = B.link[k++];
+                    const int cc = (int)(lk >> 16);
+                    nxt = (int)(lk & 0xFFFFu);
+                    if (rr < cc) { chosen = v; break; }
+                    rr -= cc;
+                }
+                w |= (uint32_t)chosen << ((d & 3) * 8);
+                if ((d & 3) == 3) { dst[d >> 2] = w; w = 0; }
+                j = nxt;
+            }
+        }
         for (; d < K; d++) {
             uint64_t av = B.avail[j];
             int k = B.cbase[j];
@@ -227,8 +250,9 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
             while (av) {
                 const int v = ctz64(av);
                 av &= av - 1;
-                nxt = B.child[k++];
-                const int cc = B.cnt16[nxt];
+                const uint32_t lk = B.link[k++];
+                const int cc = (int)(lk >> 16);
+                nxt = (int)(lk & 0xFFFFu);
                 if (rr < cc) { chosen = v; break; }
                 rr -= cc;
             }
