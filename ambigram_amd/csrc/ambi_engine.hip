@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
     // general path: only units whose block tables did not fit (flagged by ambi_enumerate_blocks_kernel)
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
+        if (b < A.n_units && A.blk_off[b] == b && A.blk_off[b + 1] == b + 1) lo = (int)b;   // one work block per unit so far: two independent reads
+        else while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
         const int u = A.unit_base + lo;
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
     int nB = 0;
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
+        if (b < A.n_units && A.blk_off[b] == b && A.blk_off[b + 1] == b + 1) lo = (int)b;   // one work block per unit so far: two independent reads
+        else while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.blk_off[mid] <= b) lo = mid; else hi = mid; }
         const int u = A.unit_base + lo;
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];

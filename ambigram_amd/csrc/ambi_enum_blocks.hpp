@@ -71,6 +71,8 @@ AMBI_HD int64_t dir_words(int nB, int NW) { return ((int64_t)nB * dir_stride(NW)
 // automaton copy used while building (group memory)
 struct BuildTables {
     uint64_t* avail;    // [nI]
+    uint64_t* cnt64;    // [nI]  exact completion counts (first rows of the directory entries)
+    int32_t* lvl;       // [kMaxNodes+3] level offsets (copied once: the level loops must not go to HBM every iteration)
     uint32_t* nblk;     // [nI]  blocks below the ideal (1 for ideals with cnt <= block_max), saturated
     uint32_t* link;     // [nC]  child link with the child's (saturated) count: child | cnt16 << 16 -- one read per sibling
     uint16_t* cbase;    // [nI]
@@ -85,6 +87,8 @@ struct BuildTables {
 AMBI_HD int64_t carve_build_tables(uint8_t* mem, int nI, int nC, BuildTables& B) {
     int64_t o = 0;
     B.avail = reinterpret_cast<uint64_t*>(mem + o); o += 8ll * nI;
+    B.cnt64 = reinterpret_cast<uint64_t*>(mem + o); o += 8ll * nI;
+    B.lvl = reinterpret_cast<int32_t*>(mem + o); o += 4ll * (kMaxNodes + 3) + 4;
     B.nblk = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * nI;
     B.link = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * nC;
     B.root_row = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * (nI + 1);
@@ -115,14 +119,17 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     uint32_t* img = reinterpret_cast<uint32_t*>(image);
     for (int i = g.tid(); i < nI; i += g.size()) {
         const uint64_t c = T.a_cnt[i];
+        B.cnt64[i] = c;
         B.avail[i] = T.a_avail[i];
         B.cbase[i] = (uint16_t)T.a_cbase[i];
         B.cnt16[i] = (uint16_t)(c > 65535 ? 65535 : c);
         B.soff[i] = 0xFFFF;
     }
     for (int i = g.tid(); i < nC; i += g.size()) B.child[i] = T.a_child[i];
+    for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) B.lvl[d] = T.lvl_off[d];
+    g.sync();
     for (int d = 0; d <= K; d++)
-        for (int p = T.lvl_off[d] + g.tid(); p < T.lvl_off[d + 1] && p < nI; p += g.size()) B.depth[p] = (uint8_t)d;
+        for (int p = B.lvl[d] + g.tid(); p < B.lvl[d + 1] && p < nI; p += g.size()) B.depth[p] = (uint8_t)d;
     g.sync();
     for (int i = g.tid(); i < nC; i += g.size()) { const uint32_t c = B.child[i]; B.link[i] = c | ((uint32_t)B.cnt16[c] << 16); }
     // possible block roots: small ideals with a large parent (marked through the parents' child links), or the empty ideal
@@ -135,7 +142,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     // blocks below every ideal, deepest level first (children live one level down)
     for (int d = K; d >= 0; d--) {
         g.sync();
-        for (int p = T.lvl_off[d] + g.tid(); p < T.lvl_off[d + 1] && p < nI; p += g.size()) {
+        for (int p = B.lvl[d] + g.tid(); p < B.lvl[d + 1] && p < nI; p += g.size()) {
             uint32_t nb = 1;
             if (B.cnt16[p] > block_max) {
                 nb = 0;
@@ -186,7 +193,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
                 const uint32_t nb = B.nblk[nxt];
                 if (rem < nb) { chosen = v; break; }
                 rem -= nb;
-                row += T.a_cnt[nxt];
+                row += B.cnt64[nxt];
             }
             w |= (uint32_t)chosen << ((d & 3) * 8);
             if ((d & 3) == 3) {
