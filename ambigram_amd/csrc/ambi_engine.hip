@@ -192,13 +192,18 @@ __global__ __launch_bounds__(256) void ambi_enumerate_kernel(BatchArgs A) {
     }
 }
 
-// Builds the block-emission tables of every unit once (LDS), and parks the position-independent image in HBM.
+// Builds the block-emission image of every unit whose table is written by MORE THAN ONE workgroup and parks it in HBM
+// (a unit with a single work block gets its image built in LDS by the enumerate workgroup itself, below).
 __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int u = A.unit_base + (int)blockIdx.x;
     const UnitOut* out = unit_out(A.results, u);
-    if (out->status != ST_OK || out->order_off < 0) { if (threadIdx.x == 0) A.unit_fallback[u] = 0; return; }   // no rows to write
+    const int64_t nblocks = A.blk_off[blockIdx.x + 1] - A.blk_off[blockIdx.x];
+    if (out->status != ST_OK || out->order_off < 0 || (nblocks == 1 && A.build_in_emit)) {   // no rows to write / image built by the enumerate kernel
+        if (threadIdx.x == 0) A.unit_fallback[u] = 0;
+        return;
+    }
     const IdealTable tbl = unit_ideal_table(A, u);
     const int K = out->K;
     BlockImageHeader H;
@@ -214,13 +219,17 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
 // Fast path: block emission (ambi_enum_blocks.hpp).  One workgroup per work block of 256*T rows; the workgroup copies
 // the unit's image (block directory + suffix rows) from HBM into LDS, then every wave streams its 64*T rows block by
 // block: four LDS reads, four ORs and one fully coalesced 16-byte store per lane and step.
-// LDS: [block_lds] image.
+// A unit with ONE work block has no image in HBM: its workgroup builds the image right here in LDS (automaton copy in
+// front, image behind it) -- the build is a latency-bound chain that hides under the store stream of the other
+// workgroups of the CU -- and the separate build kernel only serves the units that several workgroups share.
+// LDS: [block_lds] image (+ automaton copy while building).
 template <int CLS>
 __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t* tmem = ambi_lds;
+    const uint32_t* image = reinterpret_cast<const uint32_t*>(tmem);
     const int64_t total = A.blk_off[A.n_units];
     int staged_unit = -1;
     bool fits = false;
@@ -235,14 +244,27 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         if (enum_class_of(K) != CLS) continue;
         if (u != staged_unit) {
             g.sync();
-            const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
-            fits = hdr->fits != 0;
-            nB = hdr->nB;
-            if (fits) {   // coalesced copy of the unit's image into LDS
-                const int64_t nvec = ((int64_t)hdr->image_bytes + 15) >> 4;
-                const uint4* src = reinterpret_cast<const uint4*>(A.block_img + (int64_t)u * A.block_lds);
-                uint4* dst = reinterpret_cast<uint4*>(tmem);
-                for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+            if (A.build_in_emit && A.blk_off[lo + 1] - A.blk_off[lo] == 1) {
+                const IdealTable tbl = unit_ideal_table(A, u);
+                BuildTables dummy;
+                const int64_t scr = carve_build_tables(tmem, tbl.counter[0], tbl.counter[1], dummy);
+                BlockImageHeader H;
+                fits = scr < A.block_lds &&
+                       build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, tmem, scr, tmem + scr, A.block_lds - scr, H);
+                nB = H.nB;
+                image = reinterpret_cast<const uint32_t*>(tmem + scr);
+                if (!fits && threadIdx.x == 0) A.unit_fallback[u] = 1;   // the general enumerate kernel takes the unit
+            } else {
+                const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
+                fits = hdr->fits != 0;
+                nB = hdr->nB;
+                image = reinterpret_cast<const uint32_t*>(tmem);
+                if (fits) {   // coalesced copy of the unit's image into LDS
+                    const int64_t nvec = ((int64_t)hdr->image_bytes + 15) >> 4;
+                    const uint4* src = reinterpret_cast<const uint4*>(A.block_img + (int64_t)u * A.block_lds);
+                    uint4* dst = reinterpret_cast<uint4*>(tmem);
+                    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+                }
             }
             staged_unit = u;
             g.sync();
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         int64_t whi = wlo + per;
         if (whi > bhi) whi = bhi;
         if (wlo < whi)
-            emit_blocks_dispatch<CLS>(reinterpret_cast<const uint32_t*>(tmem), nB, K, (uint32_t)wlo, (uint32_t)whi,
+            emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)wlo, (uint32_t)whi,
                                       A.order_arena + out->order_off, lane, lane + 1);
     }
 }
@@ -446,6 +468,7 @@ class HipBackend : public Backend {
     hipStream_t back_stream_ = nullptr;
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr;
     uint8_t* d_first_rows_ = nullptr;
+    int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
     std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit
     bool all_done_ = false;
     int enum_grid_ = 2048;
@@ -587,6 +610,7 @@ class HipBackend : public Backend {
         }
         // first orders of every unit, written by the prepare stage (takes the enumerate kernel off the critical path of the scan)
         if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
+        { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
             HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
@@ -609,7 +633,7 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
-        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
+        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
