@@ -40,11 +40,11 @@ AMBI_HD double inversion_cn_sum(int n, const double* junc_cn) {
 AMBI_HD double junc_cn_round(double cn) { return (0.5 < cn && cn < 1) ? 1.0 : cn; }
 
 // LGM.cpp:3989-4050 getJuncCN.  junc_cn is (n+1) x 2 (row 0 unused), inv_junc[n+1] = junction index or -1.
-// slot_cnt: [n+1] ints, fb: [m] ints (fold-back junction list).  Junction ends come from group memory, the copy
+// slot_cnt: [n+1] ints, fb: [m] 16-bit junction indices (fold-back junction list; m <= 65535 per unit).  Junction ends come from group memory, the copy
 // numbers from the records in HBM (each is read once, by the thread that owns the junction / the slot).
 template <class G>
 AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* junc_cn, int32_t* inv_junc,
-                           int32_t* slot_cnt, int32_t* fb) {
+                           int32_t* slot_cnt, uint16_t* fb) {
     for (int i = g.tid(); i <= n; i += g.size()) { junc_cn[2 * i] = 0.0; junc_cn[2 * i + 1] = 0.0; inv_junc[i] = -1; slot_cnt[i] = 0; }
     g.sync();
     // one pass over the junctions: normal (reference-adjacent) ones count into their slot, fold-backs are compacted
@@ -66,7 +66,7 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
         }
         int tot;
         const int ex = g.exscan_i32(q, &tot);
-        if (q) fb[nfb + ex] = ji;
+        if (q) fb[nfb + ex] = (uint16_t)ji;
         nfb += tot;
     }
     g.sync();
@@ -149,9 +149,9 @@ AMBI_HD bool no_foldback_g(const G& g, int n, const double* junc_cn, double* sum
     return a < 0.000001;
 }
 
-// LGM.cpp:3699-3744 getIndelBias.  sv: [m] ints, taken: [m] bytes, grp: [2m+4] ints.  Mutates seg_cn[1..n].
+// LGM.cpp:3699-3744 getIndelBias.  sv: [m] 16-bit junction indices, taken: [m] bytes, grp: [2m+4] ints.  Mutates seg_cn[1..n].
 template <class G>
-AMBI_HD void get_indel_bias_g(const G& g, int n, const JuncView& J, int m, double* seg_cn, int32_t* sv, uint8_t* taken,
+AMBI_HD void get_indel_bias_g(const G& g, int n, const JuncView& J, int m, double* seg_cn, uint16_t* sv, uint8_t* taken,
                               int32_t* grp) {
     int nsv = 0;
     for (int base = 0; base < m; base += g.size()) {
@@ -167,7 +167,7 @@ AMBI_HD void get_indel_bias_g(const G& g, int n, const JuncView& J, int m, doubl
         }
         int tot;
         int ex = g.exscan_i32(q, &tot);
-        if (q) { sv[nsv + ex] = ji; taken[nsv + ex] = 0; }
+        if (q) { sv[nsv + ex] = (uint16_t)ji; taken[nsv + ex] = 0; }
         nsv += tot;
     }
     g.sync();
@@ -218,7 +218,8 @@ AMBI_HD void get_indel_bias_g(const G& g, int n, const JuncView& J, int m, doubl
 }
 
 // localhap.cpp:222-232.  target_cn[0..n] (local ids): integer adds, so a difference array + running sum gives the
-// reference's numbers in any order.  diff: [n+2] ints of group memory (may not alias target_cn).
+// reference's numbers in any order.  diff: [n+2] ints of group memory; target_cn may be the same array (every index is
+// read and then written by one thread).
 template <class G>
 AMBI_HD void target_cn_g(const G& g, const Element* el, int K, int n, int32_t* target_cn, int32_t* diff) {
     for (int i = g.tid(); i <= n + 1; i += g.size()) diff[i] = 0;

@@ -21,62 +21,60 @@ namespace ambi {
 // ---------------------------------------------------------------------------------------------
 // stage_prepare
 // ---------------------------------------------------------------------------------------------
-// Group-local memory (LDS on the GPU).  The junction-phase arrays are dead once their results have been copied to
-// the result blob, so the lattice search re-uses their bytes: footprint = persistent part + max(junction phase, lattice).
+// Group-local memory (LDS on the GPU) of the prepare stage, kept below 10 KB for the bench-sized unit (256 segments,
+// 512 junctions) so that 16 units are in flight per CU:
+//   * the f64 arrays (junction CN, segment CN) live in the unit's slots of the result blob in HBM, where they end up
+//     anyway: every element is written / read by the one thread that owns it;
+//   * fold-back and SV lists share one array of 16-bit junction indices (their phases do not overlap);
+//   * the normal-junction slot counters, the target-CN difference array and the target CN itself are one array;
+//   * the lattice search runs in the bytes of all of the above once their results are in the blob.
+// Footprint = persistent part + max(junction phase, lattice).
 struct PrepareWork {
     // persistent
     Dag* dag;
     Element* elems;       // [K]
-    int32_t* idx;         // [64]   node order
-    Rec3* loops;          // [64]   records permuted by the library sort
-    int32_t* target_cn;   // [n+1]
     // junction phase
     JuncEnds* ends;       // [m]    strand-signed junction ends (the 24-byte records stay in HBM)
-    double* seg_cn;       // [n+1]
-    double* junc_cn;      // [2(n+1)]
     int32_t* inv_junc;    // [n+1]
-    int32_t* slot_cnt;    // [n+2]  contributions per normal-junction slot; later the target-CN difference array
-    int32_t* fb;          // [m]    fold-back junction list
-    int32_t* sv;          // [m]    getIndelBias SV list
+    int32_t* slot_cnt;    // [n+2]  contributions per normal-junction slot; then the target-CN difference array / target CN
+    uint16_t* list;       // [m]    fold-back junction list, later the getIndelBias SV list
     uint8_t* taken;       // [m]
+    int32_t* idx;         // [64]   node order (constructDAG), later the stack of the sort replay
+    Rec3* loops;          // [64]   records permuted by the library sort
     // lattice phase (same bytes as the junction phase)
     uint8_t* lattice_mem; // [kPrepLatticeBytes]
 };
 // Group-local lattice search: kPrepHashSlots hash slots (at most half as many ideals) and kPrepLinks child links;
 // lattices that need more use the pools in HBM.
-constexpr int kPrepHashSlots = 512;
-constexpr int kPrepLinks = 768;
+constexpr int kPrepHashSlots = 256;
+constexpr int kPrepLinks = 352;
 constexpr int64_t kPrepLatticeBytes = 8ll * kPrepHashSlots /*keys*/ + 4ll * kPrepHashSlots /*pos*/ + 8ll * (kPrepHashSlots / 2) /*ikey*/ +
                                       8ll * (kPrepHashSlots / 2) /*cnt*/ + 4ll * (kPrepHashSlots / 2 + 2) /*cbase*/ + 4ll * kPrepLinks +
                                       4ll * (kMaxNodes + 3) + 16;
-AMBI_HD int64_t prepare_persistent_bytes(int n, int K) {
-    return pad8(sizeof(Dag)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1)) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(4ll * (n + 1));
+AMBI_HD int64_t prepare_persistent_bytes(int K) {
+    return pad8(sizeof(Dag)) + pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
 }
 AMBI_HD int64_t prepare_junction_bytes(int n, int m) {
-    return pad8(int64_t(sizeof(JuncEnds)) * m) + pad8(8ll * (n + 1)) + pad8(16ll * (n + 1)) + pad8(4ll * (n + 1)) + pad8(4ll * (n + 2)) +
-           2 * pad8(4ll * m) + pad8(m);
+    return pad8(int64_t(sizeof(JuncEnds)) * m) + pad8(4ll * (n + 1)) + pad8(4ll * (n + 2)) + pad8(2ll * m) + pad8(m) + pad8(4 * 64) +
+           pad8(sizeof(Rec3) * 64);
 }
 AMBI_HD int64_t prepare_work_bytes(int n, int m, int K) {
     const int64_t a = prepare_junction_bytes(n, m), b = pad8(kPrepLatticeBytes);
-    return prepare_persistent_bytes(n, K) + (a > b ? a : b);
+    return prepare_persistent_bytes(K) + (a > b ? a : b);
 }
 AMBI_HD PrepareWork carve_prepare(uint8_t* base, int n, int m, int K) {
     PrepareWork W;
     int64_t o = 0;
     W.dag = reinterpret_cast<Dag*>(base + o); o += pad8(sizeof(Dag));
     W.elems = reinterpret_cast<Element*>(base + o); o += pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
-    W.idx = reinterpret_cast<int32_t*>(base + o); o += pad8(4 * 64);
-    W.loops = reinterpret_cast<Rec3*>(base + o); o += pad8(sizeof(Rec3) * 64);
-    W.target_cn = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
     W.lattice_mem = base + o;
-    W.seg_cn = reinterpret_cast<double*>(base + o); o += pad8(8ll * (n + 1));
-    W.junc_cn = reinterpret_cast<double*>(base + o); o += pad8(16ll * (n + 1));
     W.ends = reinterpret_cast<JuncEnds*>(base + o); o += pad8(int64_t(sizeof(JuncEnds)) * m);
     W.inv_junc = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 1));
     W.slot_cnt = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 2));
-    W.fb = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
-    W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
-    W.taken = base + o;
+    W.list = reinterpret_cast<uint16_t*>(base + o); o += pad8(2ll * m);
+    W.taken = base + o; o += pad8(m);
+    W.idx = reinterpret_cast<int32_t*>(base + o); o += pad8(4 * 64);
+    W.loops = reinterpret_cast<Rec3*>(base + o);
     return W;
 }
 AMBI_HD LatticeWork carve_prepare_lattice(uint8_t* h) {
@@ -140,31 +138,35 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     UnitOut* out = unit_out(A.results, u);
     AMBI_MARK(A, g, u, 0);
 
-    // staging: junction ends (4 of the 24 bytes of a record), segment CN and the solution elements
+    // staging: junction ends (4 of the 24 bytes of a record) and the solution elements into group memory; the segment
+    // CNs go straight into their slot of the result blob (getIndelBias edits them there)
     const JuncView J{W.ends, A.juncs + U.junc_off};
+    double* junc_cn = reinterpret_cast<double*>(res + Lay.junc_cn);
+    double* seg_cn = reinterpret_cast<double*>(res + Lay.seg_cn);
+    int32_t* target_cn = W.slot_cnt;
     for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(J.full[j]);
-    copy_words(g, reinterpret_cast<uint32_t*>(W.seg_cn), reinterpret_cast<const uint32_t*>(A.seg_cn + U.seg_off),
-               2ll * (n + 1));
+    copy_words(g, reinterpret_cast<uint32_t*>(seg_cn), reinterpret_cast<const uint32_t*>(A.seg_cn + U.seg_off), 2ll * (n + 1));
     copy_words(g, reinterpret_cast<uint32_t*>(W.elems), reinterpret_cast<const uint32_t*>(A.elems + U.elem_off),
                int64_t(sizeof(Element) / 4) * K);
-    for (int i = g.tid(); i <= n; i += g.size()) W.target_cn[i] = 0;
     g.sync();
     AMBI_MARK(A, g, u, 1);
 
     int status = ST_OK;
     double inv_sum = 0;
-    get_junc_cn_g(g, n, J, m, W.junc_cn, W.inv_junc, W.slot_cnt, W.fb);                  // localhap.cpp:136-139
+    get_junc_cn_g(g, n, J, m, junc_cn, W.inv_junc, W.slot_cnt, W.list);                    // localhap.cpp:136-139
     AMBI_MARK(A, g, u, 2);
-    const int bias = compute_bias_g(g, n, J, W.junc_cn, W.inv_junc);                      // :141-146
+    const int bias = compute_bias_g(g, n, J, junc_cn, W.inv_junc);                        // :141-146
     AMBI_MARK(A, g, u, 3);
-    get_indel_bias_g(g, n, J, m, W.seg_cn, W.sv, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
+    get_indel_bias_g(g, n, J, m, seg_cn, W.list, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
     AMBI_MARK(A, g, u, 4);
-    const bool no_fbi = no_foldback_g(g, n, W.junc_cn, &inv_sum);                         // :150-153
+    const bool no_fbi = no_foldback_g(g, n, junc_cn, &inv_sum);                           // :150-153
+    bool have_target = false;
     if (no_fbi && !U.has_components) status = ST_SHORTCUT;                                // :164
     else if (U.infeasible) status = ST_INFEASIBLE;                                        // :213
     else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
     else {
-        target_cn_g(g, W.elems, K, n, W.target_cn, W.slot_cnt);                           // :222-232
+        target_cn_g(g, W.elems, K, n, target_cn, W.slot_cnt);                             // :222-232 (in place)
+        have_target = true;
         AMBI_MARK(A, g, u, 5);
         DagScratch DS{W.idx, W.loops};
         status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS);                  // :236
@@ -172,11 +174,11 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     g.sync();
     AMBI_MARK(A, g, u, 6);
 
-    // results: junc_cn, seg_cn (after indel bias), target_cn, fold-back map -- before the lattice search takes over
-    // the junction-phase memory
-    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.junc_cn), reinterpret_cast<const uint32_t*>(W.junc_cn), 4ll * (n + 1));
-    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.seg_cn), reinterpret_cast<const uint32_t*>(W.seg_cn), 2ll * (n + 1));
-    copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.target_cn), reinterpret_cast<const uint32_t*>(W.target_cn), int64_t(n + 1));
+    // results that still sit in group memory: target_cn, fold-back map -- before the lattice search takes the bytes
+    {
+        int32_t* gt = reinterpret_cast<int32_t*>(res + Lay.target_cn);
+        for (int i = g.tid(); i <= n; i += g.size()) gt[i] = have_target ? target_cn[i] : 0;
+    }
     copy_words(g, reinterpret_cast<uint32_t*>(res + Lay.inv_junc), reinterpret_cast<const uint32_t*>(W.inv_junc), int64_t(n + 1));
     {
         int16_t* isrc = reinterpret_cast<int16_t*>(res + Lay.inv_src);
