@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box from the repo root):
+#   gpurun --timeout 900 -- 'bash profiles/tools/collect.sh r01'
+# Every pass is its own rocprofv3 run (counters never share a run with traces other than --kernel-trace); the rocpd
+# databases go to gpurun_out/prof_<tag>/, the summaries (CSV / JSON) to gpurun_out/profiles_<tag>/ for copying into
+# profiles/.
+set -eo pipefail
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+SUM=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT" "$SUM"
+export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --steps 10 --warmup 3"
+
+pass() {   # name, rocprofv3 flags ...
+    local name=$1; shift
+    rm -rf "$OUT/$name"
+    (cd /tmp && timeout -k 10 240 rocprofv3 "$@" -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1)
+    find "$OUT/$name" -name '*_results.db' | head -1
+}
+
+db=$(pass stats --kernel-trace --stats)
+python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_bench_b4096_kernel_stats.csv"
+db=$(AMBI_OVERLAP_BACK=0 AMBI_BUILD_IN_EMIT=0 pass serial --kernel-trace --stats)
+python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_bench_b4096_serial_kernel_stats.csv"
+wr=$(pass pmc_write --kernel-trace --pmc WRITE_SIZE)
+python3 profiles/summarize_rocpd.py pmc "$wr" "$SUM/${TAG}_bench_b4096_pmc_write.csv" > /dev/null
+rd=$(pass pmc_fetch --kernel-trace --pmc FETCH_SIZE)
+python3 profiles/summarize_rocpd.py pmc "$rd" "$SUM/${TAG}_bench_b4096_pmc_fetch.csv" > /dev/null
+python3 profiles/summarize_rocpd.py traffic "$wr" "$rd" "$SUM/traffic_${TAG}.json" --batch 4096
+db=$(pass pmc_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS)
+python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_bench_b4096_pmc_sq.csv" > /dev/null
+tail -2 "$OUT/stats.log"
+ls -la "$SUM"
