@@ -131,18 +131,16 @@ struct BatchArgs {
     // scratch for indel grouping (per unit: sv[m], grp[2m+4] ints, taken[m] bytes)
     int32_t* scratch_i32;
     int64_t* scratch_off;        // [U] offset (ints) into scratch_i32
+    // single-slice runs hand the two host-visible scalars over without copy commands: the prepare kernel zeroes
+    // n_pending, the plan kernel stores orders_needed and the finish kernel n_pending straight into pinned host memory
+    int32_t zero_pending;        // 1: block 0 of the prepare kernel zeroes *n_pending
+    int32_t* host_pending;       // device address of a pinned host int32 (nullptr: the host copies n_pending itself)
+    int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)
     int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)
 };
 
 // stage-level timing marks (diagnostics only; one predictable branch per mark when off)
 constexpr int kStageSlots = 32;
-AMBI_HD int64_t stage_clock() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (int64_t)__builtin_readcyclecounter();
-#else
-    return 0;
-#endif
-}
 #define AMBI_MARK(A, g, u, slot) \
     do { if ((A).stage_clk && (g).tid() == 0) (A).stage_clk[(int64_t)(u) * kStageSlots + (slot)] = stage_clock(); } while (0)
 

@@ -97,4 +97,15 @@ struct Dag {
     uint64_t pred[64];     // transposed
 };
 
+// shader-clock marks inside the per-unit stages (diagnostics, env AMBI_STAGE_PROFILE): clk = the unit's mark array or nullptr
+AMBI_HD int64_t stage_clock() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int64_t)__builtin_readcyclecounter();
+#else
+    return 0;
+#endif
+}
+template <class G>
+AMBI_HD void clk_mark(const G& g, int64_t* clk, int slot) { if (clk && g.tid() == 0) clk[slot] = stage_clock(); }
+
 }  // namespace ambi

@@ -43,6 +43,7 @@ extern __shared__ __align__(16) uint8_t ambi_lds[];
 
 __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.n_pending = 0;   // nothing counts pending units before the scan
     stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     if (threadIdx.x == 0) {
         A.blk_off[A.n_units] = blk_carry;
         *A.orders_needed = off_carry;
+        if (A.host_needed) *A.host_needed = off_carry;
     }
 }
 
@@ -394,6 +396,8 @@ __global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int u = unit_list ? unit_list[blockIdx.x] : A.unit_base + (int)blockIdx.x;
+    // the scan kernel is complete (stream order): its count of units left for the parallel search goes to the host
+    if (A.host_pending && !unit_list && blockIdx.x == 0 && threadIdx.x == 0) *A.host_pending = *A.n_pending;
     stage_finish(g, A, u, ambi_lds);
 }
 
@@ -446,6 +450,7 @@ class HipBackend : public Backend {
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
     int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned
+    int32_t* dh_npending_ = nullptr; int64_t* dh_needed_ = nullptr; // the same two, as the device addresses them
     BatchArgs A_{};
     int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_enum_ = 0;
     std::vector<KernelTime> times_;
@@ -478,13 +483,20 @@ class HipBackend : public Backend {
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
+        d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
+        d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
+        d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
+        d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
+        d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
+        h_npending_ = nullptr; h_needed_ = nullptr;
         for (auto& e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         evs_.clear();
         for (auto st : side_) (void)hipStreamDestroy(st);
         side_.clear();
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+        ev_fork_ = nullptr;
         for (auto e : ev_join_) (void)hipEventDestroy(e);
         ev_join_.clear();
         for (auto e : ev_stage_) (void)hipEventDestroy(e);
@@ -515,6 +527,7 @@ class HipBackend : public Backend {
     int upload(const HostBatch& hb, const EngineConfig& cfg) override {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
+        if (uploaded_) { free_all(); uploaded_ = false; ran_ = false; general_path_ = -1; timed_runs_ = 0; }   // a second upload replaces the first
         hb_ = hb; cfg_ = cfg;
         const size_t U = hb.units.size();
         int rc;
@@ -545,6 +558,11 @@ class HipBackend : public Backend {
         if (getenv("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
         HIP_CK(hipHostMalloc((void**)&h_npending_, sizeof(int32_t)));
         HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t) * kMaxSlices));
+        *h_npending_ = 0;
+        dh_npending_ = nullptr; dh_needed_ = nullptr;
+        if (hipHostGetDevicePointer((void**)&dh_npending_, h_npending_, 0) != hipSuccess) dh_npending_ = nullptr;
+        if (hipHostGetDevicePointer((void**)&dh_needed_, h_needed_, 0) != hipSuccess) dh_needed_ = nullptr;
+        (void)hipGetLastError();
         arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
         HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
         HIP_CK(hipMemcpy(d_units_, hb.units.data(), U * sizeof(UnitIn), hipMemcpyHostToDevice));
@@ -642,6 +660,7 @@ class HipBackend : public Backend {
         A_.order_arena = d_arena_; A_.order_arena_bytes = arena_bytes_;
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
+        A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr;
     }
     BatchArgs slice_args(int s) const {
         BatchArgs A = A_;
@@ -730,7 +749,9 @@ class HipBackend : public Backend {
         bind(flags);
         all_done_ = false;
         const int U = A_.n_units;
-        HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
+        // one slice, arena sized: no copy commands around the kernels (see BatchArgs::zero_pending)
+        const bool direct = arena_checked_ && n_slices_ == 1 && dh_npending_ && dh_needed_;
+        if (!direct) HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
         if (!arena_checked_) {
             // first run of this batch: size the arena regions of the slices from what their order tables need
             for (int s = 0; s < n_slices_; s++) launch_front(0, slice_args(s));   // all on the caller's stream
@@ -753,6 +774,7 @@ class HipBackend : public Backend {
             arena_checked_ = true;
         }
         overlap_back_ = want_overlap_ && back_stream_ != nullptr && arena_checked_ && n_slices_ == 1;
+        if (direct) { A_.zero_pending = 1; A_.host_pending = dh_npending_; A_.host_needed = dh_needed_; }
         // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
         // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
         // share the chip instead of alternating.
@@ -768,8 +790,10 @@ class HipBackend : public Backend {
         }
         HIP_CK(hipGetLastError());
         join();
-        HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
+        if (!direct) {
+            HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+            HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
+        }
         ran_ = true;
         if (timing_) timed_runs_++;
         return 0;
@@ -871,14 +895,17 @@ class HipBackend : public Backend {
         const size_t U = hb_.units.size();
         std::vector<int64_t> clk(U * kStageSlots);
         if (hipMemcpy(clk.data(), d_stage_clk_, clk.size() * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return;
-        fprintf(stderr, "ambigram_hip stage profile (mean cycles between marks, %zu units):", U);
+        // marks 0-8 and 22-31: prepare (22-24 inside constructDAG, 26-28 inside the lattice); 9-12: scan; 16-21: finish
+        fprintf(stderr, "ambigram_hip stage profile (mean cycles from the first mark of the stage, %zu units):", U);
         for (int s = 1; s < kStageSlots; s++) {
+            const int base = (s <= 8 || s >= 22 || (s >= 13 && s <= 15)) ? 0 : (s <= 12 ? 9 : 16);
+            if (s == base) continue;
             double sum = 0; size_t cnt = 0;
             for (size_t u = 0; u < U; u++) {
-                const int64_t a = clk[u * kStageSlots + s - 1], b = clk[u * kStageSlots + s];
+                const int64_t a = clk[u * kStageSlots + base], b = clk[u * kStageSlots + s];
                 if (a && b && b >= a) { sum += (double)(b - a); cnt++; }
             }
-            if (cnt) fprintf(stderr, " [%d->%d] %.0f", s - 1, s, sum / cnt);
+            if (cnt) fprintf(stderr, " [%d]=%.0f", s, sum / cnt);
         }
         fprintf(stderr, "\n");
     }

@@ -26,7 +26,17 @@ AMBI_HD int atomic_add_i32(int* p, int v) {
 #endif
 }
 
+// element `i` (uniform over the wavefront) of a value held one element per lane; device code of wavefront groups only
+AMBI_HD uint32_t lane_get_u32(uint32_t v, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+#else
+    (void)i; return v;
+#endif
+}
+
 struct HostGroup {
+    static constexpr bool kLaneArrays = false;   // no cross-lane register arrays (ambi_sort.hpp: LaneWords)
     AMBI_HD int tid() const { return 0; }
     AMBI_HD int size() const { return 1; }
     AMBI_HD void sync() const {}
@@ -35,6 +45,7 @@ struct HostGroup {
     AMBI_HD int sum_i32(int v) const { return v; }
     AMBI_HD bool any(bool p) const { return p; }
     AMBI_HD int bcast_i32(int v, int /*src*/) const { return v; }
+    AMBI_HD uint64_t bcast_u64(uint64_t v, int /*src*/) const { return v; }   // src must be uniform over the group
     // exclusive prefix sum over the group in thread order; total returned through *total
     AMBI_HD int exscan_i32(int v, int* total) const { *total = v; return 0; }
     // sub-groups: runs of up to 64 consecutive threads (a wavefront on the GPU) that can rank flags without a barrier
@@ -44,12 +55,15 @@ struct HostGroup {
     AMBI_HD int sub_lane() const { return 0; }
     // number of set flags among the lower threads of my sub-group; *count = set flags in the whole sub-group
     AMBI_HD int flag_rank(bool q, int* count) const { *count = q ? 1 : 0; return 0; }
+    // the same over the WHOLE group: number of set flags among the lower threads; *count = set flags in the group
+    AMBI_HD int flag_exscan(bool q, int* count) const { *count = q ? 1 : 0; return 0; }
 };
 
 #if defined(__HIPCC__)
 
 // One wavefront (64 lanes on gfx950). Lanes run in lockstep; sync() only has to order LDS traffic.
 struct WaveGroup {
+    static constexpr bool kLaneArrays = true;
     __device__ inline int tid() const { return (int)(threadIdx.x & 63u); }
     __device__ inline int size() const { return 64; }
     __device__ inline void sync() const {
@@ -98,6 +112,11 @@ struct WaveGroup {
     __device__ inline int sum_i32(int v) const { return __builtin_amdgcn_readlane(incl_scan_i32(v), 63); }
     __device__ inline bool any(bool p) const { return __ballot(p) != 0ull; }
     __device__ inline int bcast_i32(int v, int src) const { return __shfl(v, src, 64); }
+    __device__ inline uint64_t bcast_u64(uint64_t v, int src) const {   // uniform src: two v_readlane, no LDS crossbar
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+        return ((uint64_t)hi << 32) | lo;
+    }
     __device__ inline int exscan_i32(int v, int* total) const {
         const int x = incl_scan_i32(v);
         *total = __builtin_amdgcn_readlane(x, 63);
@@ -112,10 +131,12 @@ struct WaveGroup {
         *count = __popcll(b);
         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     }
+    __device__ inline int flag_exscan(bool q, int* count) const { return flag_rank(q, count); }
 };
 
 // One workgroup. `scratch` points at >= 40 ints of LDS reserved for the reductions.
 struct BlockGroup {
+    static constexpr bool kLaneArrays = false;
     int* scratch;
     __device__ inline explicit BlockGroup(int* s) : scratch(s) {}
     __device__ inline int tid() const { return (int)threadIdx.x; }
@@ -142,6 +163,10 @@ struct BlockGroup {
         __syncthreads();
         return scratch[32];
     }
+    __device__ inline uint64_t bcast_u64(uint64_t v, int src) const {
+        const uint32_t lo = (uint32_t)bcast_i32((int)(uint32_t)v, src), hi = (uint32_t)bcast_i32((int)(uint32_t)(v >> 32), src);
+        return ((uint64_t)hi << 32) | lo;
+    }
     __device__ inline int exscan_i32(int v, int* total) const {
         WaveGroup w;
         int wt;
@@ -159,6 +184,7 @@ struct BlockGroup {
     __device__ inline int n_subs() const { return nwaves(); }
     __device__ inline int sub_lane() const { return (int)(threadIdx.x & 63u); }
     __device__ inline int flag_rank(bool q, int* count) const { WaveGroup w; return w.flag_rank(q, count); }
+    __device__ inline int flag_exscan(bool q, int* count) const { return exscan_i32(q ? 1 : 0, count); }
 };
 
 #endif  // __HIPCC__

@@ -63,9 +63,34 @@ AMBI_HD uint64_t avail_mask(const uint64_t* pred, int K, uint64_t I) {
     return out & ~I;
 }
 
+// two 32-bit multiplies (a 64-bit multiply is four quarter-rate instructions on the GPU, and the insert is on the
+// critical path of every lattice level); the high half of the product is folded into the low bits the table uses
+// The same with pred[] held one node per lane in a vector register (wavefront groups, K <= 64): the loop index is
+// uniform, so pred[v] arrives through v_readlane in a scalar register and the mask costs no memory access at all.
+template <class G>
+AMBI_HD uint64_t avail_mask_g(const G& g, const uint64_t* pred, uint64_t pred_lane, int K, uint64_t I) {
+    if constexpr (G::kLaneArrays) {
+        if (K <= 32) {
+            const uint32_t i32 = (uint32_t)I, pl = (uint32_t)pred_lane;
+            uint32_t o = 0;
+            for (int v = 0; v < K; v++) o |= (uint32_t)((lane_get_u32(pl, v) & ~i32) == 0) << v;
+            return (uint64_t)(o & ~i32);
+        }
+        uint64_t out = 0;
+        for (int v = 0; v < K; v++) {
+            const uint64_t p = ((uint64_t)lane_get_u32((uint32_t)(pred_lane >> 32), v) << 32) | lane_get_u32((uint32_t)pred_lane, v);
+            out |= (uint64_t)((p & ~I) == 0) << v;
+        }
+        return out & ~I;
+    } else {
+        return avail_mask(pred, K, I);
+    }
+}
+
 AMBI_HD uint32_t hash_mask(uint64_t k) {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return (uint32_t)k;
+    uint32_t h = (uint32_t)k * 0x9E3779B1u;
+    h ^= (uint32_t)(k >> 32) * 0x85EBCA6Bu;
+    return h ^ (h >> 15);
 }
 
 // The frozen lattice of one unit (HBM): ideals numbered 0..nI-1 in discovery (level) order, 0 = empty ideal.
@@ -107,13 +132,10 @@ AMBI_HD int ideal_insert(const LatticeWork& W, uint64_t key, bool* fresh) {
     uint32_t h = hash_mask(key) & (uint32_t)(W.cap - 1);
     *fresh = false;
     for (int probe = 0; probe < W.cap; probe++) {
-        uint64_t k = W.keys[h];
-        if (k == key) return (int)h;
-        if (k == kEmptyKey) {
-            uint64_t old = atomic_cas_u64(&W.keys[h], kEmptyKey, key);
-            if (old == kEmptyKey) { *fresh = true; return (int)h; }
-            if (old == key) return (int)h;
-        }
+        // one round trip per probe: the compare-and-swap itself tells "free (now mine)", "already there" or "occupied"
+        const uint64_t old = atomic_cas_u64(&W.keys[h], kEmptyKey, key);
+        if (old == kEmptyKey) { *fresh = true; return (int)h; }
+        if (old == key) return (int)h;
         h = (h + 1) & (uint32_t)(W.cap - 1);
     }
     return -1;
@@ -129,7 +151,7 @@ AMBI_HD int ideal_insert(const LatticeWork& W, uint64_t key, bool* fresh) {
 // Returns status; *R_out = number of topological orders (saturated at 2^62).
 template <class G>
 AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const LatticeWork& W, const IdealTable& T, uint64_t* R_out,
-                                  uint8_t* first_rows = nullptr, int first_count = 0) {
+                                  uint8_t* first_rows = nullptr, int first_count = 0, int64_t* clk = nullptr) {
     int maxIdeals = W.cap / 2;
     if (maxIdeals > 65535) maxIdeals = 65535;
     for (int i = g.tid(); i < W.cap; i += g.size()) W.keys[i] = kEmptyKey;
@@ -140,52 +162,67 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
         W.pos[s] = 0; W.ikey[0] = 0ull; W.lvl_off[0] = 0; W.lvl_off[1] = 1; W.counter[0] = 1; W.counter[1] = 0;
     }
     g.sync();
+    // The level bounds and the ideal counter are carried in registers (uniform over the group); the indices of the new
+    // ideals of a step come from a flag rank over the group (no atomic, no round trip through the counter in memory).
     int overflow = 0, last_level = 0, links = 0;
+    int lo = 0, hi = 1, count = 1;
+    const uint64_t pred_lane = (G::kLaneArrays && g.tid() < K) ? pred[g.tid()] : 0ull;
     for (int d = 0; d <= K; d++) {
-        const int lo = W.lvl_off[d], hi = W.lvl_off[d + 1];
         if (hi == lo) break;
+        if (d == 5) clk_mark(g, clk, 13);
         for (int base = lo; base < hi; base += g.size()) {
             const int idx = base + g.tid();
             uint64_t I = 0, av = 0;
             int nch = 0;
             if (idx < hi) {
                 I = W.ikey[idx];
-                av = avail_mask(pred, K, I);
+                av = avail_mask_g(g, pred, pred_lane, K, I);
                 W.cnt[idx] = av;   // parked here until the search is over (no store to HBM inside the level loop)
                 nch = popc64(av);
             }
+            if (d == 5) clk_mark(g, clk, 14);
             int tot;
             const int ex = g.exscan_i32(nch, &tot);
+            int k = links + ex;
             if (idx < hi) {
-                int k = links + ex;
                 W.cbase[idx] = k;
-                if (k + nch > W.link_cap) overflow = 1;
-                else {
-                    while (av) {
-                        const int v = ctz64(av);
-                        av &= av - 1;
-                        bool fresh;
-                        const uint64_t child = I | (1ull << v);
-                        const int s = ideal_insert(W, child, &fresh);
-                        if (s < 0) { overflow = 1; break; }
-                        if (fresh) {
-                            const int p = atomic_add_i32(W.counter, 1);
-                            if (p >= maxIdeals) { overflow = 1; break; }
-                            W.ikey[p] = child;
-                            W.pos[s] = p;
-                        }
-                        W.link[k++] = (uint32_t)s;
-                    }
+                if (k + nch > W.link_cap) { overflow = 1; av = 0; }
+            }
+            if (d == 5) clk_mark(g, clk, 15);
+            // step r inserts the r-th child of every ideal of the chunk
+            while (g.any(av != 0)) {
+                bool fresh = false;
+                int s = -1;
+                uint64_t child = 0;
+                if (av) {
+                    const int v = ctz64(av);
+                    av &= av - 1;
+                    child = I | (1ull << v);
+                    s = ideal_insert(W, child, &fresh);
+                    if (s < 0) { overflow = 1; av = 0; }
+                    else W.link[k++] = (uint32_t)s;
                 }
+                int nfresh;
+                const int p = count + g.flag_exscan(fresh, &nfresh);
+                if (fresh) {
+                    if (p >= maxIdeals) { overflow = 1; av = 0; }
+                    else { W.ikey[p] = child; W.pos[s] = p; }
+                }
+                count += nfresh;
             }
             links += tot;
         }
-        g.sync();
+        if (d == 5) clk_mark(g, clk, 29);
         if (g.any(overflow != 0)) return ST_ERR_IDEALS_CAPACITY;
-        if (g.tid() == 0) W.lvl_off[d + 2] = W.counter[0];
+        if (g.tid() == 0) W.lvl_off[d + 2] = count;
         g.sync();
+        lo = hi; hi = count;
         last_level = d + 1;
+        if (d == 5) clk_mark(g, clk, 30);
     }
+    if (g.tid() == 0) W.counter[0] = count;
+    g.sync();
+    clk_mark(g, clk, 26);
     const int nI = W.counter[0];
     if (links > T.child_cap) return ST_ERR_IDEALS_CAPACITY;
     if (g.tid() == 0) { W.cbase[nI] = links; W.counter[1] = links; }
@@ -207,6 +244,7 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
         }
         g.sync();
     }
+    clk_mark(g, clk, 27);
     // freeze
     for (int p = g.tid(); p < nI; p += g.size()) T.a_cnt[p] = W.cnt[p];
     if (T.a_cbase != W.cbase) for (int p = g.tid(); p <= nI; p += g.size()) T.a_cbase[p] = W.cbase[p];
@@ -214,6 +252,7 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
     for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) T.lvl_off[d] = (d <= last_level + 1) ? W.lvl_off[d] : nI;
     for (int t = g.tid(); t < 2; t += g.size()) T.counter[t] = t == 0 ? nI : links;
     *R_out = W.cnt[0];
+    clk_mark(g, clk, 28);
     // The first `first_count` orders (rows 0.. of the table, kFirstRowStride bytes apart), unranked here while the lattice
     // is still in group memory: the scan for the first valid order reads them instead of the order table, which takes
     // the enumerate kernel off its critical path.  Descent by counts over the links; the node of a step is the one bit

@@ -284,7 +284,7 @@ struct DagScratch {
 // (kind,a,b)); seg_base turns local ids into the absolute ids the reference's string keys are made of.
 // Every thread returns the same status.
 template <class G>
-AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, Dag& D, const DagScratch& W) {
+AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, Dag& D, const DagScratch& W, int64_t* clk = nullptr) {
     if (K > kMaxNodes) return ST_ERR_TOO_MANY_NODES;
     // node numbering = rank of the key in std::map order.  Every element's two decimal keys are computed once and
     // parked in D.succ / D.pred (initialised further down); the K x K comparison loop then only compares integers.
@@ -308,6 +308,7 @@ AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, 
     g.sync();
     if (g.tid() == 0) D.K = K;
     g.sync();
+    // node tables in map order; the loop records also go to W.loops, from where the sorted order gathers them
     for (int i = g.tid(); i < K; i += g.size()) {
         const Element& e = el[W.idx[i]];
         D.succ[i] = 0; D.pred[i] = 0;
@@ -320,17 +321,37 @@ AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, 
         }
     }
     g.sync();
+    clk_mark(g, clk, 22);
+    // std::sort(node2loop, compareLoops) (LGM.cpp:3303): replay of the library's algorithm on one key word per record
+    // (ambi_sort.hpp); afterwards position i takes the record whose original position is in the key's low byte
     int ub = 0;
-    if (g.tid() == 0) {
+    if constexpr (G::kLaneArrays) {
+        // keys and the stack of parked parts in two vector registers, one element per lane; all lanes run the replay
+        const int t = g.tid();
+        LaneWords keys{t < K ? loop_sort_key(W.loops[t].v[0], W.loops[t].v[1], t) : 0u, t}, stk{0u, t};
         bool u = false;
-        libstdcxx_sort_loops(W.loops, K, &u, reinterpret_cast<uint32_t*>(W.idx));   // LGM.cpp:3303 (idx is free by now)
+        libstdcxx_sort_keys(keys, K, &u, stk);
         ub = u ? 1 : 0;
+        if (!ub && t < K) { const Rec3 r = W.loops[keys.v & 255u]; D.loop[t][0] = r.v[0]; D.loop[t][1] = r.v[1]; D.loop[t][2] = r.v[2]; }
+    } else {
+        uint32_t* kw = reinterpret_cast<uint32_t*>(W.idx);   // the node order is consumed: idx is free
+        uint32_t* sw = reinterpret_cast<uint32_t*>(D.pred);  // not yet in use (zeroed again below)
+        for (int i = g.tid(); i < K; i += g.size()) kw[i] = loop_sort_key(W.loops[i].v[0], W.loops[i].v[1], i);
+        g.sync();
+        if (g.tid() == 0) {
+            MemWords keys{kw}, stk{sw};
+            bool u = false;
+            libstdcxx_sort_keys(keys, K, &u, stk);
+            ub = u ? 1 : 0;
+        }
+        ub = g.bcast_i32(ub, 0);
+        g.sync();
+        if (!ub) for (int i = g.tid(); i < K; i += g.size()) { const Rec3 r = W.loops[kw[i] & 255u]; D.loop[i][0] = r.v[0]; D.loop[i][1] = r.v[1]; D.loop[i][2] = r.v[2]; }
+        for (int i = g.tid(); i < K; i += g.size()) D.pred[i] = 0;
     }
-    ub = g.bcast_i32(ub, 0);
     if (ub) return ST_ERR_REF_UB;
     g.sync();
-    for (int i = g.tid(); i < K; i += g.size()) { D.loop[i][0] = W.loops[i].v[0]; D.loop[i][1] = W.loops[i].v[1]; D.loop[i][2] = W.loops[i].v[2]; }
-    g.sync();
+    clk_mark(g, clk, 23);
     // p -> p and p -> l edges: static tests, one thread per source node (LGM.cpp:3311-3338)
     for (int i = g.tid(); i < K; i += g.size()) {
         if (D.pat[i][0] == 0) continue;
@@ -345,33 +366,29 @@ AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, 
         while (o) { int j = __builtin_ctzll(o); o &= o - 1; atomic_or_u64(&D.pred[j], 1ull << i); }
     }
     g.sync();
-    // loops in index order (LGM.cpp:3339-3377): the "inherited from a parent" rule reads pred[i] and succ[parent] as
-    // they stand when loop i is processed, so the loop over i stays sequential; the scan over j is parallel.
+    clk_mark(g, clk, 24);
+    // loops in index order (LGM.cpp:3339-3377).  The "inherited from a parent" rule reads pred[i] and succ[parent] as
+    // they stand when loop i is processed, so the loop over i stays sequential -- but it needs no barrier: thread j
+    // owns column j (pred[j]: every edge into j, written by nobody else in this loop), "succ[parent] has j" is the
+    // same fact as "pred[j] has parent", and pred[i] is handed round by its owner.  Per step: l -> p over all j with
+    // the state before the step, then l -> l (static test), exactly the reference's two inner loops.
     for (int i = 0; i < K; i++) {
-        if (D.loop[i][0] == 0) continue;
-        const int d1 = iabs(D.loop[i][0] - D.loop[i][1]);
-        const uint64_t pred_i = D.pred[i];
-        g.sync();
-        for (int j = g.tid(); j < K; j += g.size()) {   // l -> p
-            if (pred_i & (1ull << j)) continue;
-            if (D.pat[j][0] != 0 && (D.loop[i][0] == D.pat[j][0] || D.loop[i][1] == D.pat[j][1])) {
-                bool add = d1 > iabs(D.pat[j][0] - D.pat[j][1]);
-                if (!add) {
-                    uint64_t par = pred_i;
-                    while (par) { int p = __builtin_ctzll(par); par &= par - 1; if (D.succ[p] & (1ull << j)) { add = true; break; } }
-                }
-                if (add) { atomic_or_u64(&D.succ[i], 1ull << j); atomic_or_u64(&D.pred[j], 1ull << i); }
-            }
+        const int la = D.loop[i][0], lb = D.loop[i][1];
+        if (la == 0) continue;
+        const int d1 = iabs(la - lb);
+        const int owner = i % g.size();
+        const uint64_t pred_i = g.bcast_u64(g.tid() == owner ? D.pred[i] : 0ull, owner);
+        for (int j = g.tid(); j < K; j += g.size()) {
+            const uint64_t mine = D.pred[j];
+            const int pa = D.pat[j][0], pb = D.pat[j][1], qa = D.loop[j][0], qb = D.loop[j][1];
+            bool edge = false;
+            if (!((pred_i >> j) & 1ull) && pa != 0 && (la == pa || lb == pb))                  // l -> p
+                edge = d1 > iabs(pa - pb) || (pred_i & mine) != 0;                             //   own size, or inherited from a parent
+            if (qa != 0 && (la == qa || lb == qb) && d1 > iabs(qa - qb)) edge = true;          // l1 -> l2
+            if (edge) { D.pred[j] = mine | (1ull << i); atomic_or_u64(&D.succ[i], 1ull << j); }
         }
-        g.sync();
-        for (int j = g.tid(); j < K; j += g.size()) {   // l1 -> l2
-            if (D.loop[j][0] != 0 && (D.loop[i][0] == D.loop[j][0] || D.loop[i][1] == D.loop[j][1]) && d1 > iabs(D.loop[j][0] - D.loop[j][1])) {
-                atomic_or_u64(&D.succ[i], 1ull << j);
-                atomic_or_u64(&D.pred[j], 1ull << i);
-            }
-        }
-        g.sync();
     }
+    g.sync();
     return ST_OK;
 }
 

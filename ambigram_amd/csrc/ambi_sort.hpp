@@ -9,7 +9,15 @@
 // To stay bit-exact on the GPU the engine replays the library's algorithm itself.  tests/test_sort_replica.py
 // checks this file against the real std::sort with the same comparator on random inputs (n = 0..64).
 //
-// Records are 3 x int32 (a, b, cn); a == 0 marks an empty slot.  Single-threaded by design (K <= 64).
+// Records are 3 x int32 (a, b, cn); a == 0 marks an empty slot.  The comparator looks at (empty?, |a-b|) only, so the
+// replay runs on one 32-bit word per record: key = { rank : 24 | original position : 8 } with rank = 0 for an empty
+// slot and |a-b| + 1 otherwise; compareLoops(x, y) == (rank(y) != 0 && rank(x) > rank(y)).  The caller permutes the
+// records by the position bytes afterwards.
+//
+// The algorithm is sequential (K <= 64), so on the GPU its cost is the latency of its dependent array accesses.  The
+// array type is a template parameter: MemWords = plain memory (host, tests); LaneWords = ONE vector register, element
+// i in lane i, read and written with v_readlane / v_writelane -- every lane of the wavefront runs the same scalar
+// program (indices and keys live in scalar registers), and an access costs a few cycles instead of an LDS round trip.
 #pragma once
 #include "ambi_common.hpp"
 
@@ -23,82 +31,103 @@ AMBI_HD bool compare_loops(const Rec3& x, const Rec3& y) {
     if (x.v[0] != 0 && y.v[0] != 0) { d1 = iabs(x.v[0] - x.v[1]); d2 = iabs(y.v[0] - y.v[1]); }
     return d1 > d2;
 }
+AMBI_HD uint32_t loop_sort_key(int a, int b, int pos) { return ((a != 0 ? (uint32_t)iabs(a - b) + 1u : 0u) << 8) | (uint32_t)pos; }
+AMBI_HD bool compare_keys(uint32_t x, uint32_t y) { return (y >> 8) != 0u && (x >> 8) > (y >> 8); }
 
+struct MemWords {
+    uint32_t* a;
+    AMBI_HD uint32_t get(int i) const { return a[i]; }
+    AMBI_HD void set(int i, uint32_t x) { a[i] = x; }
+};
+struct LaneWords {   // all 64 lanes call get/set together with the same (uniform) arguments; device code only
+    uint32_t v;
+    int lane;   // this thread's lane number
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ inline uint32_t get(int i) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+    __device__ inline void set(int i, uint32_t x) { v = (lane == i) ? x : v; }   // v_cmp + v_cndmask on scalar operands
+#else
+    AMBI_HD uint32_t get(int) const { return v; }
+    AMBI_HD void set(int, uint32_t x) { v = x; }
+#endif
+};
+
+template <class ARR>
 struct SortCtx {
-    Rec3* a;      // array base
+    ARR& a;       // the keys
     int n;        // number of records (guards)
     bool ub;      // an "unguarded" loop left [0,n): the library would have read out of bounds
 };
 
 namespace sortdetail {
 
-AMBI_HD void swp(SortCtx& c, int i, int j) { Rec3 t = c.a[i]; c.a[i] = c.a[j]; c.a[j] = t; }
+template <class C> AMBI_HD void swp(C& c, int i, int j) { const uint32_t t = c.a.get(i); c.a.set(i, c.a.get(j)); c.a.set(j, t); }
 
-AMBI_HD void unguarded_linear_insert(SortCtx& c, int last) {
-    Rec3 val = c.a[last];
+template <class C> AMBI_HD void unguarded_linear_insert(C& c, int last) {
+    const uint32_t val = c.a.get(last);
     int next = last - 1;
     while (true) {
         if (next < 0) { c.ub = true; break; }
-        if (!compare_loops(val, c.a[next])) break;
-        c.a[last] = c.a[next];
+        const uint32_t nx = c.a.get(next);
+        if (!compare_keys(val, nx)) break;
+        c.a.set(last, nx);
         last = next;
         --next;
     }
-    c.a[last] = val;
+    c.a.set(last, val);
 }
 
-AMBI_HD void insertion_sort(SortCtx& c, int first, int last) {
+template <class C> AMBI_HD void insertion_sort(C& c, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-        if (compare_loops(c.a[i], c.a[first])) {
-            Rec3 val = c.a[i];
-            for (int k = i; k > first; --k) c.a[k] = c.a[k - 1];   // move_backward(first, i, i+1)
-            c.a[first] = val;
+        if (compare_keys(c.a.get(i), c.a.get(first))) {
+            const uint32_t val = c.a.get(i);
+            for (int k = i; k > first; --k) c.a.set(k, c.a.get(k - 1));   // move_backward(first, i, i+1)
+            c.a.set(first, val);
         } else {
             unguarded_linear_insert(c, i);
         }
     }
 }
 
-AMBI_HD void push_heap(SortCtx& c, int first, int hole, int top, Rec3 value) {
+template <class C> AMBI_HD void push_heap(C& c, int first, int hole, int top, uint32_t value) {
     int parent = (hole - 1) / 2;
-    while (hole > top && compare_loops(c.a[first + parent], value)) {
-        c.a[first + hole] = c.a[first + parent];
+    while (hole > top && compare_keys(c.a.get(first + parent), value)) {
+        c.a.set(first + hole, c.a.get(first + parent));
         hole = parent;
         parent = (hole - 1) / 2;
     }
-    c.a[first + hole] = value;
+    c.a.set(first + hole, value);
 }
 
-AMBI_HD void adjust_heap(SortCtx& c, int first, int hole, int len, Rec3 value) {
+template <class C> AMBI_HD void adjust_heap(C& c, int first, int hole, int len, uint32_t value) {
     const int top = hole;
     int second = hole;
     while (second < (len - 1) / 2) {
         second = 2 * (second + 1);
-        if (compare_loops(c.a[first + second], c.a[first + (second - 1)])) second--;
-        c.a[first + hole] = c.a[first + second];
+        if (compare_keys(c.a.get(first + second), c.a.get(first + (second - 1)))) second--;
+        c.a.set(first + hole, c.a.get(first + second));
         hole = second;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
         second = 2 * (second + 1);
-        c.a[first + hole] = c.a[first + (second - 1)];
+        c.a.set(first + hole, c.a.get(first + (second - 1)));
         hole = second - 1;
     }
     push_heap(c, first, hole, top, value);
 }
 
-AMBI_HD void pop_heap(SortCtx& c, int first, int last, int result) {
-    Rec3 value = c.a[result];
-    c.a[result] = c.a[first];
+template <class C> AMBI_HD void pop_heap(C& c, int first, int last, int result) {
+    const uint32_t value = c.a.get(result);
+    c.a.set(result, c.a.get(first));
     adjust_heap(c, first, 0, last - first, value);
 }
 
-AMBI_HD void heap_sort_range(SortCtx& c, int first, int last) {   // __partial_sort(first, last, last)
+template <class C> AMBI_HD void heap_sort_range(C& c, int first, int last) {   // __partial_sort(first, last, last)
     int len = last - first;
     if (len >= 2) {   // __make_heap
         int parent = (len - 2) / 2;
         while (true) {
-            Rec3 value = c.a[first + parent];
+            const uint32_t value = c.a.get(first + parent);
             adjust_heap(c, first, parent, len, value);
             if (parent == 0) break;
             parent--;
@@ -109,27 +138,28 @@ AMBI_HD void heap_sort_range(SortCtx& c, int first, int last) {   // __partial_s
     while (l - first > 1) { --l; pop_heap(c, first, l, l); }
 }
 
-AMBI_HD void move_median_to_first(SortCtx& c, int result, int a, int b, int cc) {
-    if (compare_loops(c.a[a], c.a[b])) {
-        if (compare_loops(c.a[b], c.a[cc])) swp(c, result, b);
-        else if (compare_loops(c.a[a], c.a[cc])) swp(c, result, cc);
+template <class C> AMBI_HD void move_median_to_first(C& c, int result, int a, int b, int cc) {
+    const uint32_t ka = c.a.get(a), kb = c.a.get(b), kc = c.a.get(cc);
+    if (compare_keys(ka, kb)) {
+        if (compare_keys(kb, kc)) swp(c, result, b);
+        else if (compare_keys(ka, kc)) swp(c, result, cc);
         else swp(c, result, a);
-    } else if (compare_loops(c.a[a], c.a[cc])) swp(c, result, a);
-    else if (compare_loops(c.a[b], c.a[cc])) swp(c, result, cc);
+    } else if (compare_keys(ka, kc)) swp(c, result, a);
+    else if (compare_keys(kb, kc)) swp(c, result, cc);
     else swp(c, result, b);
 }
 
-AMBI_HD int unguarded_partition(SortCtx& c, int first, int last, int pivot) {
+template <class C> AMBI_HD int unguarded_partition(C& c, int first, int last, int pivot) {
     while (true) {
         while (true) {
             if (first >= c.n) { c.ub = true; return first; }
-            if (!compare_loops(c.a[first], c.a[pivot])) break;
+            if (!compare_keys(c.a.get(first), c.a.get(pivot))) break;
             ++first;
         }
         --last;
         while (true) {
             if (last < 0) { c.ub = true; return first; }
-            if (!compare_loops(c.a[pivot], c.a[last])) break;
+            if (!compare_keys(c.a.get(pivot), c.a.get(last))) break;
             --last;
         }
         if (!(first < last)) return first;
@@ -142,23 +172,23 @@ AMBI_HD int floor_lg(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return 
 
 }  // namespace sortdetail
 
-// std::sort(a, a+n, compareLoops), n <= 1023.  `stack`: kSortStack words of caller memory (group memory on the GPU: a
-// private array indexed at run time would live in scratch, i.e. in HBM) for the parked left parts: one packed word
-// { first : 10, last : 10, depth : 12 } each.  The parked parts have strictly increasing depth budgets from the top of
-// the stack down, so 2*floor(log2 n) + 1 <= 19 words suffice.
+// std::sort(a, a+n, compareLoops) on the keys, n <= 64.  `stack`: kSortStack words for the parked left parts, one
+// packed word { first : 10, last : 10, depth : 12 } each.  The parked parts have strictly increasing depth budgets from
+// the top of the stack down, so 2*floor(log2 n) + 1 <= 13 words suffice.
 constexpr int kSortStack = 24;
-AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub, uint32_t* stack) {
+template <class ARR, class STK>
+AMBI_HD void libstdcxx_sort_keys(ARR& a, int n, bool* ub, STK& stack) {
     using namespace sortdetail;
-    SortCtx c{a, n, false};
-    if (n > 1023) { if (ub) *ub = true; return; }
+    SortCtx<ARR> c{a, n, false};
+    if (n > 64) { if (ub) *ub = true; return; }
     if (n > 0) {
         // __introsort_loop.  The library recurses on the RIGHT part [cut,last) first and afterwards loops on the
         // left part [first,cut) with the same (already decremented) depth; the explicit stack below keeps exactly
         // that processing order: the left part is parked, the right part is handled at once.
         int sp = 0;
-        stack[sp++] = 0u | ((uint32_t)n << 10) | ((uint32_t)(floor_lg(n) * 2) << 20);
+        stack.set(sp++, 0u | ((uint32_t)n << 10) | ((uint32_t)(floor_lg(n) * 2) << 20));
         while (sp > 0 && !c.ub) {
-            const uint32_t f = stack[--sp];
+            const uint32_t f = stack.get(--sp);
             int first = (int)(f & 1023u), last = (int)((f >> 10) & 1023u), depth = (int)(f >> 20);
             while (last - first > 16) {
                 if (depth == 0) { heap_sort_range(c, first, last); break; }
@@ -167,7 +197,7 @@ AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub, uint32_t* stack) {
                 move_median_to_first(c, first, first + 1, mid, last - 1);
                 int cut = unguarded_partition(c, first + 1, last, first);
                 if (c.ub) break;
-                if (sp < kSortStack) stack[sp++] = (uint32_t)first | ((uint32_t)cut << 10) | ((uint32_t)depth << 20);   // left part, resumed after the right part
+                if (sp < kSortStack) stack.set(sp++, (uint32_t)first | ((uint32_t)cut << 10) | ((uint32_t)depth << 20));   // left part, resumed after the right part
                 first = cut;
             }
         }
@@ -182,6 +212,21 @@ AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub, uint32_t* stack) {
         }
     }
     if (ub) *ub = c.ub;
+}
+
+// Record form (tests/hostsim/sort_probe.cpp checks it against the real std::sort with compareLoops): keys from the
+// records, replay, records permuted by the position bytes.  n <= 64; `stack`: kSortStack + 64 words.
+AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub, uint32_t* stack) {
+    if (n > 64) { if (ub) *ub = true; return; }
+    MemWords keys{stack + kSortStack}, stk{stack};
+    for (int i = 0; i < n; i++) keys.a[i] = loop_sort_key(a[i].v[0], a[i].v[1], i);
+    bool u = false;
+    libstdcxx_sort_keys(keys, n, &u, stk);
+    if (ub) *ub = u;
+    if (u) return;
+    Rec3 tmp[64];
+    for (int i = 0; i < n; i++) tmp[i] = a[i];
+    for (int i = 0; i < n; i++) a[i] = tmp[keys.a[i] & 255u];
 }
 
 }  // namespace ambi

@@ -136,6 +136,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     uint8_t* res = A.results + U.res_off;
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
     UnitOut* out = unit_out(A.results, u);
+    int64_t* clk = A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr;
     AMBI_MARK(A, g, u, 0);
 
     // staging: junction ends (4 of the 24 bytes of a record) and the solution elements into group memory; the segment
@@ -169,7 +170,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
         have_target = true;
         AMBI_MARK(A, g, u, 5);
         DagScratch DS{W.idx, W.loops};
-        status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS);                  // :236
+        status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS, clk);                 // :236
     }
     g.sync();
     AMBI_MARK(A, g, u, 6);
@@ -199,7 +200,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
         const IdealTable T = unit_ideal_table(A, u);
         // fast path: search state in group memory (the frozen automaton itself always goes to HBM)
         uint8_t* first_rows = A.first_rows ? A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride : nullptr;
-        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R, first_rows, A.first_budget);
+        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R, first_rows, A.first_budget, clk);
         if (st == ST_ERR_IDEALS_CAPACITY)   // large lattice
             st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R, first_rows, A.first_budget);
         if (st != ST_OK) status = st;
@@ -372,7 +373,9 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     if (out->status != ST_OK) return;
     const UnitIn U = A.units[u];
     FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+    AMBI_MARK(A, g, u, 9);
     load_first_work(g, A, u, W);
+    AMBI_MARK(A, g, u, 10);
     const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
     uint8_t* res = A.results + U.res_off;
     const int K = out->K;
@@ -405,6 +408,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
             forwardDir = !forwardDir;                       // LGM.cpp:3691-3695 (the last order was invalid)
         }
     }
+    AMBI_MARK(A, g, u, 11);
     if (status == ST_OK) {
         cell_t* dst = reinterpret_cast<cell_t*>(res + Lay.bkp);
         for (int i = g.tid(); i < L; i += g.size()) dst[i] = W.bkp[i];
@@ -418,6 +422,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
         if (status == ST_PENDING) atomic_add_i32(A.n_pending, 1);
     }
     g.sync();
+    AMBI_MARK(A, g, u, 12);
 }
 
 // Parallel search support: evaluate ONE order of a unit; returns 1/0/negative.  `work` as in stage_first

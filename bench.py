@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])
     ap.add_argument("--K", type=int, default=19)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
+    ap.add_argument("--single-reps", type=int, default=200, help="repetitions of the single-sample latency leg (0 disables it)")
     ap.add_argument("--target-lanes", type=int, default=0)
     ap.add_argument("--slices", type=int, default=0, help="unit ranges run on separate HIP streams (0: engine default)")
     ap.add_argument("--gather", type=int, default=-1, help="1: the timed region ends with the packing of the paths + ONE RCCL gather to "
@@ -213,6 +214,39 @@ def main():
                          "parse and the variableIdx map: %.1f /s" % (cnt, B, recon, cnt / whole if whole > 0 else 0),
                "host_cores_available": os.cpu_count()}
 
+    # ---- single-sample latency (north star: "single-sample latency speed-up vs reference single-thread CPU") ----
+    # one 256-segment sample resident in HBM: launch of the whole chain -> results complete (host-synchronised), and
+    # the same with the upload of the unit and the download of its path included; the CPU figure is the oracle on the
+    # SAME sample (stages #7,#8,#11-#16,#20), so the ratio compares like with like.
+    single = None
+    if args.single_reps > 0:
+        one = api.Batch(lib)
+        one.add_chromosome_sol(graphs[0], 0, files[0][1][0])
+        one.upload()
+        one.run(0, stream); one.wait()
+        for _ in range(10):
+            one.run(0, stream); one.wait()
+        t1 = time.perf_counter()
+        for _ in range(args.single_reps):
+            one.run(0, stream); one.wait()
+        gpu_ms = (time.perf_counter() - t1) / args.single_reps * 1e3
+        reps2 = max(1, args.single_reps // 4)
+        t1 = time.perf_counter()
+        for _ in range(reps2):
+            one.upload(); one.run(0, stream); one.wait(); one.download(); one.unit_path(0, 1)
+        pcie_ms = (time.perf_counter() - t1) / reps2 * 1e3
+        assert one.unit_path(0, 1).tolist() == batch.unit_path(0, 1).tolist()
+        single = {"gpu_ms": gpu_ms, "gpu_ms_with_upload_and_download": pcie_ms, "reps": args.single_reps,
+                  "sample": "sample 0 of the batch (1 unit, R = %d orders)" % res[0]["num_orders"]}
+        if args.cpu_seconds > 0:
+            best = None
+            for _ in range(5):
+                r = oracle_py.run_bfb(files[0][0], files[0][1])
+                best = r["recon_seconds"] if best is None else min(best, r["recon_seconds"])
+            single["cpu_ms"] = best * 1e3
+            single["speedup"] = best * 1e3 / gpu_ms
+            single["cpu_kind"] = "port (oracle, 1 core, best of 5)"
+
     out = {
         "metric": "BFB reconstructions/sec (synthetic .lh, 256 seg) at 1/2/4/8 MI355X",
         "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -221,7 +255,7 @@ def main():
         "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, default CLI mode; %d samples per GPU resident in HBM"
                                % (args.segs, args.juncs, args.tier, args.K, B),
                    "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths to rank 0 at the end of the timed steps", 2: "; one RCCL gather of the paths to rank 0 at the end of every step"}[gather_mode])},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "single_sample": single,
     }
     print(json.dumps(out))
     if world > 1:
