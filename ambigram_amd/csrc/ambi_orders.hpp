@@ -43,50 +43,42 @@ AMBI_HD uint64_t atomic_cas_u64(uint64_t* p, uint64_t expected, uint64_t desired
 AMBI_HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 AMBI_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
-// nodes that may be appended to the ideal I: not in I, all predecessors in I.  Fixed trip count and addresses that do
-// not depend on the data, so the K loads of pred[] pipeline instead of forming a chain of dependent LDS round trips.
+// nodes that may be appended to the ideal I: not in I, all predecessors in I.  `pred` must have 64 readable entries
+// (entries >= K are read and masked off).  Serial code on a lone wavefront is paid in taken branches (~25 cycles) and
+// dependent memory round trips (~60 cycles from group memory), not in ALU operations (~4 cycles), so the loop is laid
+// out as unrolled chunks of 8 nodes behind uniform guards: the loads of a chunk are independent and pipeline, a node
+// costs three ALU operations ("has a predecessor outside I" -> its bit of the blocked mask).
 AMBI_HD uint64_t avail_mask(const uint64_t* pred, int K, uint64_t I) {
     if (K <= 32) {
-        const uint32_t i32 = (uint32_t)I;
-        uint32_t o = 0;
-        int v = 0;
-        for (; v + 4 <= K; v += 4) {   // four loads in flight
-            const uint32_t p0 = (uint32_t)pred[v], p1 = (uint32_t)pred[v + 1], p2 = (uint32_t)pred[v + 2], p3 = (uint32_t)pred[v + 3];
-            o |= ((uint32_t)((p0 & ~i32) == 0) | ((uint32_t)((p1 & ~i32) == 0) << 1) | ((uint32_t)((p2 & ~i32) == 0) << 2) |
-                  ((uint32_t)((p3 & ~i32) == 0) << 3)) << v;
+        const uint32_t ni = ~(uint32_t)I;
+        uint32_t blocked = 0;
+#define AMBI_AV8(B)                                                                                    \
+        if (K > (B)) {                                                                                 \
+            _Pragma("unroll") for (int v = (B); v < (B) + 8; v++) {                                    \
+                const uint32_t x = (uint32_t)pred[v] & ni;                                             \
+                blocked |= (x < 1u ? x : 1u) << v;                                                     \
+            }                                                                                          \
         }
-        for (; v < K; v++) o |= (uint32_t)((((uint32_t)pred[v]) & ~i32) == 0) << v;
-        return (uint64_t)(o & ~i32);
+        AMBI_AV8(0) AMBI_AV8(8) AMBI_AV8(16) AMBI_AV8(24)
+#undef AMBI_AV8
+        const uint32_t kmask = K >= 32 ? ~0u : ((1u << K) - 1u);
+        return (uint64_t)(~blocked & ni & kmask);
     }
-    uint64_t out = 0;
-    for (int v = 0; v < K; v++) out |= (uint64_t)((pred[v] & ~I) == 0) << v;
-    return out & ~I;
+    const uint64_t ni = ~I;
+    uint64_t blocked = 0;
+    for (int base = 0; base < K; base += 8) {
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const uint64_t x = pred[(base + v) & 63] & ni;
+            blocked |= (uint64_t)(x != 0) << ((base + v) & 63);
+        }
+    }
+    const uint64_t kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+    return ~blocked & ni & kmask;
 }
 
 // two 32-bit multiplies (a 64-bit multiply is four quarter-rate instructions on the GPU, and the insert is on the
 // critical path of every lattice level); the high half of the product is folded into the low bits the table uses
-// The same with pred[] held one node per lane in a vector register (wavefront groups, K <= 64): the loop index is
-// uniform, so pred[v] arrives through v_readlane in a scalar register and the mask costs no memory access at all.
-template <class G>
-AMBI_HD uint64_t avail_mask_g(const G& g, const uint64_t* pred, uint64_t pred_lane, int K, uint64_t I) {
-    if constexpr (G::kLaneArrays) {
-        if (K <= 32) {
-            const uint32_t i32 = (uint32_t)I, pl = (uint32_t)pred_lane;
-            uint32_t o = 0;
-            for (int v = 0; v < K; v++) o |= (uint32_t)((lane_get_u32(pl, v) & ~i32) == 0) << v;
-            return (uint64_t)(o & ~i32);
-        }
-        uint64_t out = 0;
-        for (int v = 0; v < K; v++) {
-            const uint64_t p = ((uint64_t)lane_get_u32((uint32_t)(pred_lane >> 32), v) << 32) | lane_get_u32((uint32_t)pred_lane, v);
-            out |= (uint64_t)((p & ~I) == 0) << v;
-        }
-        return out & ~I;
-    } else {
-        return avail_mask(pred, K, I);
-    }
-}
-
 AMBI_HD uint32_t hash_mask(uint64_t k) {
     uint32_t h = (uint32_t)k * 0x9E3779B1u;
     h ^= (uint32_t)(k >> 32) * 0x85EBCA6Bu;
@@ -166,59 +158,59 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
     // ideals of a step come from a flag rank over the group (no atomic, no round trip through the counter in memory).
     int overflow = 0, last_level = 0, links = 0;
     int lo = 0, hi = 1, count = 1;
-    const uint64_t pred_lane = (G::kLaneArrays && g.tid() < K) ? pred[g.tid()] : 0ull;
     for (int d = 0; d <= K; d++) {
         if (hi == lo) break;
-        if (d == 5) clk_mark(g, clk, 13);
         for (int base = lo; base < hi; base += g.size()) {
             const int idx = base + g.tid();
-            uint64_t I = 0, av = 0;
-            int nch = 0;
-            if (idx < hi) {
-                I = W.ikey[idx];
-                av = avail_mask_g(g, pred, pred_lane, K, I);
-                W.cnt[idx] = av;   // parked here until the search is over (no store to HBM inside the level loop)
-                nch = popc64(av);
-            }
-            if (d == 5) clk_mark(g, clk, 14);
+            // lanes behind the end of the level run the same straight-line code on a valid entry and mask the result
+            const bool act = idx < hi;
+            const uint64_t I = W.ikey[act ? idx : lo];
+            uint64_t av = avail_mask(pred, K, I);
+            if (!act) av = 0;
+            if (act) W.cnt[idx] = av;   // parked here until the search is over (no store to HBM inside the level loop)
+            const int nch = popc64(av);
             int tot;
             const int ex = g.exscan_i32(nch, &tot);
             int k = links + ex;
-            if (idx < hi) {
-                W.cbase[idx] = k;
-                if (k + nch > W.link_cap) { overflow = 1; av = 0; }
-            }
-            if (d == 5) clk_mark(g, clk, 15);
+            if (act) W.cbase[idx] = k;
+            if (k + nch > W.link_cap) { overflow = 1; av = 0; }
             // step r inserts the r-th child of every ideal of the chunk
             while (g.any(av != 0)) {
-                bool fresh = false;
-                int s = -1;
-                uint64_t child = 0;
-                if (av) {
-                    const int v = ctz64(av);
-                    av &= av - 1;
-                    child = I | (1ull << v);
-                    s = ideal_insert(W, child, &fresh);
-                    if (s < 0) { overflow = 1; av = 0; }
-                    else W.link[k++] = (uint32_t)s;
+                const bool on = av != 0;
+                const uint64_t child = I | (av & (0ull - av));   // lowest available node appended
+                av &= av - 1;
+                // first probe in straight-line code: the compare-and-swap itself tells "free (now mine)", "already
+                // there" or "occupied by another ideal"; only the last case (rare at load <= 1/2) enters the probe loop
+                uint32_t h = hash_mask(child) & (uint32_t)(W.cap - 1);
+                uint64_t old = child;
+                if (on) old = atomic_cas_u64(&W.keys[h], kEmptyKey, child);
+                bool fresh = on && old == kEmptyKey;
+                bool miss = on && old != kEmptyKey && old != child;
+                if (g.any(miss)) {
+                    for (int probe = 1; probe < W.cap && miss; probe++) {
+                        h = (h + 1) & (uint32_t)(W.cap - 1);
+                        old = atomic_cas_u64(&W.keys[h], kEmptyKey, child);
+                        if (old == kEmptyKey) { fresh = true; miss = false; }
+                        else if (old == child) miss = false;
+                    }
+                    if (miss) { overflow = 1; av = 0; }   // table full
                 }
+                if (on && !miss) W.link[k++] = h;
                 int nfresh;
                 const int p = count + g.flag_exscan(fresh, &nfresh);
                 if (fresh) {
                     if (p >= maxIdeals) { overflow = 1; av = 0; }
-                    else { W.ikey[p] = child; W.pos[s] = p; }
+                    else { W.ikey[p] = child; W.pos[h] = p; }
                 }
                 count += nfresh;
             }
             links += tot;
         }
-        if (d == 5) clk_mark(g, clk, 29);
         if (g.any(overflow != 0)) return ST_ERR_IDEALS_CAPACITY;
         if (g.tid() == 0) W.lvl_off[d + 2] = count;
         g.sync();
         lo = hi; hi = count;
         last_level = d + 1;
-        if (d == 5) clk_mark(g, clk, 30);
     }
     if (g.tid() == 0) W.counter[0] = count;
     g.sync();
