@@ -135,6 +135,7 @@ struct BatchArgs {
     // n_pending, the plan kernel stores orders_needed and the finish kernel n_pending straight into pinned host memory
     int32_t zero_pending;        // 1: block 0 of the prepare kernel zeroes *n_pending
     int32_t* host_pending;       // device address of a pinned host int32 (nullptr: the host copies n_pending itself)
+    int32_t* blocks_done;        // [1] finished workgroups of the lean finish kernel (the last one reports n_pending and resets it)
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)
     int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)
 };

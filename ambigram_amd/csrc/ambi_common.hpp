@@ -34,6 +34,7 @@ enum Status : int32_t {
     ST_INFEASIBLE = 2,          // .sol said Infeasible (localhap.cpp:213-220)
     ST_NO_VALID_ORDER = 3,      // no topological order assembles in either orientation (path stays empty)
     ST_PENDING = 4,             // internal: first-valid search budget exhausted, parallel search needed
+    ST_REFINISH = 5,            // internal: the lean finish stage met SVs that chain or edit the path; the full stage takes the unit
     ST_ERR_TOO_MANY_NODES = -10,   // K > kMaxNodes
     ST_ERR_NO_ELEMENTS = -11,      // K == 0: the reference indexes an empty order (UB)
     ST_ERR_REF_UB = -12,           // the reference would read out of bounds on this input

@@ -401,6 +401,46 @@ __global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int
     stage_finish(g, A, u, ambi_lds);
 }
 
+// Lean finish (ambi_stages.hpp: stage_finish_lean): every unit of the slice; units it cannot take are counted in
+// n_pending with status ST_REFINISH.  The last workgroup to finish reports n_pending to the host.
+__global__ __launch_bounds__(256) void ambi_finish_lean_kernel(BatchArgs A) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    // a workgroup takes every gridDim.x-th unit: the grid is sized to the number of workgroups that should be resident
+    // at a time (one per CU fits beside the enumerate workgroups), not to the batch
+    for (int i = (int)blockIdx.x; i < A.n_units; i += (int)gridDim.x) {
+        stage_finish_lean(g, A, A.unit_base + i, ambi_lds);
+        __syncthreads();
+    }
+    if (A.host_pending) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(A.blocks_done, 1) == (int)gridDim.x - 1) {
+                *A.host_pending = atomicAdd(A.n_pending, 0);
+                *A.blocks_done = 0;
+            }
+        }
+    }
+}
+
+// The same with one wavefront per unit (no cross-wave barriers): the shape for large batches, where the parallelism is
+// across units; the workgroup form above keeps the latency of a small batch low.
+__global__ __launch_bounds__(64) void ambi_finish_lean_wave_kernel(BatchArgs A) {
+    WaveGroup g;
+    for (int i = (int)blockIdx.x; i < A.n_units; i += (int)gridDim.x) {
+        stage_finish_lean(g, A, A.unit_base + i, ambi_lds);
+        g.sync();
+    }
+    if (A.host_pending && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(A.blocks_done, 1) == (int)gridDim.x - 1) {
+            *A.host_pending = atomicAdd(A.n_pending, 0);
+            *A.blocks_done = 0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void ambi_pack_scan_kernel(BatchArgs A, int which, int32_t* lengths, int64_t* pack_off, int64_t* total) {
     __shared__ int64_t sh[17];
     int64_t carry = 0;
@@ -452,7 +492,11 @@ class HipBackend : public Backend {
     int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned
     int32_t* dh_npending_ = nullptr; int64_t* dh_needed_ = nullptr; // the same two, as the device addresses them
     BatchArgs A_{};
-    int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_enum_ = 0;
+    int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_finish_lean_ = 0, lds_enum_ = 0;
+    bool lean_finish_ = true;   // env AMBI_LEAN_FINISH=0: every unit through the full finish stage
+    int finish_grid_ = 0;       // workgroups of the lean finish kernel; 0 = sized per run (env AMBI_FINISH_GRID overrides)
+    bool finish_wave_ = false;  // one wavefront per unit (env AMBI_FINISH_WAVE)
+    int32_t* d_blocks_done_ = nullptr;
     std::vector<KernelTime> times_;
     struct Ev { const char* name; hipEvent_t a, b; };
     std::vector<Ev> evs_;
@@ -481,13 +525,13 @@ class HipBackend : public Backend {
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
-                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_};
+                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
-        d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr;
+        d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         h_npending_ = nullptr; h_needed_ = nullptr;
@@ -575,6 +619,12 @@ class HipBackend : public Backend {
         lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
         lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
         lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
+        lds_finish_lean_ = (int)finish_lean_work_bytes(hb.max_n, hb.max_m, hb.max_bkp);
+        { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
+        { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
+        { const char* e = getenv("AMBI_FINISH_WAVE"); finish_wave_ = e ? atoi(e) != 0 : false; }
+        if ((rc = dalloc(&d_blocks_done_, 1))) return rc;
+        HIP_CK(hipMemset(d_blocks_done_, 0, sizeof(int32_t)));
         enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
@@ -596,6 +646,8 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_lean_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_lean_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
@@ -631,7 +683,14 @@ class HipBackend : public Backend {
         { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
-            HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
+            // the scan / finish kernels fill the gaps the enumerate kernel leaves: lowest dispatch priority (AMBI_BACK_PRIORITY=0: default)
+            { const char* e8 = getenv("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : true;
+              int least = 0, greatest = 0;
+              if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+                  HIP_CK(hipStreamCreateWithPriority(&back_stream_, hipStreamNonBlocking, least));
+              } else {
+                  HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
+              } }
             HIP_CK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
             HIP_CK(hipEventCreateWithFlags(&ev_back_, hipEventDisableTiming));
             // AMBI_ENUM_LDS_FLOOR (experiments): make the enumerate kernel ask for more LDS than its image needs, i.e. fewer
@@ -660,7 +719,7 @@ class HipBackend : public Backend {
         A_.order_arena = d_arena_; A_.order_arena_bytes = arena_bytes_;
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
-        A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr;
+        A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
     }
     BatchArgs slice_args(int s) const {
         BatchArgs A = A_;
@@ -718,6 +777,22 @@ class HipBackend : public Backend {
         hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(A.n_units), dim3(256), lds_build_, st, A);
         tick("ambi_blocks_build_kernel", s, 2, false);
     }
+    // Workgroups of the lean finish kernel.  Beside a long enumerate kernel the finish stage only has to be done when the
+    // table is: the fewer of its workgroups are resident, the less they take from the enumerate workgroups (issue slots,
+    // group-memory bandwidth), so the grid is sized to finish just in time (measured on MI355X, profiles/r01_slices.md:
+    // 128 workgroups for 4096 units of the bench workload = 3.43 M/s, 256 = 3.33 M/s, one per unit = 2.84 M/s).  Without
+    // a long enumerate kernel (small order tables, first run) every unit gets its own workgroup.
+    int finish_grid_for(int U) const {
+        if (finish_grid_ > 0) return U < finish_grid_ ? U : finish_grid_;          // env AMBI_FINISH_GRID
+        if (!overlap_back_) return U;
+        const double enum_us = (double)last_needed_ / 4.2e6;                        // order-table bytes of the previous run at ~4.2 TB/s
+        const double unit_us = 4.0 + hb_.max_path / 900.0 + hb_.max_m / 64.0;       // one unit through the lean finish stage
+        if (enum_us < 8.0 * unit_us) return U;
+        int64_t grid = (int64_t)((double)U * unit_us / enum_us) + 1;
+        grid = (grid + 31) & ~int64_t(31);
+        if (grid < 32) grid = 32;
+        return grid < U ? (int)grid : U;
+    }
     void launch_back(int s, const BatchArgs& A) {    // enumerate, first valid order, finish
         hipStream_t st = slice_stream(s);
         const int U = A.n_units;
@@ -738,7 +813,10 @@ class HipBackend : public Backend {
         hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, sb, A);
         tick("ambi_first_kernel", s, 4, false, sb);
         tick("ambi_finish_kernel", s, 5, true, sb);
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr);
+        const int fgrid = finish_grid_for(U);
+        if (lean_finish_ && finish_wave_) hipLaunchKernelGGL(ambi_finish_lean_wave_kernel, dim3(fgrid), dim3(64), lds_finish_lean_, sb, A);
+        else if (lean_finish_) hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
+        else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr);
         tick("ambi_finish_kernel", s, 5, false, sb);
         if (overlap_back_) { (void)hipEventRecord(ev_back_, sb); (void)hipStreamWaitEvent(st, ev_back_, 0); }
     }
@@ -804,23 +882,30 @@ class HipBackend : public Backend {
         const int U = A_.n_units;
         std::vector<UnitOut> hdr(U);
         HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));
-        std::vector<int32_t> pend;
-        for (int u = 0; u < U; u++) if (hdr[u].status == ST_PENDING) pend.push_back(u);
-        if (pend.empty()) return 0;
-        const int np = (int)pend.size(), chunk = 16;
+        // two kinds of leftovers: units whose scan ran out of budget (parallel search, then the full finish stage) and units
+        // the lean finish stage handed over (full finish stage only)
+        std::vector<int32_t> pend, refin;
+        for (int u = 0; u < U; u++) {
+            if (hdr[u].status == ST_PENDING) pend.push_back(u);
+            else if (hdr[u].status == ST_REFINISH) refin.push_back(u);
+        }
+        if (pend.empty() && refin.empty()) return 0;
+        const int np = (int)pend.size(), nfin = np + (int)refin.size(), chunk = 16;
         std::vector<int64_t> coff(np + 1, 0);
         for (int p = 0; p < np; p++) coff[p + 1] = coff[p] + (hdr[pend[p]].num_orders + chunk - 1) / chunk;
+        std::vector<int32_t> fin(pend);
+        fin.insert(fin.end(), refin.begin(), refin.end());
         int32_t* d_pend; int64_t* d_coff; int64_t* d_found; int32_t* d_err;
-        HIP_CK(hipMalloc((void**)&d_pend, np * sizeof(int32_t)));
+        HIP_CK(hipMalloc((void**)&d_pend, nfin * sizeof(int32_t)));
         HIP_CK(hipMalloc((void**)&d_coff, (np + 1) * sizeof(int64_t)));
-        HIP_CK(hipMalloc((void**)&d_found, np * sizeof(int64_t)));
-        HIP_CK(hipMalloc((void**)&d_err, np * sizeof(int32_t)));
-        HIP_CK(hipMemcpy(d_pend, pend.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CK(hipMalloc((void**)&d_found, (np + 1) * sizeof(int64_t)));
+        HIP_CK(hipMalloc((void**)&d_err, (np + 1) * sizeof(int32_t)));
+        HIP_CK(hipMemcpy(d_pend, fin.data(), nfin * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_CK(hipMemcpy(d_coff, coff.data(), (np + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1;
         HIP_CK(hipFuncSetAttribute((const void*)ambi_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, waves * lds_first_));
         bool fwd = !(A_.flags & FLAG_REVERSED);
-        for (int pass = 0; pass < 2; pass++) {
+        for (int pass = 0; pass < 2 && np > 0; pass++) {
             std::vector<int64_t> init(np, 0x7fffffffffffffffll);
             HIP_CK(hipMemcpy(d_found, init.data(), np * sizeof(int64_t), hipMemcpyHostToDevice));
             HIP_CK(hipMemset(d_err, 0, np * sizeof(int32_t)));
@@ -834,7 +919,7 @@ class HipBackend : public Backend {
             HIP_CK(hipStreamSynchronize(stream_));
             fwd = !fwd;
         }
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(np), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend);
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend);
         HIP_CK(hipGetLastError());
         HIP_CK(hipStreamSynchronize(stream_));
         (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_found); (void)hipFree(d_err);

@@ -56,10 +56,30 @@ struct IndelScratch {
     int32_t* last;      // [2n+1]   last occurrence
 };
 
+// Two views of the per-segment path.  LdsPath: the cells themselves (group memory).  RunPath: the path as the runs it
+// was expanded from -- breakpoint pair j covers positions [offs[j], offs[j+1]) with the values bkp[2j] + k (both the
+// '+' run a, a+1, .. and the '-' run -|a|, -(|a|-1), .. count up by one); a cell is found by bisection over the run
+// offsets.  The lean finish stage works on runs only and never materialises the cells in group memory.
+struct LdsPath {
+    const cell_t* p;
+    AMBI_HD int at(int q) const { return p[q]; }
+};
+struct RunPath {
+    const cell_t* bkp;      // [2*np]
+    const int32_t* offs;    // [np+1], offs[np] = P
+    int np;
+    AMBI_HD int at(int q) const {   // 0 <= q < P
+        int lo = 0, hi = np;        // last run whose offset is <= q (empty runs share their offset with the next one)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
+        return (int)bkp[2 * lo] + (q - offs[lo]);
+    }
+};
+
 struct SingleEdit { int kind, a, b; };   // kind 0: none, 1: erase [a,b), 2: duplicate [a,b) after b-1... (see apply)
 
 // Decision of LGM.cpp:3779-3818 for a two-vertex group (g0,g1), answered from the occurrence tables.
-AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const cell_t* path, int P, const int32_t* first, const int32_t* last) {
+template <class PATH>
+AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const PATH& path, int P, const int32_t* first, const int32_t* last) {
     SingleEdit E{0, 0, 0};
     const bool same = (g0 > 0) == (g1 > 0);
     const bool deletion = same && ((g0 > 0 && iabs(g0) < iabs(g1)) || (g0 < 0 && iabs(g0) > iabs(g1)));
@@ -73,7 +93,7 @@ AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const cell_t* path, int P,
             if (pos1 != P && last[g1 + n] > pos1) {
                 pos2 = -1;
                 int hi = pos1 + limit < P - 1 ? pos1 + limit : P - 1;
-                for (int q = pos1 + 1; q <= hi; q++) if (path[q] == g1) { pos2 = q; break; }
+                for (int q = pos1 + 1; q <= hi; q++) if (path.at(q) == g1) { pos2 = q; break; }
             }
             if (attempt == 0 && (pos1 == P || pos2 == P)) { int t = g0; g0 = -g1; g1 = -t; continue; }
             break;
@@ -97,14 +117,11 @@ AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const cell_t* path, int P,
     return E;
 }
 
-// LGM.cpp:3746-3837.  path/P are updated in place.  Returns 1 when the reference prints the
-// "BFB path with insertion, deletion, or duplication:" caption (any qualifying SV exists), 0 otherwise,
-// negative Status on capacity errors.
+// Front part of indelBFB shared by the full and the lean finish stage: the qualifying SVs in junction order
+// (S.sv, S.taken cleared) and, per SV, whether a later one could chain onto it (S.has_ext).  Uses S.first / S.last as
+// scratch.  Returns the number of SVs.
 template <class G>
-AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* path, int* P_io, int pcap,
-                      const IndelScratch& S, bool* edited = nullptr) {
-    int P = *P_io;
-    if (edited) *edited = false;
+AMBI_HD int indel_collect(const G& g, int n, const JuncEnds* ends, int m, const IndelScratch& S) {
     // -- qualifying SVs in junction order (LGM.cpp:3750-3759), compacted with a group scan
     int nsv = 0;
     for (int base = 0; base < m; base += g.size()) {
@@ -146,6 +163,20 @@ AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* pa
     }
     g.sync();
 
+    return nsv;
+}
+
+// LGM.cpp:3746-3837.  path/P are updated in place.  Returns 1 when the reference prints the
+// "BFB path with insertion, deletion, or duplication:" caption (any qualifying SV exists), 0 otherwise,
+// negative Status on capacity errors.
+template <class G>
+AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* path, int* P_io, int pcap,
+                      const IndelScratch& S, bool* edited = nullptr) {
+    int P = *P_io;
+    if (edited) *edited = false;
+    const int nsv = indel_collect(g, n, ends, m, S);
+    if (nsv == 0) return 0;
+
     auto rebuild_tables = [&]() {
         for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { S.first[i] = 0x7fffffff; S.last[i] = -1; }
         g.sync();
@@ -182,14 +213,14 @@ AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* pa
             if (S.taken[i]) continue;
             if (S.has_ext[i]) { stop = i; break; }
             const JuncEnds J = ends[S.sv[i]];
-            SingleEdit E = eval_single(J.s, J.t, n, path, P, S.first, S.last);
+            SingleEdit E = eval_single(J.s, J.t, n, LdsPath{path}, P, S.first, S.last);
             if (E.kind != 0) { stop = i; break; }
         }
         stop = g.min_i32(stop);
         if (stop == 0x7fffffff) break;
         if (!S.has_ext[stop]) {
             const JuncEnds J = ends[S.sv[stop]];
-            SingleEdit E = eval_single(J.s, J.t, n, path, P, S.first, S.last);   // uniform re-evaluation
+            SingleEdit E = eval_single(J.s, J.t, n, LdsPath{path}, P, S.first, S.last);   // uniform re-evaluation
             g.sync();
             int rc = apply_single(E);
             if (rc < 0) { *P_io = P; return rc; }
@@ -327,6 +358,60 @@ AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* pa
     return 1;
 }
 
+// A junction step (u,v) of the path, both vertices in one word.
+AMBI_HD int32_t pack_step(int u, int v) { return (int32_t)(((uint32_t)(u + 32768) << 16) | (uint32_t)(v + 32768)); }
+AMBI_HD int step_u(int32_t w) { return (int)((uint32_t)w >> 16) - 32768; }
+AMBI_HD int step_v(int32_t w) { return (int)((uint32_t)w & 0xFFFFu) - 32768; }
+
+// Tail of the output-junction synthesis (localhap.cpp:275-289) on the nc junction steps in path order, given as packed
+// (u,v) words in cand[0,nc); cand must hold 3*nc ints.  A step joins the FIRST earlier step that is the same edge or
+// its complement edge (the reference bumps that entry's count); a record can never coexist with its complement, so
+// classes are disjoint.  Returns the number of output junctions or a negative Status.
+template <class G>
+AMBI_HD int synth_classes(const G& g, int32_t* cand, int nc, OutJunc* out, int cap, int seg_base) {
+    int32_t* rep = cand + nc;      // [nc] representative (first occurrence) of every step
+    int32_t* key = cand + 2 * nc;  // [nc] canonical edge key: the smaller of (u,v) and its complement (-v,-u), packed
+    for (int c = g.tid(); c < nc; c += g.size()) {
+        const int u = step_u(cand[c]), v = step_v(cand[c]);
+        const int32_t k1 = pack_step(u, v), k2 = pack_step(-v, -u);
+        key[c] = k1 < k2 ? k1 : k2;
+    }
+    g.sync();
+    for (int c = g.tid(); c < nc; c += g.size()) {
+        const int32_t mine_key = key[c];
+        int r = c;
+        for (int k0 = 0; k0 < c; k0 += 8) {   // eight independent loads per round trip instead of one
+            int hit = c;
+#pragma unroll
+            for (int q = 7; q >= 0; q--) { const int k = k0 + q; if (k < c && key[k] == mine_key) hit = k; }
+            if (hit < c) { r = hit; break; }
+        }
+        rep[c] = r;
+    }
+    g.sync();
+    // class sizes in group memory (the key array is free now): every step bumps its representative's counter
+    for (int c = g.tid(); c < nc; c += g.size()) key[c] = 0;
+    g.sync();
+    for (int c = g.tid(); c < nc; c += g.size()) atomic_add_i32(&key[rep[c]], 1);
+    g.sync();
+    // leaders in first-appearance order -> finished records, one store each
+    int nout = 0;
+    for (int base = 0; base < nc; base += g.size()) {
+        const int c = base + g.tid();
+        const int lead = (c < nc && rep[c] == c) ? 1 : 0;
+        int tot;
+        const int ex = g.exscan_i32(lead, &tot);
+        if (lead && nout + ex < cap) {
+            OutJunc& o = out[nout + ex];
+            const int pu = step_u(cand[c]), pv = step_v(cand[c]);   // local signed ids -> absolute
+            o.u = pu > 0 ? pu + seg_base : pu - seg_base; o.v = pv > 0 ? pv + seg_base : pv - seg_base; o.count = key[c];
+        }
+        nout += tot;
+    }
+    if (nout > cap) return ST_ERR_OUTJUNC_CAPACITY;
+    return nout;
+}
+
 // localhap.cpp:267-289: consecutive path vertices that are not |id difference| == 1 on one strand become
 // output junctions; a repeat (same edge or its complement edge) bumps the count.  First-appearance order.
 // cand = scratch of cand_cap ints.  Returns the number of output junctions or a negative Status.
@@ -375,50 +460,103 @@ AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out,
         cand[r] = pos;   // cand [0, nc) never overlaps the unsorted list: nc <= list_cap and the list starts at 2*list_cap
     }
     g.sync();
-    // A step joins the FIRST earlier step that is the same edge or its complement edge (the reference bumps that
-    // entry's count, localhap.cpp:275-282); a record can never coexist with its complement, so classes are disjoint.
-    int32_t* rep = cand + nc;      // [nc] representative (first occurrence) of every step, then its output slot
-    int32_t* key = cand + 2 * nc;  // [nc] canonical edge key: the smaller of (u,v) and its complement (-v,-u), packed
+    // positions -> the step's two vertices, packed (the tail below no longer needs the path)
     for (int c = g.tid(); c < nc; c += g.size()) {
-        const int u = path[cand[c]], v = path[cand[c] + 1];
-        const int32_t k1 = (int32_t)(((uint32_t)(u + 32768) << 16) | (uint32_t)(v + 32768));
-        const int32_t k2 = (int32_t)(((uint32_t)(-v + 32768) << 16) | (uint32_t)(-u + 32768));
-        key[c] = k1 < k2 ? k1 : k2;
+        const int pos = cand[c];
+        cand[c] = pack_step(path[pos], path[pos + 1]);
     }
     g.sync();
-    for (int c = g.tid(); c < nc; c += g.size()) {
-        const int32_t mine_key = key[c];
-        int r = c;
-        for (int k0 = 0; k0 < c; k0 += 8) {   // eight independent loads per round trip instead of one
-            int hit = c;
-#pragma unroll
-            for (int q = 7; q >= 0; q--) { const int k = k0 + q; if (k < c && key[k] == mine_key) hit = k; }
-            if (hit < c) { r = hit; break; }
+    return synth_classes(g, cand, nc, out, cap, seg_base);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lean finish (runs only, no path cells in group memory).  The common case -- indelBFB looks its SVs up and edits
+// nothing -- needs the path only (a) as output, (b) for the occurrence tables and a handful of cell reads, (c) for the
+// junction steps, and all three follow from the runs: (a) expand_runs streams the cells to HBM, (b) the tables are
+// filled in the same sweep and single cells come from RunPath::at, (c) inside a run consecutive cells differ by one,
+// so junction steps exist only between the last cell of a run and the first cell of the next non-empty one.
+// A unit whose SVs chain or edit the path is handed to the full stage instead (rare).
+// ---------------------------------------------------------------------------------------------------------------
+
+// run offsets: offs[j] = first position of pair j, offs[np] = P.  Returns P.
+template <class G>
+AMBI_HD int run_offsets(const G& g, const cell_t* bkp, int L, int32_t* offs) {
+    const int np = L / 2;
+    int carry = 0;
+    for (int base = 0; base < np; base += g.size()) {
+        const int j = base + g.tid();
+        int len = 0;
+        if (j < np) {
+            const int a = bkp[2 * j], b = bkp[2 * j + 1];
+            len = a > 0 ? iabs(b) - a + 1 : (-a) - iabs(b) + 1;   // LGM.cpp:3661-3670
+            if (len < 0) len = 0;
         }
-        rep[c] = r;
-    }
-    g.sync();
-    // class sizes in group memory (the key array is free now): every step bumps its representative's counter
-    for (int c = g.tid(); c < nc; c += g.size()) key[c] = 0;
-    g.sync();
-    for (int c = g.tid(); c < nc; c += g.size()) atomic_add_i32(&key[rep[c]], 1);
-    g.sync();
-    // leaders in first-appearance order -> finished records, one store each
-    int nout = 0;
-    for (int base = 0; base < nc; base += g.size()) {
-        const int c = base + g.tid();
-        const int lead = (c < nc && rep[c] == c) ? 1 : 0;
         int tot;
-        const int ex = g.exscan_i32(lead, &tot);
-        if (lead && nout + ex < cap) {
-            OutJunc& o = out[nout + ex];
-            const int pu = path[cand[c]], pv = path[cand[c] + 1];   // local signed ids -> absolute
-            o.u = pu > 0 ? pu + seg_base : pu - seg_base; o.v = pv > 0 ? pv + seg_base : pv - seg_base; o.count = key[c];
-        }
-        nout += tot;
+        const int ex = g.exscan_i32(len, &tot);
+        if (j < np) offs[j] = carry + ex;
+        carry += tot;
     }
-    if (nout > cap) return ST_ERR_OUTJUNC_CAPACITY;
-    return nout;
+    if (g.tid() == 0) offs[np] = carry;
+    g.sync();
+    return carry;
+}
+
+// cells of every run to the result blob (absolute signed ids); with `first` != nullptr also the occurrence tables
+// (initialised by the caller) -- run-major, one sub-group (wavefront) per run as in expand_bkp
+template <class G>
+AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* offs, int32_t* gpath, int seg_base, int n,
+                         int32_t* first, int32_t* last) {
+    const int lanes = g.size() < 64 ? g.size() : 64;
+    const int sub = g.tid() / lanes, nsub = g.size() / lanes, lane = g.tid() - sub * lanes;
+    for (int j = sub; j < np; j += nsub) {
+        const int a = bkp[2 * j], o0 = offs[j], len = offs[j + 1] - o0;
+        for (int k = lane; k < len; k += lanes) {
+            const int v = a + k;
+            gpath[o0 + k] = v > 0 ? v + seg_base : v - seg_base;
+            if (first) { atomic_min_i32(&first[v + n], o0 + k); atomic_max_i32(&last[v + n], o0 + k); }
+        }
+    }
+    g.sync();
+}
+
+// indelBFB when nothing chains and nothing edits: 1 = the SVs are all look-ups without effect (the reference prints its
+// caption and the unchanged path), 0 = the full stage has to take this unit.  nsv > 0, tables filled.
+template <class G>
+AMBI_HD int indel_lookups_only(const G& g, int n, const JuncEnds* ends, int nsv, const RunPath& path, int P, const IndelScratch& S) {
+    int stop = 0;
+    for (int i = g.tid(); i < nsv && !stop; i += g.size()) {
+        if (S.has_ext[i]) { stop = 1; break; }
+        const JuncEnds J = ends[S.sv[i]];
+        if (eval_single(J.s, J.t, n, path, P, S.first, S.last).kind != 0) stop = 1;
+    }
+    return g.any(stop != 0) ? 0 : 1;
+}
+
+// output junctions from the runs; cand: 3 * (np + 1) ints
+template <class G>
+AMBI_HD int synth_out_juncs_runs(const G& g, const cell_t* bkp, int np, const int32_t* offs, OutJunc* out, int cap, int32_t* cand,
+                                 int seg_base) {
+    int nc = 0;
+    for (int base = 0; base < np; base += g.size()) {
+        const int j = base + g.tid();
+        int flag = 0, u = 0, v = 0;
+        if (j < np && offs[j + 1] > offs[j]) {
+            int nx = j + 1;
+            while (nx < np && offs[nx + 1] == offs[nx]) nx++;      // next non-empty run
+            if (nx < np) {
+                u = bkp[2 * j] + (offs[j + 1] - offs[j] - 1);
+                v = bkp[2 * nx];
+                const int d = v - u;
+                flag = (d != 1 && d != -1) ? 1 : 0;
+            }
+        }
+        int tot;
+        const int ex = g.exscan_i32(flag, &tot);
+        if (flag) cand[nc + ex] = pack_step(u, v);
+        nc += tot;
+    }
+    g.sync();
+    return synth_classes(g, cand, nc, out, cap, seg_base);
 }
 
 }  // namespace ambi

@@ -487,7 +487,12 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     int32_t* gpath2 = reinterpret_cast<int32_t*>(res + Lay.path_ind);
     OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
     const int base = U.seg_base;
-    const int status = out->status;
+    int status = out->status;
+    if (status == ST_REFINISH) {   // handed over by the lean stage: an ordinary reconstructed unit
+        status = ST_OK;
+        g.sync();
+        if (g.tid() == 0) out->status = ST_OK;
+    }
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
         // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
         int P = n <= U.path_cap ? n : U.path_cap;
@@ -526,6 +531,107 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     AMBI_MARK(A, g, u, 20);
     if (g.tid() == 0) {
         out->path_len = P; out->path_indel_len = P2; out->indel_printed = printed; out->path_ind_stored = edited ? 1 : 0;
+        out->n_out_junc = nout >= 0 ? nout : 0;
+        if (nout < 0) out->status = nout;
+    }
+    g.sync();
+    AMBI_MARK(A, g, u, 21);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage_finish_lean: the same results from the runs of the breakpoint path alone (ambi_finish.hpp, "Lean finish").
+// ~11 KB of group memory for a 256-segment unit instead of ~38 KB, so its workgroups fit beside the resident
+// enumerate workgroups instead of taking their places.  Units whose SVs chain or edit the path get ST_REFINISH, are
+// counted in n_pending and go through stage_finish afterwards.
+// ---------------------------------------------------------------------------------------------
+struct FinishLeanWork {
+    cell_t* bkp;        // [bkp_cap]
+    int32_t* offs;      // [bkp_cap/2 + 2]
+    JuncEnds* ends;     // [m]
+    int32_t* sv;        // [m]
+    int32_t* cand;      // [3 * (bkp_cap/2 + 1)]
+    int32_t* first;     // [2n+1]
+    int32_t* last;      // [2n+1]
+    uint8_t* taken;     // [m]
+    uint8_t* has_ext;   // [m]
+};
+AMBI_HD int64_t finish_lean_work_bytes(int n, int m, int bkp_cap) {
+    return pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(JuncEnds)) * m) + pad8(4ll * m) +
+           pad8(12ll * (bkp_cap / 2 + 1)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
+}
+AMBI_HD FinishLeanWork carve_finish_lean(uint8_t* base, int n, int m, int bkp_cap) {
+    FinishLeanWork W;
+    int64_t o = 0;
+    W.bkp = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * bkp_cap);
+    W.offs = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (bkp_cap / 2 + 2));
+    W.ends = reinterpret_cast<JuncEnds*>(base + o); o += pad8(int64_t(sizeof(JuncEnds)) * m);
+    W.sv = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * m);
+    W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(12ll * (bkp_cap / 2 + 1));
+    W.first = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
+    W.last = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
+    W.taken = base + o; o += pad8(m);
+    W.has_ext = base + o;
+    return W;
+}
+
+template <class G>
+AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    UnitOut* out = unit_out(A.results, u);
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc;
+    const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
+    uint8_t* res = A.results + U.res_off;
+    int32_t* gpath = reinterpret_cast<int32_t*>(res + Lay.path);
+    OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
+    const int base = U.seg_base;
+    const int status = out->status;
+    if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
+        // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
+        int P = n <= U.path_cap ? n : U.path_cap;
+        for (int i = g.tid(); i < P; i += g.size()) gpath[i] = i + 1 + base;
+        if (g.tid() == 0) {
+            out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
+            if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
+        }
+        g.sync();
+        return;
+    }
+    if (status != ST_OK) return;
+    FinishLeanWork W = carve_finish_lean(work, n, m, U.bkp_cap);
+    const int L = out->bkp_len, np = L / 2;
+    AMBI_MARK(A, g, u, 16);
+    copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
+    {
+        const Junction* gj = A.juncs + U.junc_off;
+        for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(gj[j]);
+    }
+    g.sync();
+    AMBI_MARK(A, g, u, 17);
+    const int P = run_offsets(g, W.bkp, L, W.offs);
+    if (P > U.path_cap) { if (g.tid() == 0) out->status = ST_ERR_PATH_CAPACITY; g.sync(); return; }
+    IndelScratch S{W.sv, W.taken, W.has_ext, nullptr, W.first, W.last};
+    const int nsv = indel_collect(g, n, W.ends, m, S);
+    if (nsv > 0) {
+        for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { W.first[i] = 0x7fffffff; W.last[i] = -1; }
+        g.sync();
+    }
+    expand_runs(g, W.bkp, np, W.offs, gpath, base, n, nsv > 0 ? W.first : nullptr, W.last);
+    AMBI_MARK(A, g, u, 18);
+    int printed = 0;
+    if (nsv > 0) {
+        const RunPath RP{W.bkp, W.offs, np};
+        printed = indel_lookups_only(g, n, W.ends, nsv, RP, P, S);
+        if (!printed) {   // chaining or editing SVs: the full stage redoes this unit
+            if (g.tid() == 0) { out->status = ST_REFINISH; atomic_add_i32(A.n_pending, 1); }
+            g.sync();
+            return;
+        }
+    }
+    AMBI_MARK(A, g, u, 19);
+    const int nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+    AMBI_MARK(A, g, u, 20);
+    if (g.tid() == 0) {
+        out->path_len = P; out->path_indel_len = P; out->indel_printed = printed; out->path_ind_stored = 0;
         out->n_out_junc = nout >= 0 ? nout : 0;
         if (nout < 0) out->status = nout;
     }

@@ -169,8 +169,17 @@ class HostSimBackend : public Backend {
             stage_first(g, A_, u, work.data());
         }
         if (n_pending_ > 0) search_pending();
+        // lean finish stage first, the full one for the units it hands over (AMBI_HOSTSIM_LEAN_FINISH=0: full stage only)
+        const char* lf = getenv("AMBI_HOSTSIM_LEAN_FINISH");
+        const bool lean = lf ? atoi(lf) != 0 : true;
+        for (int u = 0; u < Un && lean; u++) {
+            const UnitIn& U = units_[u];
+            std::vector<uint8_t> work((size_t)finish_lean_work_bytes(U.n_seg, U.n_junc, U.bkp_cap));
+            stage_finish_lean(g, A_, u, work.data());
+        }
         for (int u = 0; u < Un; u++) {
             const UnitIn& U = units_[u];
+            if (lean && unit_out(A_.results, u)->status != ST_REFINISH) continue;
             std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, U.path_cap, U.out_cap));
             stage_finish(g, A_, u, work.data());
         }
