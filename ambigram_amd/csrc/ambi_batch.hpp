@@ -120,6 +120,8 @@ struct BatchArgs {
     uint64_t* auto_cnt;          // [slots/2]
     int32_t* auto_cbase;         // [slots/2 + U]
     uint16_t* auto_child;        // [U * 4 * ideal_cap]
+    uint32_t* auto_nblk;         // [slots/2]  emission blocks below every ideal (for this run's block_max)
+    uint8_t* auto_depth;         // [slots/2]  level of every ideal
     // order table
     uint8_t* first_rows;         // [U][first_budget][kFirstRowStride] the first orders of every unit, unranked by the prepare stage (nullptr: the scan reads the order table)
     uint8_t* order_arena;

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     BlockImageHeader H;
     // the automaton copy sits in LDS, the image is assembled word by word straight in its HBM slot
     const bool fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, ambi_lds, A.block_scratch_lds,
-                                        A.block_img + (int64_t)u * A.block_lds, A.block_lds, H);
+                                        A.block_img + (int64_t)u * A.block_lds, A.block_lds, H,
+                                        A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
     if (threadIdx.x == 0) {
         *reinterpret_cast<BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u) = H;
         A.unit_fallback[u] = fits ? 0 : 1;
@@ -497,6 +498,7 @@ class HipBackend : public Backend {
     int finish_grid_ = 0;       // workgroups of the lean finish kernel; 0 = sized per run (env AMBI_FINISH_GRID overrides)
     bool finish_wave_ = false;  // one wavefront per unit (env AMBI_FINISH_WAVE)
     int32_t* d_blocks_done_ = nullptr;
+    uint32_t* d_anblk_ = nullptr; uint8_t* d_adepth_ = nullptr;
     std::vector<KernelTime> times_;
     struct Ev { const char* name; hipEvent_t a, b; };
     std::vector<Ev> evs_;
@@ -525,13 +527,13 @@ class HipBackend : public Backend {
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
-                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_};
+                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
-        d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr;
+        d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         h_npending_ = nullptr; h_needed_ = nullptr;
@@ -591,6 +593,8 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_acnt_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
         if ((rc = dalloc(&d_acbase_, (size_t)hb.ideal_slots / 2 + U + 1))) return rc;
         if ((rc = dalloc(&d_achild_, (size_t)hb.ideal_slots * 4 + 8))) return rc;
+        if ((rc = dalloc(&d_anblk_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
+        if ((rc = dalloc(&d_adepth_, (size_t)hb.ideal_slots / 2 + 8))) return rc;
         if ((rc = dalloc(&d_blk_off_, U + kMaxSlices + 1))) return rc;
         if ((rc = dalloc(&d_rows_, U))) return rc;
         if ((rc = dalloc(&d_npending_, 1))) return rc;
@@ -711,7 +715,7 @@ class HipBackend : public Backend {
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
         A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
-        A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_;
+        A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
         A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_link = d_ilink_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
@@ -983,7 +987,7 @@ class HipBackend : public Backend {
         // marks 0-8 and 22-31: prepare (22-24 inside constructDAG, 26-28 inside the lattice); 9-12: scan; 16-21: finish
         fprintf(stderr, "ambigram_hip stage profile (mean cycles from the first mark of the stage, %zu units):", U);
         for (int s = 1; s < kStageSlots; s++) {
-            const int base = (s <= 8 || s >= 22 || (s >= 13 && s <= 15)) ? 0 : (s <= 12 ? 9 : 16);
+            const int base = ((s >= 13 && s <= 15) || s == 29 || s == 30) ? 31 : ((s <= 8 || s >= 22) ? 0 : (s <= 12 ? 9 : 16));   // 13-15, 29, 30: image build (from 31)
             if (s == base) continue;
             double sum = 0; size_t cnt = 0;
             for (size_t u = 0; u < U; u++) {

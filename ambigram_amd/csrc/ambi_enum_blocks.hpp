@@ -107,7 +107,8 @@ AMBI_HD int64_t carve_build_tables(uint8_t* mem, int nI, int nC, BuildTables& B)
 template <class G>
 AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, int64_t R, int block_max,
                                uint8_t* scratch, int64_t scratch_bytes, uint8_t* image, int64_t image_bytes,
-                               BlockImageHeader& H) {
+                               BlockImageHeader& H, int64_t* clk = nullptr) {
+    clk_mark(g, clk, 31);
     const int nI = T.counter[0], nC = T.counter[1];
     H.fits = 0; H.nB = 0; H.suf_words = 0; H.image_bytes = 0; H.nI = nI; H.nC = nC; H.block_max = block_max; H.pad = 0;
     if (nC >= 65535 || nI >= 65535 || R <= 0 || R > 0xFFFFFFF0ll) return false;
@@ -117,6 +118,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     if (carve_build_tables(scratch, nI, nC, B) > scratch_bytes) return false;
     const int S = dir_stride(NW);
     uint32_t* img = reinterpret_cast<uint32_t*>(image);
+    // automaton, levels and blocks-below counts as the prepare stage left them (ideal_build_and_count)
     for (int i = g.tid(); i < nI; i += g.size()) {
         const uint64_t c = T.a_cnt[i];
         B.cnt64[i] = c;
@@ -124,13 +126,12 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         B.cbase[i] = (uint16_t)T.a_cbase[i];
         B.cnt16[i] = (uint16_t)(c > 65535 ? 65535 : c);
         B.soff[i] = 0xFFFF;
+        B.nblk[i] = T.a_nblk[i];
+        B.depth[i] = T.a_depth[i];
     }
     for (int i = g.tid(); i < nC; i += g.size()) B.child[i] = T.a_child[i];
-    for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) B.lvl[d] = T.lvl_off[d];
     g.sync();
-    for (int d = 0; d <= K; d++)
-        for (int p = B.lvl[d] + g.tid(); p < B.lvl[d + 1] && p < nI; p += g.size()) B.depth[p] = (uint8_t)d;
-    g.sync();
+    clk_mark(g, clk, 13);
     for (int i = g.tid(); i < nC; i += g.size()) { const uint32_t c = B.child[i]; B.link[i] = c | ((uint32_t)B.cnt16[c] << 16); }
     // possible block roots: small ideals with a large parent (marked through the parents' child links), or the empty ideal
     for (int q = g.tid(); q < nI; q += g.size()) {
@@ -139,35 +140,35 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         for (int k = k0; k < k1; k++) { const int c = B.child[k]; if (B.cnt16[c] <= block_max) B.soff[c] = 0xFFFE; }
     }
     if (g.tid() == 0 && B.cnt16[0] <= block_max) B.soff[0] = 0xFFFE;
-    // blocks below every ideal, deepest level first (children live one level down)
-    for (int d = K; d >= 0; d--) {
-        g.sync();
-        for (int p = B.lvl[d] + g.tid(); p < B.lvl[d + 1] && p < nI; p += g.size()) {
-            uint32_t nb = 1;
-            if (B.cnt16[p] > block_max) {
-                nb = 0;
-                const int k0 = B.cbase[p], k1 = k0 + popc64(B.avail[p]);
-                for (int k = k0; k < k1; k++) { nb += B.nblk[B.child[k]]; if (nb > (1u << 30)) nb = 1u << 30; }
+    g.sync();
+    clk_mark(g, clk, 14);
+    // root list in ideal order with the first row and the word offset of every root's suffix rows: two prefix sums
+    // over the marks (the same numbers a serial walk over the ideals would produce)
+    {
+        int nr = 0, rows = 0, ok = 1;
+        int64_t words = 0;
+        for (int base = 0; base < nI; base += g.size()) {
+            const int p = base + g.tid();
+            const int is_root = (p < nI && B.soff[p] == 0xFFFE) ? 1 : 0;
+            const int c = is_root ? (int)B.cnt16[p] : 0;
+            int tr, tc;
+            const int er = g.exscan_i32(is_root, &tr);
+            const int ec = g.exscan_i32(c, &tc);
+            if (is_root) {
+                const int64_t w0 = words + (int64_t)ec * NW;
+                if (w0 > 65000) ok = 0;                   // offsets are 16 bits wide
+                else { B.soff[p] = (uint16_t)w0; B.roots[nr + er] = (uint16_t)p; B.root_row[nr + er] = (uint32_t)(rows + ec); }
             }
-            B.nblk[p] = nb;
+            nr += tr; rows += tc; words += (int64_t)tc * NW;
+        }
+        ok = g.any(ok == 0) ? 0 : 1;
+        if (g.tid() == 0) {
+            B.root_row[nr] = (uint32_t)rows;
+            B.misc[0] = nr; B.misc[1] = (int32_t)(words > 0x7fffffff ? 0x7fffffff : words); B.misc[2] = ok;
         }
     }
     g.sync();
-    // root list, suffix offsets (serial over the ideals: nI is small)
-    if (g.tid() == 0) {
-        int nr = 0; int64_t rows = 0, words = 0; int ok = 1;
-        for (int p = 0; p < nI; p++) {
-            if (B.soff[p] != 0xFFFE) continue;
-            if (words > 65000) { ok = 0; break; }
-            B.soff[p] = (uint16_t)words;
-            B.roots[nr] = (uint16_t)p; B.root_row[nr] = (uint32_t)rows; nr++;
-            rows += B.cnt16[p];
-            words += (int64_t)B.cnt16[p] * NW;
-        }
-        B.root_row[nr] = (uint32_t)rows;
-        B.misc[0] = nr; B.misc[1] = (int32_t)(words > 0x7fffffff ? 0x7fffffff : words); B.misc[2] = ok;
-    }
-    g.sync();
+    clk_mark(g, clk, 15);
     const int nRoots = B.misc[0];
     const int64_t suf_words = B.misc[1];
     const int64_t nB = B.nblk[0];
@@ -218,11 +219,12 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         for (int x = NW; x < NW + 3; x++) { const int y = x % NW; e[2 + x] = y == 0 ? w0 : (y == 1 ? w1 : w2); }
     }
     if (g.tid() == 0) img[nB * S] = (uint32_t)R;
+    clk_mark(g, clk, 29);
     // ---- suffix rows: row r of root p = r-th completion of p in lexicographic order, bytes in their final positions ----
     const int total_rows = (int)B.root_row[nRoots];
     for (int f = g.tid(); f < total_rows; f += g.size()) {
         int q = 0;
-        while (q + 1 < nRoots && B.root_row[q + 1] <= (uint32_t)f) q++;
+        { int hi = nRoots; while (hi - q > 1) { const int mid = (q + hi) >> 1; if (B.root_row[mid] <= (uint32_t)f) q = mid; else hi = mid; } }   // last root whose first row is <= f
         const int p = B.roots[q];
         int rr = f - (int)B.root_row[q];
         uint32_t* dst = suf + B.soff[p] + rr * NW;
@@ -273,6 +275,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         }
     }
     g.sync();
+    clk_mark(g, clk, 30);
     H.fits = 1; H.nB = (int32_t)nB; H.suf_words = (int32_t)suf_words; H.image_bytes = (int32_t)(4 * (dw + suf_words));
     return true;
 }

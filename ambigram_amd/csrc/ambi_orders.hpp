@@ -93,6 +93,8 @@ struct IdealTable {
     uint64_t* a_cnt;     // [cap/2]  completion count per ideal index
     int32_t* a_cbase;    // [cap/2+1] first child link per ideal index
     uint16_t* a_child;   // [child_cap] child ideal indices, ascending node order
+    uint32_t* a_nblk;    // [cap/2]  emission blocks below the ideal (ambi_enum_blocks.hpp), for the run's block_max
+    uint8_t* a_depth;    // [cap/2]  |ideal| = its level
     int cap, child_cap;
 };
 
@@ -143,7 +145,7 @@ AMBI_HD int ideal_insert(const LatticeWork& W, uint64_t key, bool* fresh) {
 // Returns status; *R_out = number of topological orders (saturated at 2^62).
 template <class G>
 AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const LatticeWork& W, const IdealTable& T, uint64_t* R_out,
-                                  uint8_t* first_rows = nullptr, int first_count = 0, int64_t* clk = nullptr) {
+                                  uint8_t* first_rows = nullptr, int first_count = 0, int64_t* clk = nullptr, int block_max = 0) {
     int maxIdeals = W.cap / 2;
     if (maxIdeals > 65535) maxIdeals = 65535;
     for (int i = g.tid(); i < W.cap; i += g.size()) W.keys[i] = kEmptyKey;
@@ -226,19 +228,29 @@ AMBI_HD int ideal_build_and_count(const G& g, const uint64_t* pred, int K, const
     for (int d = last_level - 1; d >= 0; d--) {
         const int lo = W.lvl_off[d], hi = W.lvl_off[d + 1];
         for (int idx = lo + g.tid(); idx < hi; idx += g.size()) {
+            // completions, and in the same pass the emission blocks below the ideal (ambi_enum_blocks.hpp: an ideal with
+            // at most block_max completions is one block, a larger one the sum over its children) -- the image build
+            // reads them instead of repeating the level-by-level pass; W.pos is free once the links are resolved
             uint64_t c = 0;
+            uint32_t nb = 0;
             if (W.ikey[idx] == full) c = 1;
             else {
                 const int k1 = W.cbase[idx + 1];
-                for (int k = W.cbase[idx]; k < k1; k++) { c += W.cnt[W.link[k]]; if (c > kCountSat) c = kCountSat; }
+                for (int k = W.cbase[idx]; k < k1; k++) {
+                    const uint32_t l = W.link[k];
+                    c += W.cnt[l]; if (c > kCountSat) c = kCountSat;
+                    nb += (uint32_t)W.pos[l]; if (nb > (1u << 30)) nb = 1u << 30;
+                }
             }
             W.cnt[idx] = c;
+            W.pos[idx] = (int32_t)((c > (uint64_t)block_max) ? nb : 1u);
+            T.a_depth[idx] = (uint8_t)d;
         }
         g.sync();
     }
     clk_mark(g, clk, 27);
     // freeze
-    for (int p = g.tid(); p < nI; p += g.size()) T.a_cnt[p] = W.cnt[p];
+    for (int p = g.tid(); p < nI; p += g.size()) { T.a_cnt[p] = W.cnt[p]; T.a_nblk[p] = (uint32_t)W.pos[p]; }
     if (T.a_cbase != W.cbase) for (int p = g.tid(); p <= nI; p += g.size()) T.a_cbase[p] = W.cbase[p];
     for (int k = g.tid(); k < links; k += g.size()) T.a_child[k] = (uint16_t)W.link[k];
     for (int d = g.tid(); d < kMaxNodes + 3; d += g.size()) T.lvl_off[d] = (d <= last_level + 1) ? W.lvl_off[d] : nI;

@@ -106,6 +106,8 @@ AMBI_HD IdealTable unit_ideal_table(const BatchArgs& A, int u) {
     T.a_cnt = A.auto_cnt + U.ideal_off / 2;
     T.a_cbase = A.auto_cbase + U.ideal_off / 2 + u;
     T.a_child = A.auto_child + 4 * U.ideal_off;
+    T.a_nblk = A.auto_nblk + U.ideal_off / 2;
+    T.a_depth = A.auto_depth + U.ideal_off / 2;
     T.cap = U.ideal_cap;
     T.child_cap = 4 * U.ideal_cap;
     return T;
@@ -200,9 +202,9 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
         const IdealTable T = unit_ideal_table(A, u);
         // fast path: search state in group memory (the frozen automaton itself always goes to HBM)
         uint8_t* first_rows = A.first_rows ? A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride : nullptr;
-        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R, first_rows, A.first_budget, clk);
+        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R, first_rows, A.first_budget, clk, A.block_max);
         if (st == ST_ERR_IDEALS_CAPACITY)   // large lattice
-            st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R, first_rows, A.first_budget);
+            st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R, first_rows, A.first_budget, nullptr, A.block_max);
         if (st != ST_OK) status = st;
         else if (R >= kCountSat) status = ST_ERR_ORDERS_CAPACITY;   // no table of 2^62 rows: decided here, not by the plan kernel
     }

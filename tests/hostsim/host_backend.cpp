@@ -20,6 +20,7 @@ class HostSimBackend : public Backend {
     std::vector<Dag> dags_;
     std::vector<uint8_t> results_, arena_, first_rows_;
     std::vector<uint64_t> ikeys_, icnt_, aavail_, acnt_;
+    std::vector<uint32_t> anblk_; std::vector<uint8_t> adepth_;
     std::vector<uint16_t> achild_;
     std::vector<uint32_t> ilink_;
     std::vector<int32_t> ilvl_off_, icounter_, ipos_, acbase_, rows_per_lane_, scratch_;
@@ -45,6 +46,7 @@ class HostSimBackend : public Backend {
         ilink_.assign((size_t)hb.ideal_slots * 4 + 8, 0);
         ilvl_off_.assign(U * (kMaxNodes + 3), 0); icounter_.assign(2 * U, 0);
         aavail_.assign((size_t)hb.ideal_slots / 2 + 1, 0); acnt_.assign((size_t)hb.ideal_slots / 2 + 1, 0);
+        anblk_.assign((size_t)hb.ideal_slots / 2 + 1, 0); adepth_.assign((size_t)hb.ideal_slots / 2 + 8, 0);
         acbase_.assign((size_t)hb.ideal_slots / 2 + U + 1, 0); achild_.assign((size_t)hb.ideal_slots * 4 + 8, 0);
         rows_per_lane_.assign(U, 1); blk_off_.assign(U + 1, 0);
         scratch_.assign((size_t)hb.scratch_ints + 8, 0);
@@ -58,8 +60,10 @@ class HostSimBackend : public Backend {
     void bind(uint32_t flags) {
         A_.n_units = (int32_t)units_.size(); A_.unit_base = 0; A_.arena_base = 0;   // one slice
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
+        { const char* envm = getenv("AMBI_BLOCK_MAX"); int bm = envm ? atoi(envm) : cfg_.block_max;   // as HipBackend::upload
+          if (bm < 1) bm = 1; if (bm > kBlockMaxLimit) bm = kBlockMaxLimit; A_.block_max = bm; }
         A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
-        A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data();
+        A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data(); A_.auto_nblk = anblk_.data(); A_.auto_depth = adepth_.data();
         A_.units = units_.data(); A_.seg_cn = hb_.seg_cn.data(); A_.juncs = hb_.juncs.data(); A_.elems = hb_.elems.data();
         A_.dags = dags_.data(); A_.results = results_.data();
         A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_link = ilink_.data();
@@ -77,8 +81,7 @@ class HostSimBackend : public Backend {
         std::vector<uint8_t> stacks((size_t)enum_stack_bytes(64));
         const char* env = getenv("AMBI_BLOCK_LDS");
         const int64_t block_lds = env ? atoll(env) : cfg_.block_lds;
-        const char* envm = getenv("AMBI_BLOCK_MAX");
-        const int block_max = envm ? atoi(envm) : cfg_.block_max;
+        const int block_max = A_.block_max;
         std::vector<uint8_t> image((size_t)(block_lds > 64 ? block_lds : 64));
         std::vector<uint8_t> bscratch((size_t)cfg_.block_scratch_lds);
         int built_unit = -1;

@@ -164,3 +164,12 @@ def test_all_mode(hip_lib, oracle, workdir):
 
 def test_mixed_batch(hip_lib, oracle, workdir):
     ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)
+
+
+@pytest.mark.gpu
+def test_full_finish_stage_on_every_unit(hip_lib, oracle, workdir, monkeypatch):
+    """The full finish stage (path cells in LDS) on every unit instead of the lean one (runs only): same results."""
+    monkeypatch.setenv("AMBI_LEAN_FINISH", "0")
+    ec.check_fixed_and_synthetic(hip_lib, oracle, workdir, small_only=True)
+    ec.check_random_decompositions(hip_lib, oracle, workdir, range(200, 260), budget=2)
+    ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)

@@ -47,3 +47,12 @@ def test_all_mode(hostsim_lib, oracle, workdir):
 
 def test_mixed_batch(hostsim_lib, oracle, workdir):
     ec.check_mixed_batch(hostsim_lib, oracle, workdir)
+
+
+def test_full_finish_stage_on_every_unit(hostsim_lib, oracle, workdir, monkeypatch):
+    """By default the lean finish stage takes every unit and the full one only those it hands over; here the full stage
+    (path cells in group memory, edits in place) runs on every unit, as it does when SVs chain or edit the path."""
+    monkeypatch.setenv("AMBI_HOSTSIM_LEAN_FINISH", "0")
+    ec.check_fixed_and_synthetic(hostsim_lib, oracle, workdir, small_only=True)
+    ec.check_random_decompositions(hostsim_lib, oracle, workdir, range(200, 230), budget=2)
+    ec.check_mixed_batch(hostsim_lib, oracle, workdir)
