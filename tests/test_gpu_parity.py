@@ -173,3 +173,36 @@ def test_full_finish_stage_on_every_unit(hip_lib, oracle, workdir, monkeypatch):
     ec.check_fixed_and_synthetic(hip_lib, oracle, workdir, small_only=True)
     ec.check_random_decompositions(hip_lib, oracle, workdir, range(200, 260), budget=2)
     ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)
+
+
+def test_second_run_with_sized_launch(hip_lib, oracle, workdir):
+    """The batch stays resident and is run again (which units take the general path is decided after
+    (the first run): later runs of the same resident batch must give the same tables and paths."""
+    items = []
+    for i, (tier, K, nseg, njunc) in enumerate([("wide", 13, 64, 128), ("wide", 17, 128, 256), ("skew", 27, 64, 128), ("chain", 11, 64, 128), ("wide", 15, 96, 200)]):
+        s = synth.make_sample(nseg, njunc, tier, K, seed=9100 + i)
+        lh, sols = s.write(workdir, "sr%d" % i)
+        items.append((lh, sols[0]))
+    graphs, b = [], api.Batch(hip_lib)
+    for lh, sol in items:
+        g = api.Graph(hip_lib, lh)
+        graphs.append(g)
+        b.add_chromosome_sol(g, 0, sol)
+    b.upload()
+    snaps = []
+    for rep in range(3):
+        b.run(0); b.wait(); b.download()
+        snap = []
+        for u in range(len(items)):
+            r = b.unit_result(u)
+            assert r["status"] == 0, (rep, u, r)
+            snap.append((r["num_orders"], b.unit_orders(u, 0, r["num_orders"], r["n_nodes"]).tolist(), b.unit_path(u, 0).tolist(),
+                         b.unit_path(u, 1).tolist(), b.unit_bkp(u).tolist()))
+        snaps.append(snap)
+    assert snaps[0] == snaps[1] == snaps[2]
+    for u, (lh, sol) in enumerate(items):
+        o = oracle.run_bfb(lh, [sol], keep_orders=True)["chr"][0]
+        assert snaps[2][u][0] == o["num_orders"] and snaps[2][u][1] == o["orders"] and snaps[2][u][2] == o["path"]
+    b.close()
+    for g in graphs:
+        g.close()
