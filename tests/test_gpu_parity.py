@@ -175,9 +175,9 @@ def test_full_finish_stage_on_every_unit(hip_lib, oracle, workdir, monkeypatch):
     ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)
 
 
-def test_second_run_with_sized_launch(hip_lib, oracle, workdir):
-    """The batch stays resident and is run again (which units take the general path is decided after
-    (the first run): later runs of the same resident batch must give the same tables and paths."""
+def test_resident_batch_run_again(hip_lib, oracle, workdir):
+    """The batch stays resident and is run again (what the first run taught the engine -- which units take the general
+    enumerate path, how large the order arena has to be -- is reused): same tables and paths every time."""
     items = []
     for i, (tier, K, nseg, njunc) in enumerate([("wide", 13, 64, 128), ("wide", 17, 128, 256), ("skew", 27, 64, 128), ("chain", 11, 64, 128), ("wide", 15, 96, 200)]):
         s = synth.make_sample(nseg, njunc, tier, K, seed=9100 + i)
