@@ -783,13 +783,15 @@ class HipBackend : public Backend {
     }
     // Workgroups of the lean finish kernel.  Beside a long enumerate kernel the finish stage only has to be done when the
     // table is: the fewer of its workgroups are resident, the less they take from the enumerate workgroups (issue slots,
-    // group-memory bandwidth), so the grid is sized to finish just in time (measured on MI355X, profiles/r01_slices.md:
-    // 128 workgroups for 4096 units of the bench workload = 3.43 M/s, 256 = 3.33 M/s, one per unit = 2.84 M/s).  Without
-    // a long enumerate kernel (small order tables, first run) every unit gets its own workgroup.
+    // group-memory bandwidth), so the grid is sized to finish in time with a margin: too few workgroups and the finish
+    // kernel becomes the tail of the step (a steep loss), too many cost a little (measured on one MI355X,
+    // profiles/r01_slices.md: 112 / 128 / 144 / 160 / 176 / 256 / 4096 workgroups for the 4096 units of the bench workload
+    // = 1.25 / 1.17 / 1.125 / 1.126 / 1.13 / 1.14 / 1.39 ms per step).  Without a long enumerate kernel (small order
+    // tables, first run) every unit gets its own workgroup.
     int finish_grid_for(int U) const {
         if (finish_grid_ > 0) return U < finish_grid_ ? U : finish_grid_;          // env AMBI_FINISH_GRID
         if (!overlap_back_) return U;
-        const double enum_us = (double)last_needed_ / 4.2e6;                        // order-table bytes of the previous run at ~4.2 TB/s
+        const double enum_us = (double)last_needed_ / 5.2e6;                        // order-table bytes of the previous run at an optimistic 5.2 TB/s
         const double unit_us = 4.0 + hb_.max_path / 900.0 + hb_.max_m / 64.0;       // one unit through the lean finish stage
         if (enum_us < 8.0 * unit_us) return U;
         int64_t grid = (int64_t)((double)U * unit_us / enum_us) + 1;
