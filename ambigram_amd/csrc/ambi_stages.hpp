@@ -1,5 +1,5 @@
 // ambi_stages.hpp -- the per-unit stages of the reconstruction pipeline as SPMD functions over a thread group.
-// The HIP kernels (ambi_kernels.hip) are thin wrappers that carve the work areas out of LDS and call these;
+// The HIP kernels (ambi_engine.hip) are thin wrappers that carve the work areas out of LDS and call these;
 // the host simulation (tests/hostsim) calls the same functions with HostGroup and plain heap memory.
 //
 // Pipeline of one unit (reference: localhap.cpp:111-265):
@@ -7,7 +7,8 @@
 //   (plan)          order-table offsets / work blocks over the whole batch
 //   stage_enumerate block of consecutive topological orders -> R x K uint8 table
 //   stage_first     sequential scan for the first valid order (forward pass, then the flipped orientation)
-//   stage_finish    bkp -> path, indelBFB, output junctions
+//   stage_finish_lean  bkp -> path, indelBFB, output junctions, from the runs of the breakpoint path (every unit)
+//   stage_finish    the same with the path cells in group memory: units whose SVs chain or edit the path
 #pragma once
 #include "ambi_batch.hpp"
 #include "ambi_enum_blocks.hpp"
