@@ -70,6 +70,8 @@ def _declare(L):
         "ambi_batch_download": (C.c_int, [vp]),
         "ambi_batch_device_results": (C.c_int, [vp, _P(vp), pi64]),
         "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
+        "ambi_batch_pack_runs": (C.c_int, [vp, i32, vp, vp, vp, vp, i64, vp, vp]),
+        "ambi_expand_runs": (C.c_int, [vp, vp, vp, i64, vp, i64, vp]),
         "ambi_batch_unit_result": (C.c_int, [vp, i32, _P(UnitResult)]),
         "ambi_batch_unit_path": (C.c_int, [vp, i32, i32, pi32, i32]),
         "ambi_batch_unit_bkp": (C.c_int, [vp, i32, pi32, i32]),
@@ -312,6 +314,12 @@ class Batch:
         p, n = C.c_void_p(), C.c_int64()
         self._ck(self.lib.ambi_batch_device_results(self.h, C.byref(p), C.byref(n)), "device_results")
         return p.value, n.value
+
+    def pack_runs(self, which, dev_lengths_ptr, dev_run_counts_ptr, dev_run_start_ptr, dev_run_len_ptr, run_cap, dev_totals_ptr, stream=None):
+        """Final paths in run-length form into device buffers (ambi_batch_pack_runs): the payload of the exchange."""
+        self._ck(self.lib.ambi_batch_pack_runs(self.h, which, C.c_void_p(dev_lengths_ptr), C.c_void_p(dev_run_counts_ptr),
+                                                C.c_void_p(dev_run_start_ptr), C.c_void_p(dev_run_len_ptr), run_cap,
+                                                C.c_void_p(dev_totals_ptr), C.c_void_p(stream or 0)), "pack_runs")
 
     def pack_paths(self, which, dev_lengths_ptr, dev_cells_ptr, cell_cap, dev_total_ptr, stream=None):
         self._ck(self.lib.ambi_batch_pack_paths(self.h, which, C.c_void_p(dev_lengths_ptr), C.c_void_p(dev_cells_ptr), cell_cap,

@@ -33,6 +33,8 @@ class Backend {
     virtual int wait() = 0;
     virtual int download(std::vector<uint8_t>& blob) = 0;
     virtual int device_results(void** ptr, int64_t* bytes) = 0;
+    virtual int pack_runs(int which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start, int32_t* dev_run_len,
+                          int64_t run_cap, int64_t* dev_totals, void* stream) = 0;
     virtual int pack_paths(int which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap, int64_t* dev_total,
                            void* stream) = 0;
     virtual int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) = 0;
@@ -53,6 +55,9 @@ Backend* make_backend();   // defined by the linked backend
 // ILP entries (ambi_ilp_rows.hpp) written by the linked backend: the HIP engine launches ambi_ilp_fill_kernel and copies
 // col/val back, the host simulation runs the same entry function on the CPU.  kernel_ms: device time of the fill (0 on the host).
 struct IlpRowDesc;
+// runs -> cells in the backend's memory space (ambi_expand_runs of the C ABI)
+int backend_expand_runs(const int32_t* run_start, const int32_t* run_len, const int64_t* cell_off, int64_t n_runs, int32_t* cells,
+                        int64_t cell_cap, void* stream);
 int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_ptr, int start_id, int end_id, const int32_t* lit_col,
                      const double* lit_val, int64_t n_lit, int32_t* col, double* val, float* kernel_ms);
 

@@ -214,6 +214,18 @@ int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes) {
     if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     return b->be->device_results(dev_ptr, bytes);
 }
+int ambi_batch_pack_runs(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start,
+                         int32_t* dev_run_len, int64_t run_cap, int64_t* dev_totals, void* hip_stream) {
+    if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    if (!dev_lengths || !dev_run_counts || !dev_run_start || !dev_run_len || run_cap < 0) return AMBI_ERR_ARG;
+    return b->be->pack_runs(which, dev_lengths, dev_run_counts, dev_run_start, dev_run_len, run_cap, dev_totals, hip_stream);
+}
+int ambi_expand_runs(const int32_t* dev_run_start, const int32_t* dev_run_len, const int64_t* dev_cell_off, int64_t n_runs,
+                     int32_t* dev_cells, int64_t cell_cap, void* hip_stream) {
+    if (n_runs < 0 || cell_cap < 0 || (n_runs > 0 && (!dev_run_start || !dev_run_len || !dev_cell_off || !dev_cells))) return AMBI_ERR_ARG;
+    if (n_runs == 0) return 0;
+    return ambi::backend_expand_runs(dev_run_start, dev_run_len, dev_cell_off, n_runs, dev_cells, cell_cap, hip_stream);
+}
 int ambi_batch_pack_paths(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap,
                           int64_t* dev_total_cells, void* hip_stream) {
     if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;

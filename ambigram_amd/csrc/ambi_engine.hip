@@ -471,6 +471,85 @@ __global__ __launch_bounds__(256) void ambi_pack_copy_kernel(BatchArgs A, int wh
         if (off + i < cap) cells[off + i] = src[i];
 }
 
+// ---- run-length form of the final paths (payload of the end-of-batch exchange) ----
+// A run starts where a cell is not its predecessor + 1.  One workgroup per unit, two passes over the path in the result
+// blob: count the runs (all units) -> offsets (one scan) -> write {start value, length}.
+__device__ inline const int32_t* unit_final_path(const BatchArgs& A, int u, int which, int* len) {
+    const UnitIn& U = A.units[u];
+    const UnitOut* h = unit_out(A.results, u);
+    const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const bool stored = which && h->path_ind_stored;   // else the edited path equals `path`
+    *len = which ? h->path_indel_len : h->path_len;
+    return reinterpret_cast<const int32_t*>(A.results + U.res_off + (stored ? L.path_ind : L.path));
+}
+__global__ __launch_bounds__(256) void ambi_pack_runs_count_kernel(BatchArgs A, int which, int32_t* lengths, int32_t* run_counts) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    const int u = blockIdx.x;
+    int P;
+    const int32_t* src = unit_final_path(A, u, which, &P);
+    int mine = 0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) mine += (i == 0 || src[i] != src[i - 1] + 1) ? 1 : 0;
+    const int total = g.sum_i32(mine);
+    if (threadIdx.x == 0) { run_counts[u] = total; lengths[u] = P; }
+}
+__global__ __launch_bounds__(1024) void ambi_pack_runs_scan_kernel(BatchArgs A, const int32_t* lengths, const int32_t* run_counts, int64_t* run_off,
+                                                                   int64_t* totals) {
+    __shared__ int64_t sh[17];
+    int64_t carry = 0, cells = 0;
+    for (int base = 0; base < A.n_units; base += blockDim.x) {
+        const int u = base + (int)threadIdx.x;
+        const int64_t c = u < A.n_units ? run_counts[u] : 0, l = u < A.n_units ? lengths[u] : 0;
+        int64_t tot, totl;
+        const int64_t ex = block_exscan_i64(c, &tot, sh);
+        (void)block_exscan_i64(l, &totl, sh);
+        if (u < A.n_units) run_off[u] = carry + ex;
+        carry += tot; cells += totl;
+    }
+    if (threadIdx.x == 0) { run_off[A.n_units] = carry; if (totals) { totals[0] = carry; totals[1] = cells; } }
+}
+__global__ __launch_bounds__(256) void ambi_pack_runs_write_kernel(BatchArgs A, int which, const int64_t* run_off, int32_t* run_start,
+                                                                   int32_t* run_len, int64_t cap) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    const int u = blockIdx.x;
+    int P;
+    const int32_t* src = unit_final_path(A, u, which, &P);
+    const int64_t off = run_off[u];
+    const int n = (int)(run_off[u + 1] - off);
+    if (off + n > cap) return;   // the caller's buffers are too small: nothing is written for this unit (totals tell)
+    int done = 0;
+    for (int base = 0; base < P; base += blockDim.x) {      // run starts in path order: value and, for now, position
+        const int i = base + (int)threadIdx.x;
+        const int flag = (i < P && (i == 0 || src[i] != src[i - 1] + 1)) ? 1 : 0;
+        int tot;
+        const int ex = g.exscan_i32(flag, &tot);
+        if (flag) { run_start[off + done + ex] = src[i]; run_len[off + done + ex] = i; }
+        done += tot;
+    }
+    __syncthreads();
+    // positions -> lengths (the next run's position is read before anyone overwrites it: two phases)
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int k = base + (int)threadIdx.x;
+        int len = 0;
+        if (k < n) len = (k + 1 < n ? run_len[off + k + 1] : P) - run_len[off + k];
+        __syncthreads();
+        if (k < n) run_len[off + k] = len;
+        __syncthreads();
+    }
+}
+// one wavefront per run
+__global__ __launch_bounds__(256) void ambi_expand_runs_kernel(const int32_t* run_start, const int32_t* run_len, const int64_t* cell_off, int64_t n_runs,
+                                                               int32_t* cells, int64_t cap) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < n_runs; r += nwaves) {
+        const int32_t s = run_start[r], len = run_len[r];
+        const int64_t o = cell_off[r];
+        for (int k = lane; k < len; k += 64) if (o + k < cap) cells[o + k] = s + k;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backend
 // ------------------------------------------------------------------------------------------------
@@ -1014,6 +1093,18 @@ class HipBackend : public Backend {
         HIP_CK(hipGetLastError());
         return 0;
     }
+    int pack_runs(int which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start, int32_t* dev_run_len, int64_t run_cap,
+                  int64_t* dev_totals, void* stream) override {
+        hipStream_t s = (hipStream_t)stream;
+        bind(A_.flags);
+        hipLaunchKernelGGL(ambi_pack_runs_count_kernel, dim3(A_.n_units), dim3(256), 0, s, A_, which, dev_lengths, dev_run_counts);
+        hipLaunchKernelGGL(ambi_pack_runs_scan_kernel, dim3(1), dim3(1024), 0, s, A_, (const int32_t*)dev_lengths, (const int32_t*)dev_run_counts,
+                           d_pack_off_, dev_totals);
+        hipLaunchKernelGGL(ambi_pack_runs_write_kernel, dim3(A_.n_units), dim3(256), 0, s, A_, which, (const int64_t*)d_pack_off_, dev_run_start,
+                           dev_run_len, run_cap);
+        HIP_CK(hipGetLastError());
+        return 0;
+    }
     int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
         UnitOut h;
         HIP_CK(hipMemcpy(&h, d_results_ + sizeof(UnitOut) * (size_t)unit, sizeof(UnitOut), hipMemcpyDeviceToHost));
@@ -1140,6 +1231,17 @@ __global__ __launch_bounds__(256) void ambi_ilp_fill_kernel(const IlpItem* items
         const int64_t p0 = ((int64_t)__builtin_amdgcn_readlane((int)(it.p0 >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)it.p0, k);
         for (int j = j0 + lane; j < j1; j += 64) ilp_row_entry(d, G, j, lit_col, lit_val, col + p0 + j, val + p0 + j);
     }
+}
+
+int backend_expand_runs(const int32_t* run_start, const int32_t* run_len, const int64_t* cell_off, int64_t n_runs, int32_t* cells,
+                        int64_t cell_cap, void* stream) {
+    int64_t blocks = (n_runs + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ambi_expand_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, run_start, run_len, cell_off, n_runs, cells,
+                       cell_cap);
+    HIP_CK(hipGetLastError());
+    return 0;
 }
 
 int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_ptr, int s, int e, const int32_t* lit_col, const double* lit_val,

@@ -1,9 +1,16 @@
 """Sample sharding and the single end-of-batch exchange.
 
 Independent samples shard embarrassingly: rank r takes samples r, r+W, r+2W, ... and runs them as its own batch with no
-data-path collective.  The only exchange is the result gather: path lengths (int32 per unit, all_gather) followed by the
-concatenated int32 paths (gather to rank 0, padded to the largest rank).  On GPUs this is RCCL over xGMI (backend
+data-path collective.  The only exchange is the result gather to rank 0.  On GPUs this is RCCL over xGMI (backend
 "nccl"); the CPU tests run the same code on gloo.
+
+Two forms of the payload:
+* `RunExchange` (what bench.py uses): the paths travel in run-length form.  A BFB path is a few dozen runs of
+  consecutive segments on one strand (`3+4+5+`: start 3, length 3) for thousands of cells, so a rank sends ~0.5 KB per
+  256-segment sample instead of ~54 KB; the per-unit cell / run counts go out with one all_gather, the runs with one
+  gather, and rank 0 expands every rank's runs into cells in its own HBM (`ambi_expand_runs`, one wavefront per run, HBM
+  write speed).  With 4096 samples per rank that is 1.8 MB instead of 220 MB per xGMI link.
+* `PathExchange`: the expanded int32 cells themselves (all_gather of the lengths + gather of the cells).
 """
 import torch
 import torch.distributed as dist
@@ -46,6 +53,85 @@ class PathExchange:
         lens = self.lengths_all.cpu().view(self.world, self.n_units)
         for r in range(self.world):
             cells = (self.gather_list[r] if self.world > 1 else self.cells).cpu()
+            paths, off = [], 0
+            for u in range(self.n_units):
+                n = int(lens[r, u])
+                paths.append(cells[off:off + n].tolist())
+                off += n
+            out.append(paths)
+        return out
+
+
+class RunExchange:
+    """End-of-batch gather in run-length form.  `lib` is the engine library (its `ambi_expand_runs` runs on the memory
+    the tensors live in: HIP on the GPU, the host simulation in the CPU tests).  `n_units` must be the same on every rank;
+    the run and cell capacities are agreed with one all_reduce(MAX) at setup."""
+
+    def __init__(self, lib, n_units, local_runs, local_cells, device, world=None, rank=None):
+        self.lib = lib
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        cap = torch.tensor([max(int(local_runs), 1), max(int(local_cells), 1)], dtype=torch.int64, device=device)
+        if self.world > 1:
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        self.run_cap, self.cell_cap = int(cap[0].item()), int(cap[1].item())
+        self.n_units = n_units
+        self.counts = torch.zeros(2 * n_units, dtype=torch.int32, device=device)      # [cells per unit | runs per unit]
+        self.runs = torch.zeros(2 * self.run_cap, dtype=torch.int32, device=device)   # [start values | lengths]
+        self.totals = torch.zeros(2, dtype=torch.int64, device=device)                # {runs, cells} of this rank
+        multi = self.world > 1
+        self.counts_all = torch.zeros(2 * n_units * self.world, dtype=torch.int32, device=device) if multi else self.counts
+        self.gather_list = [torch.zeros_like(self.runs) for _ in range(self.world)] if (multi and self.rank == 0) else None
+        # rank 0: the expanded paths of every rank
+        self.cells_all = [torch.zeros(self.cell_cap, dtype=torch.int32, device=device) for _ in range(self.world)] if self.rank == 0 else None
+
+    @staticmethod
+    def probe(batch, n_units, device, which=1, stream=None):
+        """(runs, cells) the final paths of `batch` need: a counting pass with zero capacity (nothing is written)."""
+        counts = torch.zeros(2 * n_units, dtype=torch.int32, device=device)
+        dummy = torch.zeros(2, dtype=torch.int32, device=device)
+        totals = torch.zeros(2, dtype=torch.int64, device=device)
+        batch.pack_runs(which, counts.data_ptr(), counts[n_units:].data_ptr(), dummy.data_ptr(), dummy[1:].data_ptr(), 0, totals.data_ptr(), stream)
+        if totals.is_cuda:
+            torch.cuda.synchronize()
+        return int(totals[0].item()), int(totals[1].item())
+
+    @property
+    def lengths(self):
+        return self.counts[: self.n_units]
+
+    def pack(self, batch, which=1, stream=None):
+        """This rank's final paths -> run-length form in self.counts / self.runs (device side, on `stream`)."""
+        batch.pack_runs(which, self.counts.data_ptr(), self.counts[self.n_units:].data_ptr(), self.runs.data_ptr(),
+                        self.runs[self.run_cap:].data_ptr(), self.run_cap, self.totals.data_ptr(), stream)
+
+    def exchange(self):
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.counts_all, self.counts)
+            dist.gather(self.runs, self.gather_list, dst=0)
+
+    def expand(self, stream=None):
+        """Rank 0: every rank's runs -> cells (self.cells_all[r]); no host synchronisation (unused run slots have length 0)."""
+        if self.rank != 0:
+            return
+        import ctypes as C
+        for r in range(self.world):
+            runs = self.gather_list[r] if self.world > 1 else self.runs
+            lens = runs[self.run_cap:]
+            off = torch.cumsum(lens, 0, dtype=torch.int64) - lens
+            rc = self.lib.ambi_expand_runs(C.c_void_p(runs.data_ptr()), C.c_void_p(lens.data_ptr()), C.c_void_p(off.data_ptr()), self.run_cap,
+                                           C.c_void_p(self.cells_all[r].data_ptr()), self.cell_cap, C.c_void_p(stream or 0))
+            if rc != 0:
+                raise RuntimeError("ambi_expand_runs failed: %d" % rc)
+
+    def collect(self):
+        """Rank 0, after expand(): list (per rank) of lists (per unit) of int paths."""
+        if self.rank != 0:
+            return None
+        out = []
+        lens = self.counts_all.cpu().view(self.world, 2, self.n_units)[:, 0, :]
+        for r in range(self.world):
+            cells = self.cells_all[r].cpu()
             paths, off = [], 0
             for u in range(self.n_units):
                 n = int(lens[r, u])

@@ -6,8 +6,9 @@ bias, getIndelBias, targetCN, constructDAG, allTopologicalOrders, getBFB+imperfe
 over one batch of synthetic units that is already resident in HBM; the results (paths, breakpoints, output junctions)
 stay in the HBM of the GPU that produced them.  Samples are independent, so N GPUs run N batches (weak scaling) with
 no collective inside a step; for N > 1 the timed region ends with the single exchange the north star names ("a single
-RCCL gather over xGMI at the end"): the final paths are packed on the device and sent to rank 0 with one RCCL gather
-(`--gather 0`: leave them in each GPU's HBM, `--gather 2`: gather at the end of every step).
+RCCL gather over xGMI at the end"): the final paths are packed on the device in run-length form, sent to rank 0 with
+one RCCL gather and expanded there (`--gather 0`: leave them in each GPU's HBM, `--gather 2`: gather at the end of every
+step).
 
 Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted on: synthetic
 256-segment / 512-junction .lh samples, wide DAG tier K=19 (R = C(18,9) = 48 620 topological orders per sample),
@@ -95,19 +96,23 @@ def main():
     bad = [r for r in res if r["status"] != 0]
     if bad:
         raise SystemExit("bench: %d units did not reconstruct: %r" % (len(bad), bad[0]))
-    from ambigram_amd.dist import PathExchange
+    from ambigram_amd.dist import RunExchange
     total_cells = sum(r["path_indel_len"] for r in res)
-    px = PathExchange(B, total_cells, "cuda", world=world, rank=rank)
-    lengths, cells, tot, cell_cap = px.lengths, px.cells, px.total, px.cell_cap
+    n_runs, n_cells = RunExchange.probe(batch, B, "cuda", 1, stream)
+    assert n_cells == total_cells
+    px = RunExchange(lib, B, n_runs, n_cells, "cuda", world=world, rank=rank)
 
     gather_mode = (1 if world > 1 else 0) if args.gather < 0 else args.gather
 
     def gather():
-        # the single end-of-batch exchange of the north star: pack the final paths on the device, all-gather the path
-        # lengths, gather the concatenated int32 paths to rank 0 (RCCL over xGMI).  The reconstruction itself has no
-        # exchange step (samples are independent), so at N = 1 there is nothing to send and the step is the pipeline alone.
-        batch.pack_paths(1, lengths.data_ptr(), cells.data_ptr(), cell_cap, tot.data_ptr(), stream)
+        # the single end-of-batch exchange of the north star: the final paths in run-length form (a few dozen runs of
+        # consecutive segments per sample instead of thousands of cells), one all-gather of the per-sample counts and one
+        # gather of the runs to rank 0 (RCCL over xGMI), where every rank's runs are expanded into cells again.  The
+        # reconstruction itself has no exchange step (samples are independent), so at N = 1 there is nothing to send and
+        # the step is the pipeline alone.
+        px.pack(batch, 1, stream)
         px.exchange()
+        px.expand(stream)
 
     def step():
         batch.run(0, stream)
@@ -139,13 +144,18 @@ def main():
     ktimes = batch.kernel_times()
     batch.set_timing(False)
 
-    # sanity (outside the timed region): the packed payload equals the downloaded paths
+    # sanity (outside the timed region): the exchanged payload, expanded again, equals the downloaded paths
     gather()
     torch.cuda.synchronize()
     batch.download()
-    assert int(tot.item()) == total_cells
-    l_host = lengths.cpu().tolist()
+    assert int(px.totals[1].item()) == total_cells and int(px.totals[0].item()) == n_runs
+    l_host = px.lengths.cpu().tolist()
     assert l_host == [batch.unit_result(u)["path_indel_len"] for u in range(B)]
+    if rank == 0:
+        import numpy as np
+        mine = px.cells_all[0][:total_cells].cpu().numpy()
+        want = np.concatenate([batch.unit_path(u, 1) for u in range(B)]) if B else np.zeros(0, np.int32)
+        assert mine.shape == want.shape and bool((mine == want).all()), "expanded runs differ from the downloaded paths"
 
     if rank != 0:
         if world > 1:
@@ -254,7 +264,7 @@ def main():
         "dtype": "u8/int16 (order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
         "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, default CLI mode; %d samples per GPU resident in HBM"
                                % (args.segs, args.juncs, args.tier, args.K, B),
-                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths to rank 0 at the end of the timed steps", 2: "; one RCCL gather of the paths to rank 0 at the end of every step"}[gather_mode])},
+                   "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths (run-length form, expanded on rank 0) at the end of the timed steps", 2: "; one RCCL gather of the paths (run-length form) to rank 0 at the end of every step"}[gather_mode])},
         "roofline": roofline, "cpu_baseline": cpu, "single_sample": single,
     }
     print(json.dumps(out))

@@ -129,6 +129,19 @@ int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes);
 int ambi_batch_pack_paths(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap,
                           int64_t* dev_total_cells, void* hip_stream);
 
+/* The same payload in run-length form: a path is a sequence of runs whose cells count up by one (a stretch of
+ * consecutive segments on one strand: `3+4+5+` = start 3, length 3; `5-4-3-` = start -5, length 3), a few dozen runs for
+ * thousands of cells, so the exchange moves kilobytes instead of megabytes per sample and the receiving rank expands
+ * the runs in its own memory (ambi_expand_runs).  Per unit: dev_lengths[u] = cells, dev_run_counts[u] = runs; the runs
+ * of all units follow each other in dev_run_start / dev_run_len (int32 each, at most run_cap).  dev_totals (device,
+ * int64[2]) receives {runs, cells}. */
+int ambi_batch_pack_runs(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start,
+                         int32_t* dev_run_len, int64_t run_cap, int64_t* dev_totals, void* hip_stream);
+/* Expands runs into cells: run r writes dev_cells[dev_cell_off[r] + k] = dev_run_start[r] + k, k < dev_run_len[r]
+ * (dev_cell_off = exclusive prefix sum of the lengths, int64).  All pointers are device memory of the current device. */
+int ambi_expand_runs(const int32_t* dev_run_start, const int32_t* dev_run_len, const int64_t* dev_cell_off, int64_t n_runs,
+                     int32_t* dev_cells, int64_t cell_cap, void* hip_stream);
+
 typedef struct {
     int32_t status;
     int32_t bias;             /* localhap.cpp:141-146 */

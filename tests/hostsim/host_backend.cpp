@@ -275,6 +275,27 @@ class HostSimBackend : public Backend {
         if (total) *total = off;
         return 0;
     }
+    int pack_runs(int which, int32_t* lengths, int32_t* run_counts, int32_t* run_start, int32_t* run_len, int64_t cap, int64_t* totals,
+                  void*) override {
+        int64_t off = 0, cells = 0;
+        for (size_t u = 0; u < units_.size(); u++) {
+            const UnitOut* h = unit_out(results_.data(), (int)u);
+            const UnitIn& U = units_[u];
+            UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+            const int len = which ? h->path_indel_len : h->path_len;
+            const int32_t* src = reinterpret_cast<const int32_t*>(results_.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
+            lengths[u] = len;
+            int n = 0;
+            for (int i = 0; i < len; i++) {
+                if (i == 0 || src[i] != src[i - 1] + 1) { if (off + n < cap) { run_start[off + n] = src[i]; run_len[off + n] = 0; } n++; }
+                if (off + n - 1 < cap) run_len[off + n - 1]++;
+            }
+            run_counts[u] = n;
+            off += n; cells += len;
+        }
+        if (totals) { totals[0] = off; totals[1] = cells; }
+        return 0;
+    }
     int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
         const UnitOut* h = unit_out(results_.data(), unit);
         if (h->order_off < 0 || first < 0 || first + count > h->num_orders) return ST_ERR_BAD_INPUT;
@@ -290,6 +311,13 @@ class HostSimBackend : public Backend {
 };
 
 Backend* make_backend() { return new HostSimBackend(); }
+
+int backend_expand_runs(const int32_t* run_start, const int32_t* run_len, const int64_t* cell_off, int64_t n_runs, int32_t* cells,
+                        int64_t cell_cap, void*) {
+    for (int64_t r = 0; r < n_runs; r++)
+        for (int k = 0; k < run_len[r]; k++) if (cell_off[r] + k < cell_cap) cells[cell_off[r] + k] = run_start[r] + k;
+    return 0;
+}
 
 int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_ptr, int s, int e, const int32_t* lit_col, const double* lit_val,
                      int64_t, int32_t* col, double* val, float* kernel_ms) {

@@ -14,7 +14,7 @@ WORKER = textwrap.dedent('''
     import torch
     import torch.distributed as dist
     from ambigram_amd import api, synth
-    from ambigram_amd.dist import PathExchange, shard
+    from ambigram_amd.dist import PathExchange, RunExchange, shard
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
@@ -36,8 +36,20 @@ WORKER = textwrap.dedent('''
     batch.pack_paths(1, px.lengths.data_ptr(), px.cells.data_ptr(), px.cell_cap, px.total.data_ptr())
     px.exchange()
     got = px.collect()
+    # the same gather in run-length form (what bench.py does): pack -> all_gather of the counts + gather of the runs ->
+    # rank 0 expands every rank's runs
+    n_runs, n_cells = RunExchange.probe(batch, n_units, "cpu")
+    assert n_cells == cells_needed and 0 < n_runs <= n_cells
+    rx = RunExchange(lib, n_units, n_runs, n_cells, "cpu", world=world, rank=rank)
+    rx.pack(batch, 1)
+    rx.exchange()
+    rx.expand()
+    got_runs = rx.collect()
     if rank == 0:
+        assert got_runs == got, "run-length exchange differs from the cell exchange"
         json.dump(got, open(os.path.join(tmp, "gathered.json"), "w"))
+        json.dump({"runs": [int(x) for x in rx.counts_all.view(world, 2, n_units)[:, 1, :].sum(1)], "cells": [int(x) for x in rx.counts_all.view(world, 2, n_units)[:, 0, :].sum(1)]},
+                  open(os.path.join(tmp, "payload.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()
 ''')

@@ -206,3 +206,36 @@ def test_resident_batch_run_again(hip_lib, oracle, workdir):
     b.close()
     for g in graphs:
         g.close()
+
+
+def test_run_length_exchange_payload(hip_lib, oracle, workdir):
+    """pack_runs -> expand_runs on the GPU reproduces the downloaded paths (the payload of bench.py's gather), for both
+    path kinds, with far fewer runs than cells."""
+    import torch
+    from ambigram_amd.dist import RunExchange
+    items = []
+    for i in range(12):
+        s = synth.make_sample(64, 128, ("chain", "wide", "mixed")[i % 3], 9, seed=9300 + i, n_del=i % 3, imperfect=i % 2)
+        lh, sols = s.write(workdir, "rl%d" % i)
+        items.append((lh, sols[0]))
+    graphs, b = [], api.Batch(hip_lib)
+    for lh, sol in items:
+        g = api.Graph(hip_lib, lh)
+        graphs.append(g)
+        b.add_chromosome_sol(g, 0, sol)
+    b.upload(); b.run(0); b.wait(); b.download()
+    U = len(items)
+    for which in (0, 1):
+        n_runs, n_cells = RunExchange.probe(b, U, "cuda", which)
+        want = [b.unit_path(u, which).tolist() for u in range(U)]
+        assert n_cells == sum(len(w) for w in want) and 0 < n_runs <= max(n_cells, 1)
+        rx = RunExchange(hip_lib, U, n_runs, n_cells, "cuda", world=1, rank=0)
+        rx.pack(b, which)
+        rx.exchange()
+        rx.expand()
+        torch.cuda.synchronize()
+        assert rx.collect()[0] == want
+        assert n_runs * 8 < n_cells, (n_runs, n_cells)      # the point of the run-length form
+    b.close()
+    for g in graphs:
+        g.close()
