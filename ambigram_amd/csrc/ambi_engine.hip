@@ -210,9 +210,27 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     const int K = out->K;
     BlockImageHeader H;
     // the automaton copy sits in LDS, the image is assembled word by word straight in its HBM slot
-    const bool fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, ambi_lds, A.block_scratch_lds,
-                                        A.block_img + (int64_t)u * A.block_lds, A.block_lds, H,
-                                        A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
+    uint8_t* slot = A.block_img + (int64_t)u * A.block_lds;
+    bool fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, ambi_lds, A.block_scratch_lds, slot, A.block_lds, H,
+                                  A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
+    if (!fits && A.block_dfs) {
+        // one directory entry per block does not fit (many rows): the directory-free image -- [build tables][suffix rows],
+        // walked block by block at emission (emit_blocks_dfs_wave) -- with the largest block size whose suffix rows fit
+        BuildTables dummy;
+        const int64_t scr = carve_build_tables(ambi_lds, tbl.counter[0], tbl.counter[1], dummy);
+        const int64_t budget = (int64_t)A.block_lds - kDfsStateBytes - scr;
+        for (int bm = A.block_max; bm >= 8 && !fits && budget > 0 && scr <= A.block_scratch_lds; bm >>= 1) {
+            __syncthreads();
+            fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, bm, ambi_lds, A.block_scratch_lds, slot + scr, budget, H, nullptr, false);
+        }
+        if (fits) {   // the tables the walk reads travel with the suffix rows
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ambi_lds);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(slot);
+            for (int64_t i = threadIdx.x; i < scr / 4; i += blockDim.x) dst[i] = src[i];
+            H.pad = (int32_t)scr;
+            H.image_bytes += (int32_t)scr;
+        }
+    }
     if (threadIdx.x == 0) {
         *reinterpret_cast<BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u) = H;
         A.unit_fallback[u] = fits ? 0 : 1;
@@ -237,6 +255,13 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
     int staged_unit = -1;
     bool fits = false;
     int nB = 0;
+    // directory-free images (header fits == 2): tables at the front of the image, suffix rows behind; per-wave walk state
+    // in the last kDfsStateBytes of the workgroup's group memory
+    bool dfs = false;
+    int dfs_block_max = 0;
+    BuildTables Bt;
+    const uint32_t* dfs_suf = nullptr;
+    uint8_t* wave_state = tmem + A.block_lds - kDfsStateBytes + wave * (kDfsStateBytes / 4);
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
         if (b < A.n_units && A.blk_off[b] == b && A.blk_off[b + 1] == b + 1) lo = (int)b;   // one work block per unit so far: two independent reads
@@ -254,14 +279,21 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
                 BlockImageHeader H;
                 fits = scr < A.block_lds &&
                        build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, tmem, scr, tmem + scr, A.block_lds - scr, H);
+                dfs = false;
                 nB = H.nB;
                 image = reinterpret_cast<const uint32_t*>(tmem + scr);
                 if (!fits && threadIdx.x == 0) A.unit_fallback[u] = 1;   // the general enumerate kernel takes the unit
             } else {
                 const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
                 fits = hdr->fits != 0;
+                dfs = hdr->fits == 2;
                 nB = hdr->nB;
                 image = reinterpret_cast<const uint32_t*>(tmem);
+                if (dfs) {
+                    (void)carve_build_tables(tmem, hdr->nI, hdr->nC, Bt);
+                    dfs_suf = reinterpret_cast<const uint32_t*>(tmem + hdr->pad);
+                    dfs_block_max = hdr->block_max;
+                }
                 if (fits) {   // coalesced copy of the unit's image into LDS
                     const int64_t nvec = ((int64_t)hdr->image_bytes + 15) >> 4;
                     const uint4* src = reinterpret_cast<const uint4*>(A.block_img + (int64_t)u * A.block_lds);
@@ -284,9 +316,14 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         const int64_t wlo = blo + (int64_t)wave * per;
         int64_t whi = wlo + per;
         if (whi > bhi) whi = bhi;
-        if (wlo < whi)
-            emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)wlo, (uint32_t)whi,
-                                      A.order_arena + out->order_off, lane, lane + 1);
+        if (wlo < whi) {
+            if (dfs)
+                emit_blocks_dfs_dispatch<CLS>(Bt, dfs_suf, K, dfs_block_max, (uint32_t)wlo, (uint32_t)whi, A.order_arena + out->order_off,
+                                              reinterpret_cast<uint16_t*>(wave_state), reinterpret_cast<uint32_t*>(wave_state + 128), lane, lane + 1);
+            else
+                emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)wlo, (uint32_t)whi,
+                                          A.order_arena + out->order_off, lane, lane + 1);
+        }
     }
 }
 
@@ -599,6 +636,7 @@ class HipBackend : public Backend {
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr;
     uint8_t* d_first_rows_ = nullptr;
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
+    int block_dfs_ = 1;       // env AMBI_BLOCK_DFS=0: no directory-free images (units whose directory does not fit take the general path)
     std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit
     bool all_done_ = false;
     int enum_grid_ = 2048;
@@ -764,6 +802,7 @@ class HipBackend : public Backend {
         // first orders of every unit, written by the prepare stage (takes the enumerate kernel off the critical path of the scan)
         if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
         { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
+        { const char* e9 = getenv("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
             // the scan / finish kernels fill the gaps the enumerate kernel leaves: lowest dispatch priority (AMBI_BACK_PRIORITY=0: default)
@@ -793,7 +832,7 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
-        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
+        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.block_dfs = block_dfs_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;

@@ -35,6 +35,7 @@ AMBI_HD int uni(int x) {
 #endif
 }
 AMBI_HD uint32_t uniu(uint32_t x) { return (uint32_t)uni((int)x); }
+AMBI_HD uint64_t uniu64(uint64_t x) { return ((uint64_t)uniu((uint32_t)(x >> 32)) << 32) | uniu((uint32_t)x); }
 
 // x / N for the small x of block emission (in-block dword offsets, x <= kBlockMaxLimit * N) without the 32x32
 // multiply-high of a generic constant division: halve even N, 16-bit multiply-shift by 2^16/N for odd N.  The
@@ -107,7 +108,7 @@ AMBI_HD int64_t carve_build_tables(uint8_t* mem, int nI, int nC, BuildTables& B)
 template <class G>
 AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, int64_t R, int block_max,
                                uint8_t* scratch, int64_t scratch_bytes, uint8_t* image, int64_t image_bytes,
-                               BlockImageHeader& H, int64_t* clk = nullptr) {
+                               BlockImageHeader& H, int64_t* clk = nullptr, bool with_directory = true) {
     clk_mark(g, clk, 31);
     const int nI = T.counter[0], nC = T.counter[1];
     H.fits = 0; H.nB = 0; H.suf_words = 0; H.image_bytes = 0; H.nI = nI; H.nC = nC; H.block_max = block_max; H.pad = 0;
@@ -171,8 +172,10 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     clk_mark(g, clk, 15);
     const int nRoots = B.misc[0];
     const int64_t suf_words = B.misc[1];
-    const int64_t nB = B.nblk[0];
-    const int64_t dw = dir_words((int)(nB > (1 << 24) ? (1 << 24) : nB), NW);
+    // without the directory (tables + suffix rows only) the emission walks the blocks itself (emit_blocks_dfs_wave): the
+    // form for units with so many rows that one directory entry per block does not fit
+    const int64_t nB = with_directory ? (int64_t)B.nblk[0] : 0;
+    const int64_t dw = with_directory ? dir_words((int)(nB > (1 << 24) ? (1 << 24) : nB), NW) : 0;
     if (!B.misc[2] || nB > (1 << 24) || 4 * (dw + suf_words) > image_bytes) return false;
     uint32_t* suf = img + dw;
     // ---- directory: block b = b-th stop of the walk, unranked over nblk; first row from the exact 64-bit counts ----
@@ -218,7 +221,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         e[1] = B.soff[i];
         for (int x = NW; x < NW + 3; x++) { const int y = x % NW; e[2 + x] = y == 0 ? w0 : (y == 1 ? w1 : w2); }
     }
-    if (g.tid() == 0) img[nB * S] = (uint32_t)R;
+    if (with_directory && g.tid() == 0) img[nB * S] = (uint32_t)R;
     clk_mark(g, clk, 29);
     // ---- suffix rows: row r of root p = r-th completion of p in lexicographic order, bytes in their final positions ----
     const int total_rows = (int)B.root_row[nRoots];
@@ -276,13 +279,40 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     }
     g.sync();
     clk_mark(g, clk, 30);
-    H.fits = 1; H.nB = (int32_t)nB; H.suf_words = (int32_t)suf_words; H.image_bytes = (int32_t)(4 * (dw + suf_words));
+    H.fits = with_directory ? 1 : 2; H.nB = (int32_t)nB; H.suf_words = (int32_t)suf_words; H.image_bytes = (int32_t)(4 * (dw + suf_words));
     return true;
 }
 
+// One piece of the table: rows [cur, end) of the block whose first row is r0, whose suffix rows start at dword `so` of
+// `suf` and whose prefix words (with three wrap copies) are pp[0 .. NW+2].  lane_lo/lane_hi: the lanes this call
+// stands for ([lane, lane+1) on the GPU, [0, 64) in the host simulation).
+template <int NW>
+AMBI_HD void emit_piece(const uint32_t* suf, uint32_t so, uint32_t r0, uint32_t cur, uint32_t end, const uint32_t* pp, uint32_t* table,
+                        int lane_lo, int lane_hi) {
+    const int n = (int)(end - cur) * NW;                 // dwords of this piece (starts at a row boundary)
+    const int64_t g0 = (int64_t)cur * NW;
+    int head = (int)((-g0) & 3); if (head > n) head = n;   // dwords before the first 16-byte boundary
+    const int body_end = head + ((n - head) & ~3);
+    const uint32_t* sp = suf + so + (cur - r0) * NW;     // suffix dword of in-piece offset 0
+    uint32_t* out = table + g0;
+    for (int lane = lane_lo; lane < lane_hi; lane++) {
+        if (lane < head) out[lane] = sp[lane] | pp[lane];                        // lane < 4 <= NW + 3
+        const int rel = body_end + lane;
+        if (rel < n) out[rel] = sp[rel] | pp[small_mod<NW>((uint32_t)rel)];
+    }
+    for (int base = head; base < body_end; base += 256) {
+        for (int lane = lane_lo; lane < lane_hi; lane++) {
+            const int rel = base + 4 * lane;
+            if (rel < body_end) {
+                const uint32_t k = small_mod<NW>((uint32_t)rel);
+                store4(out + rel, sp[rel] | pp[k], sp[rel + 1] | pp[k + 1], sp[rel + 2] | pp[k + 2], sp[rel + 3] | pp[k + 3]);
+            }
+        }
+    }
+}
+
 // Rows [rlo, rhi) of one unit's table, written by ONE wave from the unit's image (`img`, nB blocks).  `table` = the
-// unit's rows as dwords (16-byte aligned).  lane_lo/lane_hi: the lanes this call stands for ([lane, lane+1) on the
-// GPU, [0, 64) in the host simulation).
+// unit's rows as dwords (16-byte aligned).
 template <int NW>
 AMBI_HD void emit_blocks_wave(const uint32_t* img, int nB, uint32_t rlo, uint32_t rhi, uint32_t* table, int lane_lo, int lane_hi) {
     if (rlo >= rhi || nB <= 0) return;
@@ -299,29 +329,86 @@ AMBI_HD void emit_blocks_wave(const uint32_t* img, int nB, uint32_t rlo, uint32_
         const uint32_t* e = img + b * S;
         const uint32_t r0 = uniu(e[0]), r1 = uniu(e[S]), so = uniu(e[1]);
         const uint32_t end = r1 < rhi ? r1 : rhi;
-        const int n = (int)(end - cur) * NW;                 // dwords of this piece (starts at a row boundary)
-        const int64_t g0 = (int64_t)cur * NW;
-        int head = (int)((-g0) & 3); if (head > n) head = n;   // dwords before the first 16-byte boundary
-        const int body_end = head + ((n - head) & ~3);
-        const uint32_t* sp = suf + so + (cur - r0) * NW;     // suffix dword of in-piece offset 0
-        const uint32_t* pp = e + 2;                          // prefix dword of in-piece offset x: pp[x % NW]
-        uint32_t* out = table + g0;
-        for (int lane = lane_lo; lane < lane_hi; lane++) {
-            if (lane < head) out[lane] = sp[lane] | pp[lane];                        // lane < 4 <= NW + 3
-            const int rel = body_end + lane;
-            if (rel < n) out[rel] = sp[rel] | pp[small_mod<NW>((uint32_t)rel)];
-        }
-        for (int base = head; base < body_end; base += 256) {
-            for (int lane = lane_lo; lane < lane_hi; lane++) {
-                const int rel = base + 4 * lane;
-                if (rel < body_end) {
-                    const uint32_t k = small_mod<NW>((uint32_t)rel);
-                    store4(out + rel, sp[rel] | pp[k], sp[rel + 1] | pp[k + 1], sp[rel + 2] | pp[k + 2], sp[rel + 3] | pp[k + 3]);
-                }
-            }
-        }
+        emit_piece<NW>(suf, so, r0, cur, end, e + 2, table, lane_lo, lane_hi);
         cur = end;
         b++;
+    }
+}
+
+// The same rows without a directory: the wave walks the blocks itself.  A block is a root of the cut (an ideal with at
+// most block_max completions whose parent has more); the walk is the depth-first traversal of the order tree above the
+// roots in child order -- unrank the first row once (exact 64-bit counts), then per block: emit, climb to the first
+// ancestor with a further child, take it, descend along first children to the next root.  Everything about the walk is
+// uniform over the wave (every lane reads the same table entries); per wave it keeps the ideals on the current path
+// (`stack`, one uint16 per depth) and the prefix words with their three wrap copies (`pw`, NW + 3 dwords) in group
+// memory.  One step of the walk costs a handful of dependent reads per ~block_max rows, which is what makes this form
+// slower than the directory when the directory fits, and the only block form when it does not (R beyond ~10^5 rows).
+template <int NW>
+AMBI_HD void emit_blocks_dfs_wave(const BuildTables& B, const uint32_t* suf, int K, int block_max, uint32_t rlo, uint32_t rhi, uint32_t* table,
+                                  uint16_t* stack, uint32_t* pw, int lane_lo, int lane_hi) {
+    if (rlo >= rhi) return;
+    // every lane of the wave runs this bookkeeping with identical values; the stores to the wave's own stack / pw slots
+    // are the same from all of them
+    auto set_byte = [&](int d, uint32_t v) {
+        const int wi = d >> 2, sh = (d & 3) * 8;
+        const uint32_t w = (uniu(pw[wi]) & ~(0xFFu << sh)) | (v << sh);
+        pw[wi] = w;
+        if (wi < 3) pw[NW + wi] = w;
+    };
+    for (int x = 0; x < NW + 3; x++) pw[x] = 0;
+    int i = 0, d = 0;
+    uint64_t rem = rlo;
+    while (uni(B.cnt16[i]) > block_max) {          // unrank rlo down to its root
+        uint64_t av = uniu64(B.avail[i]);
+        int k = B.cbase[i], chosen = 0, nxt = 0;
+        while (av) {
+            const int v = ctz64(av);
+            av &= av - 1;
+            nxt = uni(B.child[k++]);
+            const uint64_t cc = uniu64(B.cnt64[nxt]);
+            if (rem < cc) { chosen = v; break; }
+            rem -= cc;
+        }
+        stack[d] = (uint16_t)i;
+        set_byte(d, (uint32_t)chosen);
+        i = nxt; d++;
+    }
+    uint32_t cur = rlo;
+    uint32_t r0 = rlo - (uint32_t)rem;
+    while (true) {
+        const uint32_t r1 = r0 + uniu(B.cnt16[i]);
+        const uint32_t end = r1 < rhi ? r1 : rhi;
+        emit_piece<NW>(suf, uniu(B.soff[i]), r0, cur, end, pw, table, lane_lo, lane_hi);
+        cur = end;
+        if (cur >= rhi) break;
+        // next block: first ancestor with a child behind the one taken, then first children down to a root
+        int nxt = -1;
+        while (d > 0) {
+            d--;
+            const int p = uni(stack[d]);
+            const int v = (int)((uniu(pw[d >> 2]) >> ((d & 3) * 8)) & 0xFFu);           // the node taken at depth d
+            const uint64_t av = uniu64(B.avail[p]);
+            const uint64_t rest = v >= 63 ? 0ull : (av & ~((2ull << v) - 1ull));       // nodes behind it
+            if (rest) {
+                const int v2 = ctz64(rest);
+                const int k = uni(B.cbase[p]) + popc64(av & ((1ull << v2) - 1ull));
+                set_byte(d, (uint32_t)v2);
+                nxt = uni(B.child[k]);
+                d++;
+                break;
+            }
+            set_byte(d, 0u);                                                            // bytes behind the prefix stay zero
+        }
+        if (nxt < 0) break;                     // no further block (cur < rhi <= R should not get here)
+        i = nxt;
+        while (uni(B.cnt16[i]) > block_max) {
+            const uint64_t av = uniu64(B.avail[i]);
+            stack[d] = (uint16_t)i;
+            set_byte(d, (uint32_t)ctz64(av));
+            i = uni(B.child[uni(B.cbase[i])]);
+            d++;
+        }
+        r0 = cur;
     }
 }
 

@@ -302,6 +302,22 @@ AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t r
 #undef AMBI_EB
 }
 
+// The directory-free form (emit_blocks_dfs_wave); stack / pw: the calling wave's slots in group memory.
+template <int CLS>
+AMBI_HD void emit_blocks_dfs_dispatch(const BuildTables& B, const uint32_t* suf, int K, int block_max, uint32_t rlo, uint32_t rhi,
+                                      uint8_t* unit_rows, uint16_t* stack, uint32_t* pw, int lane_lo, int lane_hi) {
+    const int nw = row_stride(K) / 4;
+    uint32_t* table = reinterpret_cast<uint32_t*>(unit_rows);
+#define AMBI_ED(N) emit_blocks_dfs_wave<N>(B, suf, K, block_max, rlo, rhi, table, stack, pw, lane_lo, lane_hi); return;
+    if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_ED(1) case 2: AMBI_ED(2) case 3: AMBI_ED(3) case 4: AMBI_ED(4) case 5: AMBI_ED(5) default: break; } }
+    if (CLS < 0 || CLS == 1) { switch (nw) { case 6: AMBI_ED(6) case 7: AMBI_ED(7) case 8: AMBI_ED(8) default: break; } }
+    if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_ED(12) } else if (nw == 16) { AMBI_ED(16) } }
+#undef AMBI_ED
+}
+// group memory of the walk per wave: the ideals of the current path + prefix words with wrap copies
+constexpr int kDfsWaveBytes = 2 * 64 + 4 * (16 + 3) + 4;   // 208
+constexpr int kDfsStateBytes = 4 * ((kDfsWaveBytes + 15) & ~15);   // four waves per workgroup
+
 // Row-width classes of the enumerate kernel (one kernel instantiation each, so that the register budget of the wide
 // rows does not throttle the occupancy of the narrow ones): 0: K <= 20, 1: K <= 32, 2: K <= 63.
 AMBI_HD int enum_class_of(int K) { return K <= 20 ? 0 : (K <= 32 ? 1 : 2); }

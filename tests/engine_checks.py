@@ -161,7 +161,10 @@ def check_enumerate_variants(lib, oracle, workdir, big=False):
         oc = oracle.run_bfb(lh, sols, keep_orders=True)["chr"][0]
         samples.append((lh, sols, oc))
     variants = [({}, 0), ({"AMBI_BLOCK_MAX": "1"}, 0), ({"AMBI_BLOCK_MAX": "6"}, 64), ({"AMBI_BLOCK_MAX": "1024", "AMBI_BLOCK_LDS": "150000"}, 0),
-                ({"AMBI_BLOCK_LDS": "64"}, 0), ({"AMBI_BLOCK_LDS": "64"}, 100000), ({"AMBI_BLOCK_MAX": "37"}, 1 << 20)]
+                ({"AMBI_BLOCK_LDS": "64"}, 0), ({"AMBI_BLOCK_LDS": "64"}, 100000), ({"AMBI_BLOCK_MAX": "37"}, 1 << 20),
+                # budgets in which the directory of most units does not fit but tables + suffix rows do: the
+                # directory-free block walk, started at the top of the table and (few rows per lane) in the middle of it
+                ({"AMBI_BLOCK_LDS": "12288"}, 0), ({"AMBI_BLOCK_LDS": "8192", "AMBI_BLOCK_MAX": "24"}, 256), ({"AMBI_BLOCK_LDS": "6144"}, 64)]
     saved = {k: os.environ.get(k) for k in ("AMBI_BLOCK_MAX", "AMBI_BLOCK_LDS")}
     try:
         for env, lanes in variants:

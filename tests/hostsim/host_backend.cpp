@@ -86,7 +86,10 @@ class HostSimBackend : public Backend {
         std::vector<uint8_t> bscratch((size_t)cfg_.block_scratch_lds);
         int built_unit = -1;
         BlockImageHeader H{};
-        bool fast = false;
+        bool fast = false, dfs = false;
+        BuildTables Bt{};
+        std::vector<uint16_t> dfs_stack(64);
+        std::vector<uint32_t> dfs_pw(20);
         for (int64_t b = 0; b < total; b++) {
             int lo = 0, hi = (int)units_.size();
             while (hi - lo > 1) { int mid = (lo + hi) / 2; if (blk_off_[mid] <= b) lo = mid; else hi = mid; }
@@ -100,6 +103,17 @@ class HostSimBackend : public Backend {
             if (u != built_unit) {   // ambi_blocks_build_kernel: once per unit
                 fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, block_max, bscratch.data(), (int64_t)bscratch.size(),
                                          image.data(), block_lds, H);
+                dfs = false;
+                if (!fast) {   // ambi_blocks_build_kernel's second form: tables + suffix rows, walked at emission
+                    BuildTables dummy;
+                    const int64_t scr = carve_build_tables(bscratch.data(), tbl.counter[0], tbl.counter[1], dummy);
+                    const int64_t budget = block_lds - kDfsStateBytes - scr;
+                    for (int bm = block_max; bm >= 8 && !fast && budget > 0 && scr <= (int64_t)bscratch.size(); bm >>= 1)
+                        fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, bm, bscratch.data(), (int64_t)bscratch.size(),
+                                                 image.data(), budget, H, nullptr, false);
+                    if (fast) { dfs = true; (void)carve_build_tables(bscratch.data(), tbl.counter[0], tbl.counter[1], Bt); }
+                    if (getenv("AMBI_HOSTSIM_TRACE")) fprintf(stderr, "hostsim: unit %d (K=%d, R=%lld): %s\n", u, K, (long long)R, fast ? "directory-free block walk" : "general path");
+                }
                 built_unit = u;
             }
             for (int w = 0; w < 4; w++) {
@@ -107,7 +121,10 @@ class HostSimBackend : public Backend {
                 int64_t whi = wlo + 64ll * T;
                 if (whi > R) whi = R;
                 if (wlo >= R) break;
-                if (fast) {
+                if (fast && dfs) {
+                    emit_blocks_dfs_dispatch<-1>(Bt, reinterpret_cast<const uint32_t*>(image.data()), K, H.block_max, (uint32_t)wlo, (uint32_t)whi, rows,
+                                                 dfs_stack.data(), dfs_pw.data(), 0, 64);
+                } else if (fast) {
                     emit_blocks_dispatch<-1>(reinterpret_cast<const uint32_t*>(image.data()), H.nB, K, (uint32_t)wlo, (uint32_t)whi, rows, 0, 64);
                 } else {
                     GlobalAuto ga{V};
