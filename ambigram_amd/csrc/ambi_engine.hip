@@ -270,6 +270,10 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         const UnitOut* out = unit_out(A.results, u);
         const int K = out->K, T = A.rows_per_lane[u];
         if (enum_class_of(K) != CLS) continue;
+        if (A.first_rows && out->num_orders <= A.first_budget) {   // the table is among the rows unranked for the scan
+            copy_first_rows(g, A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride, K, out->num_orders, A.order_arena + out->order_off);
+            continue;
+        }
         if (u != staged_unit) {
             g.sync();
             if (A.build_in_emit && A.blk_off[lo + 1] - A.blk_off[lo] == 1) {

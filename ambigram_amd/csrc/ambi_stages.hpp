@@ -302,6 +302,19 @@ AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t r
 #undef AMBI_EB
 }
 
+// A unit with no more orders than the prepare stage unranked for the scan (R <= first_budget: every chain-like DAG) has
+// its whole table among those rows already: the table is a copy (node bytes, then the 0xFF padding of the row), no image.
+template <class G>
+AMBI_HD void copy_first_rows(const G& g, const uint8_t* first, int K, int64_t R, uint8_t* rows) {
+    const int stride = row_stride(K);
+    const int64_t bytes = R * stride;
+    for (int64_t x = g.tid(); x < bytes; x += g.size()) {
+        const int64_t r = x / stride;
+        const int d = (int)(x - r * stride);
+        rows[x] = d < K ? first[r * kFirstRowStride + d] : (uint8_t)0xFF;
+    }
+}
+
 // The directory-free form (emit_blocks_dfs_wave); stack / pw: the calling wave's slots in group memory.
 template <int CLS>
 AMBI_HD void emit_blocks_dfs_dispatch(const BuildTables& B, const uint32_t* suf, int K, int block_max, uint32_t rlo, uint32_t rhi,

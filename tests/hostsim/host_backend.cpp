@@ -100,6 +100,10 @@ class HostSimBackend : public Backend {
             IdealTable tbl = unit_ideal_table(A_, u);
             AutoView V = auto_view(tbl);
             uint8_t* rows = A_.order_arena + out->order_off;
+            if (A_.first_rows && R <= A_.first_budget) {   // as ambi_enumerate_blocks_kernel: the table is a copy of the first rows
+                copy_first_rows(g, A_.first_rows + (int64_t)u * A_.first_budget * kFirstRowStride, K, R, rows);
+                continue;
+            }
             if (u != built_unit) {   // ambi_blocks_build_kernel: once per unit
                 fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, block_max, bscratch.data(), (int64_t)bscratch.size(),
                                          image.data(), block_lds, H);
