@@ -284,6 +284,19 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
                 fits = scr < A.block_lds &&
                        build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, A.block_max, tmem, scr, tmem + scr, A.block_lds - scr, H);
                 dfs = false;
+                if (!fits && A.block_dfs) {   // directory too large: tables + suffix rows, walked at emission (as the build kernel does)
+                    const int64_t budget = (int64_t)A.block_lds - kDfsStateBytes - scr;
+                    for (int bm = A.block_max; bm >= 8 && !fits && budget > 0; bm >>= 1) {
+                        g.sync();
+                        fits = build_block_image(g, tbl, K, row_stride(K) / 4, out->num_orders, bm, tmem, scr, tmem + scr, budget, H, nullptr, false);
+                    }
+                    if (fits) {
+                        dfs = true;
+                        (void)carve_build_tables(tmem, tbl.counter[0], tbl.counter[1], Bt);
+                        dfs_suf = reinterpret_cast<const uint32_t*>(tmem + scr);
+                        dfs_block_max = H.block_max;
+                    }
+                }
                 nB = H.nB;
                 image = reinterpret_cast<const uint32_t*>(tmem + scr);
                 if (!fits && threadIdx.x == 0) A.unit_fallback[u] = 1;   // the general enumerate kernel takes the unit
