@@ -207,7 +207,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a single-thread port of the reference path) on this box's host cores ----
     cpu = None
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and world == 1:      # rank 0 at N = 1 only
         from oracle import oracle_py
         oracle_py.build(ref=False)
         spent, recon, whole, cnt = 0.0, 0.0, 0.0, 0
@@ -231,7 +231,7 @@ def main():
     # the same with the upload of the unit and the download of its path included; the CPU figure is the oracle on the
     # SAME sample (stages #7,#8,#11-#16,#20), so the ratio compares like with like.
     single = None
-    if args.single_reps > 0:
+    if args.single_reps > 0 and world == 1:
         one = api.Batch(lib)
         one.add_chromosome_sol(graphs[0], 0, files[0][1][0])
         one.upload()
@@ -250,7 +250,7 @@ def main():
         assert one.unit_path(0, 1).tolist() == batch.unit_path(0, 1).tolist()
         single = {"gpu_ms": gpu_ms, "gpu_ms_with_upload_and_download": pcie_ms, "reps": args.single_reps,
                   "sample": "sample 0 of the batch (1 unit, R = %d orders)" % res[0]["num_orders"]}
-        if args.cpu_seconds > 0:
+        if cpu is not None:
             best = None
             for _ in range(5):
                 r = oracle_py.run_bfb(files[0][0], files[0][1])
