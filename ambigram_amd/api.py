@@ -80,6 +80,7 @@ def _declare(L):
         "ambi_batch_unit_out_juncs": (C.c_int, [vp, i32, pi32, pi32, pi32, i32]),
         "ambi_batch_unit_orders": (C.c_int, [vp, i32, i64, i64, pu8]),
         "ambi_batch_set_timing": (C.c_int, [vp, i32]),
+        "ambi_batch_set_timing_mask": (C.c_int, [vp, C.c_uint32]),
         "ambi_batch_kernel_count": (C.c_int, [vp]),
         "ambi_batch_kernel_time": (C.c_int, [vp, i32, _P(C.c_char_p), _P(C.c_float)]),
         "ambi_batch_slices": (C.c_int, [vp]),
@@ -369,6 +370,16 @@ class Batch:
 
     def set_timing(self, on=True):
         self.lib.ambi_batch_set_timing(self.h, 1 if on else 0)
+
+    KERNEL_INDEX = {"ambi_prepare_kernel": 0, "ambi_plan_kernel": 1, "ambi_blocks_build_kernel": 2, "ambi_enumerate_kernel": 3,
+                    "ambi_first_kernel": 4, "ambi_finish_kernel": 5}
+
+    def set_timing_only(self, kernel_names):
+        """HIP events around the named kernels only (every event pair is a marker in the stream)."""
+        mask = 0
+        for k in kernel_names:
+            mask |= 1 << self.KERNEL_INDEX[k]
+        self.lib.ambi_batch_set_timing_mask(self.h, mask)
 
     def all_orders(self, u, pass_):
         """--all: indices of the valid orders of pass 0 (first orientation) / 1 (flipped), in print order."""

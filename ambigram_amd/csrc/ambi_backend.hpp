@@ -40,6 +40,7 @@ class Backend {
     virtual int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) = 0;
     virtual int copy_dag(int unit, Dag* out) = 0;
     virtual void set_timing(bool on) = 0;
+    virtual void set_timing_mask(uint32_t mask) { set_timing(mask != 0); }
     virtual const std::vector<KernelTime>& kernel_times() = 0;
     virtual int64_t order_bytes_written() const = 0;
     virtual int slice_count() const { return 1; }   // launches of every kernel per run

@@ -332,6 +332,7 @@ int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t fi
     return b->be->all_paths(unit, pass, first, count, lengths, cells, stride);
 }
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on) { if (!b) return AMBI_ERR_ARG; b->be->set_timing(on != 0); return 0; }
+int ambi_batch_set_timing_mask(ambi_batch_t* b, uint32_t mask) { if (!b) return AMBI_ERR_ARG; b->be->set_timing_mask(mask); return 0; }
 int ambi_batch_slices(const ambi_batch_t* b) { return b ? b->be->slice_count() : AMBI_ERR_ARG; }
 int ambi_batch_kernel_count(const ambi_batch_t* b) { return b ? (int)b->be->kernel_times().size() : AMBI_ERR_ARG; }
 int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms) {

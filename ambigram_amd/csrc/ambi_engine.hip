@@ -611,6 +611,7 @@ class HipBackend : public Backend {
     HostBatch hb_;
     EngineConfig cfg_;
     bool uploaded_ = false, timing_ = false, arena_checked_ = false, ran_ = false;
+    uint32_t timing_mask_ = ~0u;   // kernels that get events (bit = kernel index)
     hipStream_t stream_ = nullptr;
     // device buffers
     UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; Element* d_elems_ = nullptr;
@@ -876,7 +877,7 @@ class HipBackend : public Backend {
     // runs be averaged without a host sync per run: run r records into slot r % kTimingSlots.
     static constexpr int kTimingSlots = 64, kTimedKernels = 6;
     void tick(const char* name, int slice, size_t idx, bool begin, hipStream_t on = (hipStream_t)-1) {
-        if (!timing_) return;
+        if (!timing_ || !((timing_mask_ >> idx) & 1u)) return;
         const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
         const size_t at = (slot * n_slices_ + slice) * kTimedKernels + idx;
         while (evs_.size() <= at) {
@@ -1094,8 +1095,11 @@ class HipBackend : public Backend {
             // switched on (every run launches each kernel once per slice)
             const long filled = timed_runs_ < kTimingSlots ? timed_runs_ : kTimingSlots;
             times_.clear();
+            static const char* const kKernelNames[kTimedKernels] = {"ambi_prepare_kernel", "ambi_plan_kernel", "ambi_blocks_build_kernel",
+                                                                    "ambi_enumerate_kernel", "ambi_first_kernel", "ambi_finish_kernel"};
             for (int k = 0; k < kTimedKernels; k++) {
-                double sum = 0; int cnt = 0; const char* nm = "";
+                double sum = 0; int cnt = 0; const char* nm = kKernelNames[k];
+                if (!((timing_mask_ >> k) & 1u)) { times_.push_back({nm, -1.0f}); continue; }
                 for (long sl = 0; sl < filled; sl++) {
                     for (int sc = 0; sc < n_slices_; sc++) {
                         size_t at = ((size_t)sl * n_slices_ + sc) * kTimedKernels + k;
@@ -1176,7 +1180,8 @@ class HipBackend : public Backend {
         HIP_CK(hipMemcpy(out, d_dags_ + unit, sizeof(Dag), hipMemcpyDeviceToHost));
         return 0;
     }
-    void set_timing(bool on) override { timing_ = on; timed_runs_ = 0; }
+    void set_timing(bool on) override { timing_ = on; timing_mask_ = ~0u; timed_runs_ = 0; }
+    void set_timing_mask(uint32_t mask) override { timing_ = mask != 0; timing_mask_ = mask; timed_runs_ = 0; }
     const std::vector<KernelTime>& kernel_times() override { return times_; }
     int64_t order_bytes_written() const override { return last_needed_; }
     int slice_count() const override { return n_slices_; }

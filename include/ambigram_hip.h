@@ -190,6 +190,11 @@ int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t
  * automatic).  Enable with ambi_batch_set_timing(b, 1) before run. */
 int ambi_batch_slices(const ambi_batch_t* b);
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on);
+/* The same for a subset of the kernels: bit k of `mask` = kernel index k of ambi_batch_kernel_time (0 prepare, 1 plan,
+ * 2 image build, 3 enumerate, 4 scan, 5 finish); the others report -1.  Every pair of events is a marker in the
+ * stream, and twelve of them per run cost ~4 % on the bench workload -- a timed region that needs one kernel's duration
+ * asks for that kernel only. */
+int ambi_batch_set_timing_mask(ambi_batch_t* b, uint32_t mask);
 int ambi_batch_kernel_count(const ambi_batch_t* b);
 int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms);
 /* bytes: inputs resident in HBM, order-table bytes written by the last run, result blob bytes */
