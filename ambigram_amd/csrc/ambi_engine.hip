@@ -638,6 +638,7 @@ class HipBackend : public Backend {
     std::vector<Ev> evs_;
     int64_t last_needed_ = 0;
     int general_path_ = -1;   // units that take the general enumerate path: -1 unknown (first run), else the count (inputs are immutable)
+    int shared_units_ = -1;   // units whose table is written by several workgroups: -1 unknown, else the count
     long timed_runs_ = 0;
     // slices: contiguous unit ranges whose kernel chains run on different streams (see BatchArgs)
     static constexpr int kMaxSlices = 16;
@@ -708,7 +709,8 @@ class HipBackend : public Backend {
     int upload(const HostBatch& hb, const EngineConfig& cfg) override {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
-        if (uploaded_) { free_all(); uploaded_ = false; ran_ = false; general_path_ = -1; timed_runs_ = 0; }   // a second upload replaces the first
+        if (uploaded_) { free_all(); uploaded_ = false; ran_ = false; general_path_ = -1; timed_runs_ = 0; }
+        shared_units_ = -1;   // a second upload replaces the first
         hb_ = hb; cfg_ = cfg;
         const size_t U = hb.units.size();
         int rc;
@@ -1005,7 +1007,8 @@ class HipBackend : public Backend {
             if (A.n_units <= 0) continue;
             if (s > 0 && stagger_) (void)hipStreamWaitEvent(slice_stream(s), ev_stage_[s - 1], 0);
             launch_front(s, A);
-            launch_build(s, A);
+            if (!(build_in_emit_ && shared_units_ == 0)) launch_build(s, A);
+            else { tick("ambi_blocks_build_kernel", s, 2, true); tick("ambi_blocks_build_kernel", s, 2, false); }   // nothing to build
             if (s + 1 < n_slices_) (void)hipEventRecord(ev_stage_[s], slice_stream(s));
             launch_back(s, A);
         }
@@ -1078,6 +1081,14 @@ class HipBackend : public Backend {
             HIP_CK(hipMemcpy(fb.data(), d_fallback_, fb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
             general_path_ = 0;
             for (int32_t f : fb) general_path_ += f != 0;
+            // ... and whether any unit's table is shared by several workgroups (only those go through the build kernel
+            // when single-block units build their image in the enumerate workgroup): if none, later runs do not launch it
+            if (n_slices_ == 1) {
+                std::vector<int64_t> bo(hb_.units.size() + 1);
+                HIP_CK(hipMemcpy(bo.data(), d_blk_off_, bo.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+                shared_units_ = 0;
+                for (size_t u2 = 0; u2 + 1 < bo.size(); u2++) shared_units_ += (bo[u2 + 1] - bo[u2] > 1) ? 1 : 0;
+            }
         }
         for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s];
         if (*h_npending_ > 0) {
@@ -1110,6 +1121,7 @@ class HipBackend : public Backend {
                 }
                 times_.push_back({nm, cnt ? (float)(sum / cnt) : -1.0f});
             }
+            (void)hipGetLastError();   // an event pair that was never recorded reports an error above: not one of ours
         }
         return 0;
     }
