@@ -633,6 +633,7 @@ class HipBackend : public Backend {
     bool finish_wave_ = false;  // one wavefront per unit (env AMBI_FINISH_WAVE)
     int32_t* d_blocks_done_ = nullptr;
     uint32_t* d_anblk_ = nullptr; uint8_t* d_adepth_ = nullptr;
+    int finish_path_cells_ = 0;
     std::vector<KernelTime> times_;
     struct Ev { const char* name; hipEvent_t a, b; };
     std::vector<Ev> evs_;
@@ -759,7 +760,12 @@ class HipBackend : public Backend {
         // LDS budgets (dynamic shared memory), sized for the largest unit of the batch
         lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
         lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
-        lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, hb.max_path, hb.max_out);
+        // the full finish stage keeps the path cells in LDS: as many as fit beside its other arrays (longer paths are
+        // served by the lean stage alone)
+        finish_path_cells_ = hb.max_path < kPathLdsCells ? hb.max_path : kPathLdsCells;
+        while (finish_path_cells_ > 4096 && finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, finish_path_cells_, hb.max_out) > 160 * 1024 - 1024)
+            finish_path_cells_ -= 2048;
+        lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, finish_path_cells_, hb.max_out);
         lds_finish_lean_ = (int)finish_lean_work_bytes(hb.max_n, hb.max_m, hb.max_bkp);
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
@@ -852,7 +858,7 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
-        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.block_dfs = block_dfs_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
+        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;

@@ -9,7 +9,8 @@
 
 namespace ambi {
 
-constexpr int kPathCapLimit = 65536;   // cells; the finish kernel keeps the path in LDS as int16
+constexpr int kPathCapLimit = 1 << 22;   // cells per unit in the result blob (the lean finish stage streams them; only the full stage,
+                                         // which edits the path in LDS, is limited to kPathLdsCells)
 constexpr int kDefaultIdealCap = 4096; // slots per unit (holds up to 2048 order ideals)
 
 struct HostBatch {

@@ -488,6 +488,14 @@ struct FinishWork {
 };
 // (the deque of the general indelBFB path, 2m+4 ints, lives in the unit's HBM scratch: it is touched only when SVs chain)
 AMBI_HD int finish_cand_cap(int bkp_cap, int out_cap) { return out_cap + 2 * bkp_cap + 32; }
+// the full finish stage holds the path cells in group memory: at most kPathLdsCells of them (longer paths are served by
+// the lean stage only; if their SVs chain or edit the path the unit ends with ST_ERR_PATH_CAPACITY)
+constexpr int kPathLdsCells = 65536;
+AMBI_HD int lds_path_cap(const BatchArgs& A, int path_cap) {
+    const int lim = A.finish_path_cells > 0 && A.finish_path_cells < kPathLdsCells ? A.finish_path_cells : kPathLdsCells;
+    return path_cap < lim ? path_cap : lim;
+}
+// path_cap: already limited by lds_path_cap
 AMBI_HD int64_t finish_work_bytes(int n, int m, int bkp_cap, int path_cap, int out_cap) {
     return pad8(2ll * path_cap + 16) + pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(JuncEnds)) * m) +
            pad8(4ll * m) + pad8(4ll * finish_cand_cap(bkp_cap, out_cap)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
@@ -537,7 +545,8 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
         return;
     }
     if (status != ST_OK) return;
-    FinishWork W = carve_finish(work, n, m, U.bkp_cap, U.path_cap, U.out_cap);
+    const int pcap = lds_path_cap(A, U.path_cap);
+    FinishWork W = carve_finish(work, n, m, U.bkp_cap, pcap, U.out_cap);
     const int L = out->bkp_len;
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
@@ -547,13 +556,13 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     }
     g.sync();
     AMBI_MARK(A, g, u, 17);
-    int P = expand_bkp(g, W.bkp, L, W.path, U.path_cap, W.offs, gpath, base);
+    int P = expand_bkp(g, W.bkp, L, W.path, pcap, W.offs, gpath, base);
     if (P < 0) { if (g.tid() == 0) out->status = P; g.sync(); return; }
     int P2 = P;
     AMBI_MARK(A, g, u, 18);
     IndelScratch S{W.sv, W.taken, W.has_ext, A.scratch_i32 + A.scratch_off[u], W.first, W.last};
     bool edited = false;
-    int printed = indel_bfb(g, n, W.ends, m, W.path, &P2, U.path_cap, S, &edited);
+    int printed = indel_bfb(g, n, W.ends, m, W.path, &P2, pcap, S, &edited);
     if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
     AMBI_MARK(A, g, u, 19);
     // the edited path is materialised only when indelBFB changed something; otherwise readers take `path`

@@ -336,3 +336,41 @@ def check_mixed_batch(lib, oracle, workdir, big=False):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def check_max_sizes(lib, oracle, workdir):
+    """The engine's documented limits (DESIGN.md section 8): 63 DAG nodes per unit work, 64 are refused when the unit is added;
+    a path longer than the 65 536 cells the full finish stage holds in group memory is served by the lean stage (runs
+    only) -- unless its SVs edit the path, which is ST_ERR_PATH_CAPACITY."""
+    import pytest
+    from ambigram_amd import synth
+    for tier, K in (("chain", 63), ("skew", 63)):
+        s = synth.make_sample(512, 1024, tier, K, seed=4242)
+        lh, sols = s.write(workdir, "max_%s%d" % (tier, K))
+        o = oracle.run_bfb(lh, sols)["chr"][0]
+        assert len(o["path"]) > 65536                       # really beyond the group-memory limit
+        g = api.Graph(lib, lh)
+        b = api.Batch(lib)
+        b.add_chromosome_sol(g, 0, sols[0])
+        b.upload(); b.run(0); b.download()
+        r = b.unit_result(0)
+        assert r["status"] == 0 and r["n_nodes"] == K and r["num_orders"] == o["num_orders"], r
+        assert b.unit_path(0, 0).tolist() == o["path"] and b.unit_path(0, 1).tolist() == o["path_indel"]
+        b.close(); g.close()
+    s = synth.make_sample(512, 1024, "chain", 64, seed=4242)
+    lh, sols = s.write(workdir, "max_chain64")
+    g = api.Graph(lib, lh)
+    with pytest.raises(api.AmbiError) as e:
+        api.Batch(lib).add_chromosome_sol(g, 0, sols[0])
+    assert e.value.code == -10
+    g.close()
+    s = synth.make_sample(512, 1024, "chain", 63, seed=4242, n_del=2)      # long path AND an SV that edits it
+    lh, sols = s.write(workdir, "max_chain63_del")
+    o = oracle.run_bfb(lh, sols)["chr"][0]
+    assert len(o["path"]) > 65536 and o["path_indel"] != o["path"]
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sols[0])
+    b.upload(); b.run(0); b.download()
+    assert b.unit_result(0)["status"] == -14
+    b.close(); g.close()

@@ -204,7 +204,7 @@ class HostSimBackend : public Backend {
         for (int u = 0; u < Un; u++) {
             const UnitIn& U = units_[u];
             if (lean && unit_out(A_.results, u)->status != ST_REFINISH) continue;
-            std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, U.path_cap, U.out_cap));
+            std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, lds_path_cap(A_, U.path_cap), U.out_cap));
             stage_finish(g, A_, u, work.data());
         }
         if (flags & FLAG_ALL) compute_all();

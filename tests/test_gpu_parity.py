@@ -239,3 +239,7 @@ def test_run_length_exchange_payload(hip_lib, oracle, workdir):
     b.close()
     for g in graphs:
         g.close()
+
+
+def test_max_sizes(hip_lib, oracle, workdir):
+    ec.check_max_sizes(hip_lib, oracle, workdir)

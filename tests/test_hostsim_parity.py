@@ -56,3 +56,7 @@ def test_full_finish_stage_on_every_unit(hostsim_lib, oracle, workdir, monkeypat
     ec.check_fixed_and_synthetic(hostsim_lib, oracle, workdir, small_only=True)
     ec.check_random_decompositions(hostsim_lib, oracle, workdir, range(200, 230), budget=2)
     ec.check_mixed_batch(hostsim_lib, oracle, workdir)
+
+
+def test_max_sizes(hostsim_lib, oracle, workdir):
+    ec.check_max_sizes(hostsim_lib, oracle, workdir)
