@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --steps 10 --warmup 3"   # batch leg only: the single-sample leg would mix 1-unit launches into the per-kernel means
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --steps 10 --warmup 3"   # batch leg only: the single-sample and two-batch legs would mix other launches into the per-kernel means
 
 pass() {   # name, rocprofv3 flags ...
     local name=$1; shift
