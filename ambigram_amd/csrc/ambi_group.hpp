@@ -46,6 +46,8 @@ struct HostGroup {
     AMBI_HD bool any(bool p) const { return p; }
     AMBI_HD int bcast_i32(int v, int /*src*/) const { return v; }
     AMBI_HD uint64_t bcast_u64(uint64_t v, int /*src*/) const { return v; }   // src must be uniform over the group
+    AMBI_HD int bcast_i32_u(int v, int /*src*/) const { return v; }
+    AMBI_HD uint64_t ballot_u64(bool q) const { return q ? 1ull : 0ull; }
     // exclusive prefix sum over the group in thread order; total returned through *total
     AMBI_HD int exscan_i32(int v, int* total) const { *total = v; return 0; }
     // sub-groups: runs of up to 64 consecutive threads (a wavefront on the GPU) that can rank flags without a barrier
@@ -112,6 +114,8 @@ struct WaveGroup {
     __device__ inline int sum_i32(int v) const { return __builtin_amdgcn_readlane(incl_scan_i32(v), 63); }
     __device__ inline bool any(bool p) const { return __ballot(p) != 0ull; }
     __device__ inline int bcast_i32(int v, int src) const { return __shfl(v, src, 64); }
+    __device__ inline int bcast_i32_u(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }   // src uniform over the wave
+    __device__ inline uint64_t ballot_u64(bool q) const { return __ballot(q); }
     __device__ inline uint64_t bcast_u64(uint64_t v, int src) const {   // uniform src: two v_readlane, no LDS crossbar
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);

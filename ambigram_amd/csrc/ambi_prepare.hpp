@@ -262,8 +262,10 @@ AMBI_HD int dec_str_cmp(uint32_t x, uint32_t y) {   // <0, 0, >0
 AMBI_HD uint64_t dec_key(uint32_t x) {
     const int d = 1 + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) +
                   (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
-    uint64_t v = x;
-    for (int i = d; i < 10; i++) v *= 10;
+    // x * 10^(10-d) without a loop of 64-bit multiplies: the power by a chain of selects, one multiply
+    const uint32_t p32 = d >= 10 ? 1u : d == 9 ? 10u : d == 8 ? 100u : d == 7 ? 1000u : d == 6 ? 10000u : d == 5 ? 100000u :
+                         d == 4 ? 1000000u : d == 3 ? 10000000u : d == 2 ? 100000000u : 1000000000u;
+    const uint64_t v = (uint64_t)x * (uint64_t)p32;
     return (v << 4) | (uint64_t)d;
 }
 // std::string operator< on the two keys (A,B are ABSOLUTE segment ids)
@@ -372,6 +374,31 @@ AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, 
     // owns column j (pred[j]: every edge into j, written by nobody else in this loop), "succ[parent] has j" is the
     // same fact as "pred[j] has parent", and pred[i] is handed round by its owner.  Per step: l -> p over all j with
     // the state before the step, then l -> l (static test), exactly the reference's two inner loops.
+    if constexpr (G::kLaneArrays) {
+        // wavefront form (K <= 63 < 64 lanes): node j lives in lane j's registers for the whole loop -- its two records,
+        // its column pred[j] -- and loop i's record and pred[i] come from lane i through v_readlane; the edges of step i
+        // are one ballot.  No memory access inside the loop.
+        const int j = g.tid();
+        const bool in = j < K;
+        uint64_t mine = in ? D.pred[j] : 0ull, row = 0;
+        const int pa = in ? D.pat[j][0] : 0, pb = in ? D.pat[j][1] : 0, qa = in ? D.loop[j][0] : 0, qb = in ? D.loop[j][1] : 0;
+        for (int i = 0; i < K; i++) {
+            const int la = g.bcast_i32_u(qa, i), lb = g.bcast_i32_u(qb, i);
+            if (la == 0) continue;
+            const int d1 = iabs(la - lb);
+            const uint64_t pred_i = g.bcast_u64(mine, i);
+            bool edge = false;
+            if (!((pred_i >> j) & 1ull) && pa != 0 && (la == pa || lb == pb)) edge = d1 > iabs(pa - pb) || (pred_i & mine) != 0;
+            if (qa != 0 && (la == qa || lb == qb) && d1 > iabs(qa - qb)) edge = true;
+            edge = edge && in;
+            if (edge) mine |= 1ull << i;
+            const uint64_t col = g.ballot_u64(edge);
+            if (j == i) row = col;
+        }
+        if (in) { D.pred[j] = mine; D.succ[j] |= row; }
+        g.sync();
+        return ST_OK;
+    }
     for (int i = 0; i < K; i++) {
         const int la = D.loop[i][0], lb = D.loop[i][1];
         if (la == 0) continue;

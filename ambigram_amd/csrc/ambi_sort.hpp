@@ -34,10 +34,19 @@ AMBI_HD bool compare_loops(const Rec3& x, const Rec3& y) {
 AMBI_HD uint32_t loop_sort_key(int a, int b, int pos) { return ((a != 0 ? (uint32_t)iabs(a - b) + 1u : 0u) << 8) | (uint32_t)pos; }
 AMBI_HD bool compare_keys(uint32_t x, uint32_t y) { return (y >> 8) != 0u && (x >> 8) > (y >> 8); }
 
+// Besides get / set the array types answer the three linear scans of the library's inner loops and do its block move
+// -- element by element in memory, with one ballot / one lane shift in the register form; the permutation after each
+// library operation is the same either way:
+//   first_not_before(from, n, pk)  smallest i in [from, n) with !comp(a[i], pk), else n   (__unguarded_partition, left scan)
+//   last_not_after(from, x)        largest  i in [0, from] with !comp(x, a[i]), else -1   (right scan; __unguarded_linear_insert)
+//   shift_up(lo, hi)               a[k + 1] = a[k] for k = hi-1 .. lo                     (move_backward / the insert's moves)
 struct MemWords {
     uint32_t* a;
     AMBI_HD uint32_t get(int i) const { return a[i]; }
     AMBI_HD void set(int i, uint32_t x) { a[i] = x; }
+    AMBI_HD int first_not_before(int from, int n, uint32_t pk) const { int i = from; while (i < n && compare_keys(a[i], pk)) i++; return i; }
+    AMBI_HD int last_not_after(int from, uint32_t x) const { int i = from; while (i >= 0 && compare_keys(x, a[i])) i--; return i; }
+    AMBI_HD void shift_up(int lo, int hi) { for (int k = hi; k > lo; --k) a[k] = a[k - 1]; }
 };
 struct LaneWords {   // all 64 lanes call get/set together with the same (uniform) arguments; device code only
     uint32_t v;
@@ -45,9 +54,24 @@ struct LaneWords {   // all 64 lanes call get/set together with the same (unifor
 #if defined(__HIP_DEVICE_COMPILE__)
     __device__ inline uint32_t get(int i) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
     __device__ inline void set(int i, uint32_t x) { v = (lane == i) ? x : v; }   // v_cmp + v_cndmask on scalar operands
+    __device__ inline int first_not_before(int from, int n, uint32_t pk) const {
+        const unsigned long long m = __ballot(lane >= from && lane < n && !compare_keys(v, pk));
+        return m ? (int)__builtin_ctzll(m) : n;
+    }
+    __device__ inline int last_not_after(int from, uint32_t x) const {
+        const unsigned long long m = __ballot(lane <= from && !compare_keys(x, v));
+        return m ? 63 - (int)__builtin_clzll(m) : -1;
+    }
+    __device__ inline void shift_up(int lo, int hi) {
+        const uint32_t below = (uint32_t)__shfl_up((int)v, 1, 64);   // lane k-1's element
+        v = (lane > lo && lane <= hi) ? below : v;
+    }
 #else
     AMBI_HD uint32_t get(int) const { return v; }
     AMBI_HD void set(int, uint32_t x) { v = x; }
+    AMBI_HD int first_not_before(int, int n, uint32_t) const { return n; }
+    AMBI_HD int last_not_after(int, uint32_t) const { return -1; }
+    AMBI_HD void shift_up(int, int) {}
 #endif
 };
 
@@ -63,17 +87,13 @@ namespace sortdetail {
 template <class C> AMBI_HD void swp(C& c, int i, int j) { const uint32_t t = c.a.get(i); c.a.set(i, c.a.get(j)); c.a.set(j, t); }
 
 template <class C> AMBI_HD void unguarded_linear_insert(C& c, int last) {
+    // the library moves a[next] up while comp(val, a[next]) and stops at the first element (from the right) for which
+    // the comparison fails -- or runs off the front (the "unguarded" read out of bounds)
     const uint32_t val = c.a.get(last);
-    int next = last - 1;
-    while (true) {
-        if (next < 0) { c.ub = true; break; }
-        const uint32_t nx = c.a.get(next);
-        if (!compare_keys(val, nx)) break;
-        c.a.set(last, nx);
-        last = next;
-        --next;
-    }
-    c.a.set(last, val);
+    const int stop = c.a.last_not_after(last - 1, val);
+    if (stop < 0) c.ub = true;
+    c.a.shift_up(stop + 1, last);
+    c.a.set(stop + 1, val);
 }
 
 template <class C> AMBI_HD void insertion_sort(C& c, int first, int last) {
@@ -81,7 +101,7 @@ template <class C> AMBI_HD void insertion_sort(C& c, int first, int last) {
     for (int i = first + 1; i != last; ++i) {
         if (compare_keys(c.a.get(i), c.a.get(first))) {
             const uint32_t val = c.a.get(i);
-            for (int k = i; k > first; --k) c.a.set(k, c.a.get(k - 1));   // move_backward(first, i, i+1)
+            c.a.shift_up(first, i);                                       // move_backward(first, i, i+1)
             c.a.set(first, val);
         } else {
             unguarded_linear_insert(c, i);
@@ -150,18 +170,12 @@ template <class C> AMBI_HD void move_median_to_first(C& c, int result, int a, in
 }
 
 template <class C> AMBI_HD int unguarded_partition(C& c, int first, int last, int pivot) {
+    const uint32_t pk = c.a.get(pivot);      // the pivot sits in front of the range and is not moved by the swaps below
     while (true) {
-        while (true) {
-            if (first >= c.n) { c.ub = true; return first; }
-            if (!compare_keys(c.a.get(first), c.a.get(pivot))) break;
-            ++first;
-        }
-        --last;
-        while (true) {
-            if (last < 0) { c.ub = true; return first; }
-            if (!compare_keys(c.a.get(pivot), c.a.get(last))) break;
-            --last;
-        }
+        first = c.a.first_not_before(first, c.n, pk);
+        if (first >= c.n) { c.ub = true; return first; }
+        last = c.a.last_not_after(last - 1, pk);
+        if (last < 0) { c.ub = true; return first; }
         if (!(first < last)) return first;
         swp(c, first, last);
         ++first;
