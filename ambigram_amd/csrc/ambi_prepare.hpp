@@ -42,6 +42,14 @@ AMBI_HD double junc_cn_round(double cn) { return (0.5 < cn && cn < 1) ? 1.0 : cn
 // LGM.cpp:3989-4050 getJuncCN.  junc_cn is (n+1) x 2 (row 0 unused), inv_junc[n+1] = junction index or -1.
 // slot_cnt: [n+1] ints, fb: [m] 16-bit junction indices (fold-back junction list; m <= 65535 per unit).  Junction ends come from group memory, the copy
 // numbers from the records in HBM (each is read once, by the thread that owns the junction / the slot).
+AMBI_HD void atomic_min_slot(int32_t* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+
 template <class G>
 AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* junc_cn, int32_t* inv_junc,
                            int32_t* slot_cnt, uint16_t* fb) {
@@ -75,12 +83,29 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
     for (int i = g.tid(); i <= n; i += g.size()) multi |= (slot_cnt[i] > 1);
     const bool serial_normal = g.any(multi != 0);
     if (!serial_normal) {
-        for (int ji = g.tid(); ji < m; ji += g.size()) {
-            const JuncEnds E = J.e[ji];
-            const int s = iabs(E.s), t = iabs(E.t);
-            if (s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0)) continue;
-            if (s + 1 == t) junc_cn[2 * s] = 0.0 + junc_cn_round(J.full[ji].cn);
-            else if (s - 1 == t) junc_cn[2 * t] = 0.0 + junc_cn_round(J.full[ji].cn);
+        // four junctions per thread and round: the copy numbers come from the records in HBM (L2 by now), so the four
+        // loads are issued together instead of one round trip per junction
+        for (int base = 0; base < m; base += 4 * g.size()) {
+            int slot[4];
+            double cn[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ji = base + q * g.size() + g.tid();
+                slot[q] = -1;
+                cn[q] = 0.0;
+                if (ji < m) {
+                    const JuncEnds E = J.e[ji];
+                    const int s = iabs(E.s), t = iabs(E.t);
+                    if (!(s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0))) {
+                        if (s + 1 == t) slot[q] = s;
+                        else if (s - 1 == t) slot[q] = t;
+                    }
+                    if (slot[q] >= 0) cn[q] = J.full[ji].cn;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (slot[q] >= 0) junc_cn[2 * slot[q]] = 0.0 + junc_cn_round(cn[q]);
         }
     } else if (g.tid() == 0) {
         for (int ji = 0; ji < m; ji++) {
@@ -93,7 +118,24 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
     }
     // fold-back claims are first come first served (LGM.cpp:4012-4041): serial over the compacted list.  A slot is
     // claimed at most once, so its copy number is 0 + cn of the claiming junction: assigned in parallel afterwards.
-    if (g.tid() == 0) {
+    bool claimed = false;
+    if constexpr (G::kLaneArrays) {
+        if (nfb <= g.size()) {
+            // wavefront form: fold-back k's two ends sit in lane k; the serial walk is a scalar program reading them with
+            // v_readlane (one LDS round trip per step, for the slot itself, instead of three dependent ones)
+            const int k0 = g.tid();
+            int ms = 0, mt = 0, mj = 0;
+            if (k0 < nfb) { mj = fb[k0]; const JuncEnds E = J.e[mj]; ms = iabs(E.s); mt = iabs(E.t); }
+            for (int k = 0; k < nfb; k++) {
+                const int s = g.bcast_i32_u(ms, k), t = g.bcast_i32_u(mt, k), jj = g.bcast_i32_u(mj, k);
+                if (inv_junc[s] < 0) { if (g.tid() == 0) inv_junc[s] = jj; }
+                else if (inv_junc[t] < 0) { if (g.tid() == 0) inv_junc[t] = jj; }
+                g.sync();
+            }
+            claimed = true;
+        }
+    }
+    if (!claimed && g.tid() == 0) {
         for (int k = 0; k < nfb; k++) {
             const JuncEnds E = J.e[fb[k]];
             const int s = iabs(E.s), t = iabs(E.t);
@@ -107,14 +149,20 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
         if (ji >= 0) junc_cn[2 * i + 1] = 0.0 + junc_cn_round(J.full[ji].cn);
     }
     g.sync();
-    if (g.tid() == 0) {   // LGM.cpp:4043-4049: remaining ends point at their junction, no copy number
-        for (int k = 0; k < nfb; k++) {
-            const JuncEnds E = J.e[fb[k]];
-            const int s = iabs(E.s), t = iabs(E.t);
-            if (inv_junc[s] < 0) inv_junc[s] = fb[k];
-            if (inv_junc[t] < 0) inv_junc[t] = fb[k];
-        }
+    // LGM.cpp:4043-4049: remaining ends point at their junction, no copy number.  Serial in the reference, but here the
+    // first fold-back (in list order) that touches a still-free end simply gets it -- a minimum over the list positions per
+    // end (the slot counters are free by now and hold the claimant's position)
+    for (int i = g.tid(); i <= n; i += g.size()) slot_cnt[i] = 0x7fffffff;
+    g.sync();
+    for (int k = g.tid(); k < nfb; k += g.size()) {
+        const JuncEnds E = J.e[fb[k]];
+        const int s = iabs(E.s), t = iabs(E.t);
+        if (inv_junc[s] < 0) atomic_min_slot(&slot_cnt[s], k);
+        if (inv_junc[t] < 0) atomic_min_slot(&slot_cnt[t], k);
     }
+    g.sync();
+    for (int i = g.tid(); i <= n; i += g.size())
+        if (inv_junc[i] < 0 && slot_cnt[i] != 0x7fffffff) inv_junc[i] = fb[slot_cnt[i]];
     g.sync();
 }
 
@@ -295,6 +343,21 @@ AMBI_HD int construct_dag_g(const G& g, const Element* el, int K, int seg_base, 
         D.pred[i] = dec_key((uint32_t)(el[i].b + seg_base));
     }
     g.sync();
+    if constexpr (G::kLaneArrays) {
+        // wavefront form: element i's keys stay in lane i's registers, element j's arrive by v_readlane
+        const int i = g.tid();
+        const bool in = i < K;
+        const int li = in ? el[i].is_loop : 0;
+        const uint64_t ka = in ? D.succ[i] : 0ull, kb = in ? D.pred[i] : 0ull;
+        int r = 0;
+        for (int j = 0; j < K; j++) {
+            const int lj = g.bcast_i32_u(li, j);
+            const uint64_t ja = g.bcast_u64(ka, j), jb = g.bcast_u64(kb, j);
+            const bool less = (lj != li) ? (lj > li) : ((ja != ka) ? (ja < ka) : (jb < kb));   // key_less(j, i)
+            r += (j != i && less) ? 1 : 0;
+        }
+        if (in) W.idx[r] = i;
+    } else
     for (int i = g.tid(); i < K; i += g.size()) {
         const int li = el[i].is_loop;
         const uint64_t ka = D.succ[i], kb = D.pred[i];
