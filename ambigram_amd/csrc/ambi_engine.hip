@@ -1147,7 +1147,7 @@ class HipBackend : public Backend {
         // marks 0-8 and 22-31: prepare (22-24 inside constructDAG, 26-28 inside the lattice); 9-12: scan; 16-21: finish
         fprintf(stderr, "ambigram_hip stage profile (mean cycles from the first mark of the stage, %zu units):", U);
         for (int s = 1; s < kStageSlots; s++) {
-            const int base = ((s >= 13 && s <= 15) || s == 29 || s == 30) ? 31 : ((s <= 8 || s >= 22) ? 0 : (s <= 12 ? 9 : 16));   // 13-15, 29, 30: image build (from 31)
+            const int base = ((s >= 13 && s <= 15) || s == 29 || s == 30) ? 31 : (s == 25 ? 9 : ((s <= 8 || s >= 22) ? 0 : (s <= 12 ? 9 : 16)));   // 13-15, 29, 30: image build (from 31)
             if (s == base) continue;
             double sum = 0; size_t cnt = 0;
             for (size_t u = 0; u < U; u++) {

@@ -65,65 +65,73 @@ AMBI_HD void shift_down(const G& g, T* a, int L, int at, int count) {
 }
 
 // LGM.cpp:3431-3512.  Returns false when the reference would have read out of bounds.
+// The walk over pos is the reference's; inside a step nothing is left to one thread: the cells a step looks at are read
+// by every thread (same addresses), the first later occurrence of -bkp[pos] is one flag rank per chunk of cells, the
+// plain step's rewrite is computed by all and stored by one, and the rewrite of a palindrome -- in the reference a loop
+// from the middle outwards -- runs one iteration per thread: iteration t touches the four cells p1, p1+1, p2-1, p2 with
+// p1 = mid - 2t, p2 = mid + 1 + 2t, reads only bkp[p1], and no two iterations share a cell (parities), so they commute.
 template <class G>
 AMBI_HD bool imperfect_fbi(const G& g, cell_t* bkp, int L, const InvMap& inv) {
     int pos = 0;
     while (pos < L) {
         if (pos + 1 >= L) return false;
+        const int c0 = bkp[pos], c1 = bkp[pos + 1];
         int r = L;
         if (pos + 3 < L) {
-            int want = -bkp[pos];
-            int best = 0x7fffffff;
-            for (int q = pos + 3 + g.tid(); q < L; q += g.size())
-                if (bkp[q] == want) { best = q; break; }
-            best = g.min_i32(best);
-            if (best != 0x7fffffff) r = best;
+            const int want = -c0;
+            for (int base = pos + 3; base < L; base += g.size()) {
+                const int q = base + g.tid();
+                const int hit = g.first_flag(q < L && bkp[q] == want);
+                if (hit >= 0) { r = base + hit; break; }
+            }
         }
-        int l = r - 1;
-        bool plain = (r == L) || (bkp[l] != -bkp[pos + 1]);
+        const int l = r - 1;
+        const bool plain = (r == L) || (bkp[l] != -c1);
         g.sync();
         if (plain) {
-            if (g.tid() == 0) {
-                int id = iabs(bkp[pos + 1]);
-                if (inv.src[id] != 0) {
-                    int s = inv.src[id], t = inv.tgt[id];
-                    if (bkp[pos + 1] > 0) bkp[pos + 1] = (cell_t)((s < t) ? s : t);
-                    else bkp[pos + 1] = (cell_t)((s < t) ? -t : -s);
+            int n0 = c0, n1 = c1;
+            {
+                const int id = iabs(c1);
+                const int s = inv.src[id];
+                if (s != 0) {
+                    const int t = inv.tgt[id];
+                    n1 = c1 > 0 ? ((s < t) ? s : t) : ((s < t) ? -t : -s);
                 }
-                if (pos > 0) {
-                    id = iabs(bkp[pos]);
-                    if (inv.src[id] != 0 && iabs(bkp[pos - 1]) == id) {
-                        int other = (inv.src[id] == id) ? inv.tgt[id] : inv.src[id];
-                        bkp[pos] = (cell_t)(bkp[pos] > 0 ? other : -other);
-                    }
-                }
-                if (bkp[pos] > 0 && iabs(bkp[pos]) > iabs(bkp[pos + 1])) bkp[pos + 1] = bkp[pos];
-                if (bkp[pos] < 0 && iabs(bkp[pos]) < iabs(bkp[pos + 1])) bkp[pos + 1] = bkp[pos];
             }
+            if (pos > 0) {
+                const int id = iabs(c0);
+                const int s = inv.src[id];
+                if (s != 0 && iabs(bkp[pos - 1]) == id) {
+                    const int other = (s == id) ? inv.tgt[id] : s;
+                    n0 = c0 > 0 ? other : -other;
+                }
+            }
+            if (n0 > 0 && iabs(n0) > iabs(n1)) n1 = n0;
+            if (n0 < 0 && iabs(n0) < iabs(n1)) n1 = n0;
+            if (g.tid() == 0) { bkp[pos] = (cell_t)n0; bkp[pos + 1] = (cell_t)n1; }
             g.sync();
             pos += 2;
         } else {
+            const int mid = pos + ((l - pos) / 2);
             int bad = 0;
-            if (g.tid() == 0) {
-                int p1 = pos + ((l - pos) / 2), p2 = p1 + 1;
-                while (p1 >= pos - 1 && p1 > 0) {
-                    int id = iabs(bkp[p1]);
-                    if (inv.src[id] != 0) {
-                        int s = inv.src[id], t = inv.tgt[id];
-                        if (p1 + 1 >= L) { bad = 1; break; }
-                        if (bkp[p1] > 0) {
-                            if (s < t) { bkp[p1] = (cell_t)s; bkp[p1 + 1] = (cell_t)-t; }
-                            else { bkp[p1] = (cell_t)t; bkp[p1 + 1] = (cell_t)-s; }
-                        } else {
-                            if (s < t) { bkp[p1] = (cell_t)-t; bkp[p1 + 1] = (cell_t)s; }
-                            else { bkp[p1] = (cell_t)-s; bkp[p1 + 1] = (cell_t)t; }
-                        }
-                        if (p2 != p1 + 1) {
-                            if (p1 > pos - 1) { if (p2 >= L) { bad = 1; break; } bkp[p2] = (cell_t)-bkp[p1]; }
-                            bkp[p2 - 1] = (cell_t)-bkp[p1 + 1];
-                        }
+            // iterations t = 0, 1, ..: p1 = mid - 2t while p1 >= pos - 1 and p1 > 0
+            for (int t = g.tid();; t += g.size()) {
+                const int p1 = mid - 2 * t, p2 = mid + 1 + 2 * t;
+                if (!(p1 >= pos - 1 && p1 > 0)) break;
+                const int v = bkp[p1];
+                const int id = iabs(v);
+                const int s = inv.src[id];
+                if (s != 0) {
+                    const int tt = inv.tgt[id];
+                    if (p1 + 1 >= L) { bad = 1; break; }
+                    int w0, w1;
+                    if (v > 0) { if (s < tt) { w0 = s; w1 = -tt; } else { w0 = tt; w1 = -s; } }
+                    else { if (s < tt) { w0 = -tt; w1 = s; } else { w0 = -s; w1 = tt; } }
+                    bkp[p1] = (cell_t)w0; bkp[p1 + 1] = (cell_t)w1;
+                    if (p2 != p1 + 1) {
+                        if (p1 > pos - 1) { if (p2 >= L) { bad = 1; break; } bkp[p2] = (cell_t)-w0; }
+                        bkp[p2 - 1] = (cell_t)-w1;
                     }
-                    p1 -= 2; p2 += 2;
                 }
             }
             g.sync();
@@ -137,7 +145,7 @@ AMBI_HD bool imperfect_fbi(const G& g, cell_t* bkp, int L, const InvMap& inv) {
 // Evaluate one order.  Returns 1 valid / 0 invalid / negative Status on error.  *L_out = bkp length.
 template <class G>
 AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forward, const InvMap& inv,
-                       cell_t* bkp, int cap, int* L_out) {
+                       cell_t* bkp, int cap, int* L_out, int64_t* clk = nullptr) {
     const int K = D.K;
     int L = 0;
     int x = ord[0];
@@ -171,10 +179,24 @@ AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forwar
             g.sync();
         } else if (D.loop[x][0] != 0) {   // LGM.cpp:3586-3644
             int s = D.loop[x][0], e = D.loop[x][1], cn = D.loop[x][2];
-            bool viaV1 = true;
-            int f = find_last_slot(g, bkp, L, -s, true);
-            if (f < 0) { f = find_last_slot(g, bkp, L, e, false); viaV1 = false; }
-            if (f < 0) break;
+            // LGM.cpp:3591-3602: the last slot holding -s (nesting test "<"), else the last slot holding e (">"): both
+            // searches in one sweep and one reduction (a -s hit outranks every e hit)
+            int best = -1;
+            for (int q = g.tid(); q < L; q += g.size()) {
+                if (!(q & 1)) continue;
+                const int c = bkp[q];
+                if (c != -s && c != e) continue;
+                bool skip = false;
+                if (q < L - 2) {
+                    const int x = iabs(bkp[q - 1]), y = iabs(bkp[q + 2]);
+                    skip = (c == -s) ? (x < y) : (x > y);
+                }
+                if (!skip) { const int enc = (c == -s) ? 0x10000 + q : q; if (enc > best) best = enc; }
+            }
+            best = g.max_i32(best);
+            if (best < 0) break;
+            const bool viaV1 = best >= 0x10000;
+            const int f = viaV1 ? best - 0x10000 : best;
             int cnt = 4 * cn;
             if (L + cnt > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
             bool hasNext = (f + 1 != L);
@@ -195,6 +217,7 @@ AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forwar
         }
         // both slots empty (possible after the library sort for K > 16): nothing is placed, the loop goes on
     }
+    clk_mark(g, clk, 25);
     bool ok = imperfect_fbi(g, bkp, L, inv);   // LGM.cpp:3656, before the validity test
     *L_out = L;
     if (!ok) return ST_ERR_REF_UB;

@@ -48,6 +48,7 @@ struct HostGroup {
     AMBI_HD uint64_t bcast_u64(uint64_t v, int /*src*/) const { return v; }   // src must be uniform over the group
     AMBI_HD int bcast_i32_u(int v, int /*src*/) const { return v; }
     AMBI_HD uint64_t ballot_u64(bool q) const { return q ? 1ull : 0ull; }
+    AMBI_HD int first_flag(bool q) const { return q ? 0 : -1; }   // lowest thread with the flag set, -1 if none
     // exclusive prefix sum over the group in thread order; total returned through *total
     AMBI_HD int exscan_i32(int v, int* total) const { *total = v; return 0; }
     // sub-groups: runs of up to 64 consecutive threads (a wavefront on the GPU) that can rank flags without a barrier
@@ -116,6 +117,7 @@ struct WaveGroup {
     __device__ inline int bcast_i32(int v, int src) const { return __shfl(v, src, 64); }
     __device__ inline int bcast_i32_u(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }   // src uniform over the wave
     __device__ inline uint64_t ballot_u64(bool q) const { return __ballot(q); }
+    __device__ inline int first_flag(bool q) const { const unsigned long long b = __ballot(q); return b ? (int)__builtin_ctzll(b) : -1; }
     __device__ inline uint64_t bcast_u64(uint64_t v, int src) const {   // uniform src: two v_readlane, no LDS crossbar
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
@@ -189,6 +191,7 @@ struct BlockGroup {
     __device__ inline int sub_lane() const { return (int)(threadIdx.x & 63u); }
     __device__ inline int flag_rank(bool q, int* count) const { WaveGroup w; return w.flag_rank(q, count); }
     __device__ inline int flag_exscan(bool q, int* count) const { return exscan_i32(q ? 1 : 0, count); }
+    __device__ inline int first_flag(bool q) const { const int m = min_i32(q ? (int)threadIdx.x : 0x7fffffff); return m == 0x7fffffff ? -1 : m; }
 };
 
 #endif  // __HIPCC__

@@ -429,7 +429,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
             for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * rstride + d];
             g.sync();
             int Lo = 0;
-            int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo);
+            int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo, A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
             evaluated++;
             if (v < 0) { status = v; found = -2; break; }
             if (v == 1) { found = nidx; found_fwd = forwardDir ? 1 : 0; L = Lo; status = ST_OK; break; }
