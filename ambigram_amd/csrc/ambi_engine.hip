@@ -479,23 +479,6 @@ __global__ __launch_bounds__(256) void ambi_finish_lean_kernel(BatchArgs A) {
     }
 }
 
-// The same with one wavefront per unit (no cross-wave barriers): the shape for large batches, where the parallelism is
-// across units; the workgroup form above keeps the latency of a small batch low.
-__global__ __launch_bounds__(64) void ambi_finish_lean_wave_kernel(BatchArgs A) {
-    WaveGroup g;
-    for (int i = (int)blockIdx.x; i < A.n_units; i += (int)gridDim.x) {
-        stage_finish_lean(g, A, A.unit_base + i, ambi_lds);
-        g.sync();
-    }
-    if (A.host_pending && threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(A.blocks_done, 1) == (int)gridDim.x - 1) {
-            *A.host_pending = atomicAdd(A.n_pending, 0);
-            *A.blocks_done = 0;
-        }
-    }
-}
-
 __global__ __launch_bounds__(1024) void ambi_pack_scan_kernel(BatchArgs A, int which, int32_t* lengths, int64_t* pack_off, int64_t* total) {
     __shared__ int64_t sh[17];
     int64_t carry = 0;
@@ -630,7 +613,6 @@ class HipBackend : public Backend {
     int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_finish_lean_ = 0, lds_enum_ = 0;
     bool lean_finish_ = true;   // env AMBI_LEAN_FINISH=0: every unit through the full finish stage
     int finish_grid_ = 0;       // workgroups of the lean finish kernel; 0 = sized per run (env AMBI_FINISH_GRID overrides)
-    bool finish_wave_ = false;  // one wavefront per unit (env AMBI_FINISH_WAVE)
     int32_t* d_blocks_done_ = nullptr;
     uint32_t* d_anblk_ = nullptr; uint8_t* d_adepth_ = nullptr;
     int finish_path_cells_ = 0;
@@ -769,7 +751,6 @@ class HipBackend : public Backend {
         lds_finish_lean_ = (int)finish_lean_work_bytes(hb.max_n, hb.max_m, hb.max_bkp);
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
-        { const char* e = getenv("AMBI_FINISH_WAVE"); finish_wave_ = e ? atoi(e) != 0 : false; }
         if ((rc = dalloc(&d_blocks_done_, 1))) return rc;
         HIP_CK(hipMemset(d_blocks_done_, 0, sizeof(int32_t)));
         enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
@@ -794,7 +775,6 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_lean_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_lean_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
@@ -965,8 +945,7 @@ class HipBackend : public Backend {
         tick("ambi_first_kernel", s, 4, false, sb);
         tick("ambi_finish_kernel", s, 5, true, sb);
         const int fgrid = finish_grid_for(U);
-        if (lean_finish_ && finish_wave_) hipLaunchKernelGGL(ambi_finish_lean_wave_kernel, dim3(fgrid), dim3(64), lds_finish_lean_, sb, A);
-        else if (lean_finish_) hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
+        if (lean_finish_) hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
         else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr);
         tick("ambi_finish_kernel", s, 5, false, sb);
         if (overlap_back_) { (void)hipEventRecord(ev_back_, sb); (void)hipStreamWaitEvent(st, ev_back_, 0); }

@@ -73,7 +73,6 @@ AMBI_HD int64_t dir_words(int nB, int NW) { return ((int64_t)nB * dir_stride(NW)
 struct BuildTables {
     uint64_t* avail;    // [nI]
     uint64_t* cnt64;    // [nI]  exact completion counts (first rows of the directory entries)
-    int32_t* lvl;       // [kMaxNodes+3] level offsets (copied once: the level loops must not go to HBM every iteration)
     uint32_t* nblk;     // [nI]  blocks below the ideal (1 for ideals with cnt <= block_max), saturated
     uint32_t* link;     // [nC]  child link with the child's (saturated) count: child | cnt16 << 16 -- one read per sibling
     uint16_t* cbase;    // [nI]
@@ -89,7 +88,6 @@ AMBI_HD int64_t carve_build_tables(uint8_t* mem, int nI, int nC, BuildTables& B)
     int64_t o = 0;
     B.avail = reinterpret_cast<uint64_t*>(mem + o); o += 8ll * nI;
     B.cnt64 = reinterpret_cast<uint64_t*>(mem + o); o += 8ll * nI;
-    B.lvl = reinterpret_cast<int32_t*>(mem + o); o += 4ll * (kMaxNodes + 3) + 4;
     B.nblk = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * nI;
     B.link = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * nC;
     B.root_row = reinterpret_cast<uint32_t*>(mem + o); o += 4ll * (nI + 1);
