@@ -96,6 +96,7 @@ def _declare(L):
         "ambi_ilp_sizes": (C.c_int, [vp, pi64, pi64, pi32, pi32]),
         "ambi_ilp_copy": (C.c_int, [vp, pi64, pi32, pd, pd, pd, pd, pd, pd]),
         "ambi_ilp_write_lp": (C.c_int, [vp, C.c_char_p]),
+        "ambi_ilp_write_mps": (C.c_int, [vp, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -593,6 +594,11 @@ class IlpModel:
         self.lib.ambi_ilp_copy(self.h, p(rp, C.c_int64), p(col, C.c_int32), p(val, C.c_double), p(rlo, C.c_double), p(rup, C.c_double),
                                p(clo, C.c_double), p(cup, C.c_double), p(obj, C.c_double))
         return dict(row_ptr=rp, col=col, val=val, row_lo=rlo, row_up=rup, col_lo=clo, col_up=cup, obj=obj)
+
+    def write_mps(self, path):
+        rc = self.lib.ambi_ilp_write_mps(self.h, path.encode())
+        if rc != 0:
+            raise AmbiError(self.lib, rc, "write_mps")
 
     def write_lp(self, path):
         rc = self.lib.ambi_ilp_write_lp(self.h, path.encode())

@@ -441,5 +441,9 @@ int ambi_ilp_write_lp(const ambi_ilp_t* p, const char* path) {
     if (!p || !path) return AMBI_ERR_ARG;
     return ambi::write_lp(path, p->m) ? 0 : AMBI_ERR_OPEN;
 }
+int ambi_ilp_write_mps(const ambi_ilp_t* p, const char* path) {
+    if (!p || !path) return AMBI_ERR_ARG;
+    return ambi::write_mps(path, p->m) ? 0 : AMBI_ERR_OPEN;
+}
 
 }  // extern "C"

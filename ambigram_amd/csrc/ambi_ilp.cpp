@@ -216,4 +216,67 @@ bool write_lp(const std::string& path, const IlpModel& m) {
     return true;
 }
 
+bool write_mps(const std::string& path, const IlpModel& m) {
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    const double INF = DBL_MAX;
+    const int64_t nr = m.n_rows();
+    // CSR -> CSC by counting
+    std::vector<int64_t> cptr((size_t)m.n_cols + 1, 0);
+    for (int64_t k = 0; k < m.nnz(); k++) cptr[(size_t)m.col[k] + 1]++;
+    for (int c = 0; c < m.n_cols; c++) cptr[(size_t)c + 1] += cptr[c];
+    std::vector<int32_t> crow((size_t)m.nnz());
+    std::vector<double> cval((size_t)m.nnz());
+    {
+        std::vector<int64_t> at(cptr.begin(), cptr.end() - 1);
+        for (int64_t r = 0; r < nr; r++)
+            for (int64_t k = m.row_ptr[r]; k < m.row_ptr[r + 1]; k++) { const int64_t p = at[m.col[k]]++; crow[p] = (int32_t)r; cval[p] = m.val[k]; }
+    }
+    fprintf(f, "NAME ambigram_bfb\nROWS\n N OBJ\n");
+    for (int64_t r = 0; r < nr; r++) {
+        const double lo = m.row_lo[r], up = m.row_up[r];
+        const char t = (lo == up) ? 'E' : (lo <= -INF ? 'L' : (up >= INF ? 'G' : 'L'));   // two-sided: L row + range
+        fprintf(f, " %c R%lld\n", t, (long long)r);
+    }
+    fprintf(f, "COLUMNS\n");
+    bool in_int = false;
+    for (int c = 0; c < m.n_cols; c++) {
+        if (c < m.n_int && !in_int) { fprintf(f, " MARKER MARKER INTORG\n"); in_int = true; }
+        if (c >= m.n_int && in_int) { fprintf(f, " MARKER MARKER INTEND\n"); in_int = false; }
+        bool any = false;
+        if (m.obj[c] != 0) { fprintf(f, " x%d OBJ %.15g\n", c, m.obj[c]); any = true; }
+        for (int64_t k = cptr[c]; k < cptr[(size_t)c + 1]; k++) { fprintf(f, " x%d R%d %.15g\n", c, crow[k], cval[k]); any = true; }
+        if (!any) fprintf(f, " x%d OBJ 0\n", c);    // a column must appear to exist
+    }
+    if (in_int) fprintf(f, " MARKER MARKER INTEND\n");
+    fprintf(f, "RHS\n");
+    for (int64_t r = 0; r < nr; r++) {
+        const double lo = m.row_lo[r], up = m.row_up[r];
+        const double rhs = (lo == up) ? lo : (lo <= -INF ? up : (up >= INF ? lo : up));
+        if (rhs != 0) fprintf(f, " RHS R%lld %.15g\n", (long long)r, rhs);
+    }
+    bool ranges = false;
+    for (int64_t r = 0; r < nr; r++) {
+        const double lo = m.row_lo[r], up = m.row_up[r];
+        if (lo != up && lo > -INF && up < INF) {
+            if (!ranges) { fprintf(f, "RANGES\n"); ranges = true; }
+            fprintf(f, " RNG R%lld %.15g\n", (long long)r, up - lo);
+        }
+    }
+    fprintf(f, "BOUNDS\n");
+    for (int c = 0; c < m.n_cols; c++) {
+        const double lo = m.col_lo[c], up = m.col_up[c];
+        if (lo == up) fprintf(f, " FX BND x%d %.15g\n", c, lo);
+        else {
+            if (lo <= -INF) fprintf(f, " MI BND x%d\n", c);
+            else if (lo != 0) fprintf(f, " LO BND x%d %.15g\n", c, lo);
+            if (up < INF) fprintf(f, " UP BND x%d %.15g\n", c, up);
+            else if (c < m.n_int) fprintf(f, " PL BND x%d\n", c);   // integer columns default to [0,1] in MPS readers
+        }
+    }
+    fprintf(f, "ENDATA\n");
+    fclose(f);
+    return true;
+}
+
 }  // namespace ambi

@@ -40,5 +40,9 @@ void build_bfb_ilp_rows(int start_id, int end_id, const double* seg_cn, const do
 // (the .sol parser relies on it, localhap.cpp:204-205).  Rows whose lower bound 0 is implied (non-negative variables and
 // coefficients) are written one-sided.
 bool write_lp(const std::string& path, const IlpModel& m);
+// The same model as an MPS file (the reference leaves <prefix>.mps beside <prefix>.lp, LGM.cpp:4749): free-format MPS with
+// rows R<i>, columns x<j> (the names the .sol parser expects), integer markers around the first n_int columns, RANGES for
+// two-sided rows.  Column-major, so the CSR is transposed first (O(nnz)).
+bool write_mps(const std::string& path, const IlpModel& m);
 
 }  // namespace ambi

@@ -122,6 +122,7 @@ int main(int argc, char** argv) {
             ambi_ilp_t* ilp = nullptr;
             if ((rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp)) != 0) return die(ambi_error_string(rc));
             std::cout << "Declare done" << std::endl << "ILP formula done" << std::endl << "Variable constrains done" << std::endl;
+            ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());   // LGM.cpp:4749-4750: both side files
             ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
             ambi_ilp_destroy(ilp);
             std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181

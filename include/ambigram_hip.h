@@ -231,6 +231,8 @@ int ambi_ilp_copy(const ambi_ilp_t* p, int64_t* row_ptr, int32_t* col, double* v
                   double* col_lo, double* col_up, double* obj);
 /* writes <path> as CPLEX-LP text with CoinUtils column names x<j> (what `cbc <prefix>.lp solve solu <prefix>.sol` reads) */
 int ambi_ilp_write_lp(const ambi_ilp_t* p, const char* path);
+/* <prefix>.mps beside <prefix>.lp, as the reference leaves it (LGM.cpp:4749): free-format MPS of the same model. */
+int ambi_ilp_write_mps(const ambi_ilp_t* p, const char* path);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ def check_readme(exe, cwd, oracle):
     got = [l for l in r.stdout.splitlines() if not l.startswith("fake cbc")]
     assert got == want
     assert got[-1] == "1+2+3+4+5+6+|6-5-4-3-2-|2+3+4+|4-3-|3+4+|4-3-2-|2+3+4+5+6+|6-5-4-3-2-1-"   # README.md:122
-    assert os.path.exists(os.path.join(cwd, "readme.lp")) and os.path.exists(os.path.join(cwd, "readme.sol"))
+    assert all(os.path.exists(os.path.join(cwd, "readme." + ext)) for ext in ("lp", "mps", "sol"))      # the three side files (LGM.cpp:4749-4750, localhap.cpp:179)
     # time.csv: name,nSeg,nInv,nOtherJunc,cnSum,pathLen,maxCN,seconds  (readme6,6,4,0,32,32,8,<sec>)
     row = open(os.path.join(cwd, "time.csv")).read().strip().split(",")
     assert row[1:7] == ["6", "4", "0", "32", "32", "8"]

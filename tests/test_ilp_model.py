@@ -92,6 +92,77 @@ def test_lp_text_is_written(hostsim_lib, workdir):
     assert text.count("\nR") >= 140
 
 
+def _parse_mps(path):
+    """Minimal free-format MPS reader (test infrastructure): rows, column entries, RHS, ranges, bounds, integer set."""
+    rows, kinds, entries, obj, rhs, rng, bounds, ints = [], {}, {}, {}, {}, {}, {}, set()
+    sec, in_int = None, False
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if not line.startswith(" "):
+            sec = t[0]
+            continue
+        if sec == "ROWS":
+            kinds[t[1]] = t[0]
+            if t[0] != "N":
+                rows.append(t[1])
+        elif sec == "COLUMNS":
+            if t[0] == "MARKER":
+                in_int = t[2] == "INTORG"
+                continue
+            if in_int:
+                ints.add(t[0])
+            if t[1] == "OBJ":
+                if float(t[2]) != 0:
+                    obj[t[0]] = float(t[2])
+            else:
+                entries[(t[1], t[0])] = float(t[2])
+        elif sec == "RHS":
+            rhs[t[1]] = float(t[2])
+        elif sec == "RANGES":
+            rng[t[1]] = float(t[2])
+        elif sec == "BOUNDS":
+            bounds.setdefault(t[2], []).append((t[0], float(t[3]) if len(t) > 3 else None))
+    return rows, kinds, entries, obj, rhs, rng, bounds, ints
+
+
+def test_mps_round_trip(hostsim_lib, workdir):
+    """<prefix>.mps (the reference leaves it beside <prefix>.lp): parsed back, it is the model entry for entry."""
+    INF = 1.7976931348623157e308
+    for lh, ci in ((os.path.join(DATA, "readme6.lh"), 0), (os.path.join(DATA, "trx_c2.lh"), 1)):
+        m = _model_from_engine(hostsim_lib, lh, ci, "", False, hostsim_lib)
+        p = os.path.join(workdir, "m%d.mps" % ci)
+        m.write_mps(p)
+        A = m.arrays()
+        rows, kinds, entries, obj, rhs, rng, bounds, ints = _parse_mps(p)
+        assert len(rows) == m.n_rows and ints == {"x%d" % c for c in range(m.n_int)}
+        want = {}
+        for r in range(m.n_rows):
+            for k in range(A["row_ptr"][r], A["row_ptr"][r + 1]):
+                want[("R%d" % r, "x%d" % A["col"][k])] = want.get(("R%d" % r, "x%d" % A["col"][k]), 0.0) + A["val"][k]
+        assert entries == want
+        assert obj == {"x%d" % c: A["obj"][c] for c in range(m.n_cols) if A["obj"][c] != 0}
+        for r in range(m.n_rows):
+            lo, up, name = A["row_lo"][r], A["row_up"][r], "R%d" % r
+            b = rhs.get(name, 0.0)
+            if lo == up:
+                assert kinds[name] == "E" and b == lo
+            elif lo <= -INF:
+                assert kinds[name] == "L" and b == up
+            elif up >= INF:
+                assert kinds[name] == "G" and b == lo
+            else:
+                assert kinds[name] == "L" and b == up and rng[name] == up - lo
+        for c in range(m.n_cols):
+            lo, up, bs = A["col_lo"][c], A["col_up"][c], dict(bounds.get("x%d" % c, []))
+            if lo == up:
+                assert bs == {"FX": lo}
+            else:
+                assert bs.get("LO", 0.0) == lo and (bs.get("UP") == up if up < INF else "UP" not in bs)
+        m.close()
+
+
 def _row_form_cases(workdir):
     out = [(os.path.join(DATA, "readme6.lh"), 0, "", False), (os.path.join(DATA, "trx_c2.lh"), 1, "", False)]
     j = os.path.join(workdir, "r6b.juncs")
