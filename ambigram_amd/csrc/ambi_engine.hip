@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
         const int64_t wlo = blo + (int64_t)wave * per;
         int64_t whi = wlo + per;
         if (whi > bhi) whi = bhi;
-        if (wlo < whi) {
+        if (!dfs && A.emit_interleave) {   // the blocks of the whole work block dealt round-robin to the waves
+            if (blo < bhi)
+                emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)blo, (uint32_t)bhi, A.order_arena + out->order_off, lane, lane + 1, wave, nwave);
+        } else if (wlo < whi) {
             if (dfs)
                 emit_blocks_dfs_dispatch<CLS>(Bt, dfs_suf, K, dfs_block_max, (uint32_t)wlo, (uint32_t)whi, A.order_arena + out->order_off,
                                               reinterpret_cast<uint16_t*>(wave_state), reinterpret_cast<uint32_t*>(wave_state + 128), lane, lane + 1);
@@ -638,6 +641,7 @@ class HipBackend : public Backend {
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr;
     uint8_t* d_first_rows_ = nullptr;
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
+    int emit_interleave_ = 1; // env AMBI_EMIT_INTERLEAVE=0: every wave a contiguous quarter of the work block instead of every fourth block
     int block_dfs_ = 1;       // env AMBI_BLOCK_DFS=0: no directory-free images (units whose directory does not fit take the general path)
     std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit
     bool all_done_ = false;
@@ -809,6 +813,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
         { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e9 = getenv("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
+        { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
             // the scan / finish kernels fill the gaps the enumerate kernel leaves: lowest dispatch priority (AMBI_BACK_PRIORITY=0: default)
@@ -838,7 +843,7 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
-        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
+        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.emit_interleave = emit_interleave_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;

@@ -311,8 +311,13 @@ AMBI_HD void emit_piece(const uint32_t* suf, uint32_t so, uint32_t r0, uint32_t 
 
 // Rows [rlo, rhi) of one unit's table, written by ONE wave from the unit's image (`img`, nB blocks).  `table` = the
 // unit's rows as dwords (16-byte aligned).
+// `part` / `parts`: the blocks of the range are dealt round-robin to `parts` waves (block b of the range goes to wave
+// b mod parts), so that the waves of a workgroup write ONE compact window of the table that moves forward, instead of
+// `parts` separate streams a quarter of the range apart (measured on a pure store stream, profiles/tools/hbm_write_pat.hip:
+// 5.70 -> 5.98 TB/s).  parts = 1: the whole range.
 template <int NW>
-AMBI_HD void emit_blocks_wave(const uint32_t* img, int nB, uint32_t rlo, uint32_t rhi, uint32_t* table, int lane_lo, int lane_hi) {
+AMBI_HD void emit_blocks_wave(const uint32_t* img, int nB, uint32_t rlo, uint32_t rhi, uint32_t* table, int lane_lo, int lane_hi,
+                              int part = 0, int parts = 1) {
     if (rlo >= rhi || nB <= 0) return;
     constexpr int S = NW + 5;
     const uint32_t* suf = img + dir_words(nB, NW);
@@ -322,14 +327,13 @@ AMBI_HD void emit_blocks_wave(const uint32_t* img, int nB, uint32_t rlo, uint32_
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (uniu(img[mid * S]) <= rlo) lo = mid; else hi = mid; }
         b = lo;
     }
-    uint32_t cur = rlo;
-    while (cur < rhi && b < nB) {
+    for (b += part; b < nB; b += parts) {
         const uint32_t* e = img + b * S;
         const uint32_t r0 = uniu(e[0]), r1 = uniu(e[S]), so = uniu(e[1]);
+        if (r0 >= rhi) break;
+        const uint32_t cur = r0 > rlo ? r0 : rlo;        // the first / last block of the range may be cut
         const uint32_t end = r1 < rhi ? r1 : rhi;
         emit_piece<NW>(suf, so, r0, cur, end, e + 2, table, lane_lo, lane_hi);
-        cur = end;
-        b++;
     }
 }
 

@@ -292,10 +292,10 @@ AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R,
 // Block-emission form (ambi_enum_blocks.hpp) of one wave's rows [rlo, rhi); dispatch on the row width.
 template <int CLS>
 AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t rlo, uint32_t rhi, uint8_t* unit_rows,
-                                  int lane_lo, int lane_hi) {
+                                  int lane_lo, int lane_hi, int part = 0, int parts = 1) {
     const int nw = row_stride(K) / 4;
     uint32_t* table = reinterpret_cast<uint32_t*>(unit_rows);
-#define AMBI_EB(N) emit_blocks_wave<N>(img, nB, rlo, rhi, table, lane_lo, lane_hi); return;
+#define AMBI_EB(N) emit_blocks_wave<N>(img, nB, rlo, rhi, table, lane_lo, lane_hi, part, parts); return;
     if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_EB(1) case 2: AMBI_EB(2) case 3: AMBI_EB(3) case 4: AMBI_EB(4) case 5: AMBI_EB(5) default: break; } }
     if (CLS < 0 || CLS == 1) { switch (nw) { case 6: AMBI_EB(6) case 7: AMBI_EB(7) case 8: AMBI_EB(8) default: break; } }
     if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_EB(12) } else if (nw == 16) { AMBI_EB(16) } }
