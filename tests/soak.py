@@ -47,4 +47,10 @@ for i in range(count // 5):
                 print("MISMATCH", lh, rev, d[:3], flush=True)
 print("synthetic samples: %d compared, %d mismatches; agreed: %d without a valid order, %d refused where the reference reads out of bounds (%.0f s)"
       % (n, bad, agreed_none, agreed_ub, time.time() - t0))
+t0 = time.time()
+st = ec.check_all_mode(lib, oracle_py, work, seeds=range(first, first + count // 20))
+print("--all mode: %s (%.0f s)" % (st, time.time() - t0), flush=True)
+ec.check_search_budget(lib, oracle_py, work)
+ec.check_large_lattice(lib, oracle_py, work, K=56, k2=6)
+print("search budget, large lattice: ok")
 sys.exit(1 if bad else 0)
