@@ -45,6 +45,12 @@ int main() {
     for (int i = 0; i < 4; i++) printf("%-22s %.3f ms  %.1f GB/s\n", nm[i], ms[i], bytes / (ms[i] * 1e-3) / 1e9);
     printf("%-22s %.3f ms\n", "P3 grid 1024", run<3>(d, bytes, 1024));
     printf("%-22s %.3f ms\n", "P3 grid 16384", run<3>(d, bytes, 16384));
+    printf("%-22s %.3f ms\n", "P3 grid 65536", run<3>(d, bytes, 65536));
+    printf("%-22s %.3f ms\n", "P3 grid 262144", run<3>(d, bytes, 262144));
+    printf("%-22s %.3f ms\n", "P3 grid 1048576 (one 4 KB piece per workgroup)", run<3>(d, bytes, 1048576));
+    printf("%-22s %.3f ms\n", "P2 grid 16384 (256 KB chunks)", run<2>(d, bytes, 16384));
+    printf("%-22s %.3f ms\n", "P2 grid 65536 (64 KB chunks)", run<2>(d, bytes, 65536));
+    printf("%-22s %.3f ms\n", "P0 grid 16384 (256 KB chunks)", run<0>(d, bytes, 16384));
     { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); float best = 1e9f;
       for (int rep = 0; rep < 4; rep++) { (void)hipEventRecord(a); (void)hipMemsetAsync(d, 1, bytes, 0); (void)hipEventRecord(b); (void)hipEventSynchronize(b); float t; (void)hipEventElapsedTime(&t, a, b); if (rep && t < best) best = t; }
       printf("%-22s %.3f ms  %.1f GB/s\n", "P4 hipMemsetAsync", best, bytes / (best * 1e-3) / 1e9); }
