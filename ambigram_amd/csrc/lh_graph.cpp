@@ -50,17 +50,29 @@ bool same_edges(int s1, int sd1, int t1, int td1, int s2, int sd2, int t2, int t
 }
 }  // namespace
 
+// one key for an edge (a, b) and its complement (-b, -a): the smaller of the two pairs (ids > 0, so signs are faithful)
+static uint64_t edge_key(int s, int sd, int t, int td) {
+    int64_t a = sd > 0 ? s : -(int64_t)s, b = td > 0 ? t : -(int64_t)t;
+    int64_t a2 = -b, b2 = -a;
+    if (a2 < a || (a2 == a && b2 < b)) { a = a2; b = b2; }
+    return ((uint64_t)(uint32_t)(int32_t)a << 32) | (uint64_t)(uint32_t)(int32_t)b;
+}
+
 int LhGraph::find_junction(int src, int sdir, int tgt, int tdir) const {
+    if (src > 0 && tgt > 0 && junc_index.size() == (size_t)n_junc()) {   // every junction is indexed (ids are positive)
+        auto it = junc_index.find(edge_key(src, sdir, tgt, tdir));
+        return it == junc_index.end() ? -1 : it->second;
+    }
     for (int i = 0; i < n_junc(); i++)
         if (same_edges(j_src[i], j_sdir[i], j_tgt[i], j_tdir[i], src, sdir, tgt, tdir)) return i;
     return -1;
 }
 
 bool LhGraph::add_junction(int src, int sdir, int tgt, int tdir, double cov, double cn, bool inferred, bool bounded) {
-    bool hs = false, ht = false;
-    for (int id : seg_id) { hs |= (id == src); ht |= (id == tgt); }
-    if (!hs || !ht) return false;
+    for (; segs_indexed < seg_id.size(); segs_indexed++) seg_index.emplace(seg_id[segs_indexed], (int32_t)segs_indexed);
+    if (!seg_index.count(src) || !seg_index.count(tgt)) return false;
     if (find_junction(src, sdir, tgt, tdir) >= 0) return true;   // duplicate: ignored (Graph.cpp:592-595)
+    if (src > 0 && tgt > 0 && junc_index.size() == (size_t)n_junc()) junc_index.emplace(edge_key(src, sdir, tgt, tdir), (int32_t)n_junc());
     j_src.push_back(src); j_tgt.push_back(tgt); j_sdir.push_back((int8_t)sdir); j_tdir.push_back((int8_t)tdir);
     j_cov.push_back(cov); j_cn.push_back(cn); j_inferred.push_back(inferred); j_bounded.push_back(bounded);
     return true;

@@ -4,6 +4,7 @@
 // with SoA vectors: a vertex is a signed segment id, a junction is (src, sdir, tgt, tdir, cn) and its two
 // complementary edges are derived on the fly.
 #pragma once
+#include <unordered_map>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -45,6 +46,11 @@ struct LhGraph {
     int n_junc() const { return (int)j_src.size(); }
     int n_chr() const { return (int)source_ids.size(); }
     int find_junction(int src, int sdir, int tgt, int tdir) const;   // Graph.cpp:501-511, -1 if absent
+    // indices behind find_junction / add_junction (the reference compares printed edge strings pair by pair, O(m^2)):
+    // an edge and its complement share one key; segments by id
+    std::unordered_map<uint64_t, int32_t> junc_index;
+    std::unordered_map<int32_t, int32_t> seg_index;
+    size_t segs_indexed = 0;
     bool add_junction(int src, int sdir, int tgt, int tdir, double cov, double cn, bool inferred, bool bounded);
 };
 
