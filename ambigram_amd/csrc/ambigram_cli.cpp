@@ -127,7 +127,8 @@ int main(int argc, char** argv) {
             ambi_ilp_destroy(ilp);
             std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181
             std::cout.flush();
-            (void)system(cmd.c_str());
+            const int solver_rc = system(cmd.c_str());   // the reference ignores the exit status too; a missing .sol is caught below
+            (void)solver_rc;
             rc = ambi_batch_add_chromosome_sol(b, g, c, ("./" + prefix + ".sol").c_str());
             if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:187-190
             if (rc < 0) return die(ambi_error_string(rc));
