@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of two builds of the engine library on one box:  python3 profiles/tools/lib_ab.py libA.so libB.so [reps]
+"""A/B of two builds of the engine library on one box:  python3 profiles/tools/lib_ab.py libA.so libB.so [libC.so ...] [reps]
 Each library runs the bench batch (4096 units, K = 19) in its own child process, interleaved; prints ms per step and the
 enumerate kernel's event time."""
 import os, subprocess, sys
@@ -26,8 +26,8 @@ for _ in range(20): b.run(0, st)
 b.wait(); dt = (time.perf_counter() - t) / 20
 print("%%-40s %%.4f ms per step, enumerate %%.4f ms" %% (os.path.basename(sys.argv[1]), dt * 1e3, b.kernel_times()["ambi_enumerate_kernel"]))
 ''' % ROOT
-libs = sys.argv[1:3]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+reps = int(sys.argv[-1]) if not sys.argv[-1].endswith(".so") else 2
 for r in range(reps):
     for l in libs:
         out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(l)], capture_output=True, text=True)
