@@ -590,6 +590,11 @@ __global__ __launch_bounds__(256) void ambi_expand_runs_kernel(const int32_t* ru
     }
 }
 
+// The dynamic-LDS ceiling of a kernel is a per-function, process-wide attribute: every batch asks for the device limit,
+// so that a second batch with smaller units cannot lower it under a first batch that is still launching (the launches
+// themselves request only what their units need).
+constexpr int kLdsMaxDynamic = 160 * 1024 - 1024;
+
 // ------------------------------------------------------------------------------------------------
 // backend
 // ------------------------------------------------------------------------------------------------
@@ -768,23 +773,23 @@ class HipBackend : public Backend {
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
         if ((rc = dalloc(&d_blk_img_, U * (size_t)block_lds_))) return rc;
         if ((rc = dalloc(&d_blk_hdr_, U * 8))) return rc;
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_build_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
                     lds_prepare_, lds_first_, lds_finish_);
             return ST_ERR_BAD_INPUT;
         }
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_prepare_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_first_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_finish_lean_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_enum_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         enum_classes_ = 0;
         for (const UnitIn& un : hb.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
         // slices: env AMBI_SLICES or the configuration; 0 = automatic (4 when the batch is large enough to fill the
@@ -830,9 +835,9 @@ class HipBackend : public Backend {
             // of its workgroups per CU.  Measured (profiles/r01_slices.md): no floor is best -- the scan / finish
             // workgroups slip in as enumerate workgroups retire.
             { const char* e6 = getenv("AMBI_ENUM_LDS_FLOOR"); const int floor_lds = e6 ? atoi(e6) : 0; if (lds_blocks_ < floor_lds && floor_lds <= kLdsLimit) lds_blocks_ = floor_lds; }
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_blocks_));
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         }
         uploaded_ = true; arena_checked_ = false;
         return 0;
@@ -1039,7 +1044,7 @@ class HipBackend : public Backend {
         HIP_CK(hipMemcpy(d_pend, fin.data(), nfin * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_CK(hipMemcpy(d_coff, coff.data(), (np + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1;
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, waves * lds_first_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         bool fwd = !(A_.flags & FLAG_REVERSED);
         for (int pass = 0; pass < 2 && np > 0; pass++) {
             std::vector<int64_t> init(np, 0x7fffffffffffffffll);
@@ -1199,7 +1204,7 @@ class HipBackend : public Backend {
         all_idx_[0].assign(U, {}); all_idx_[1].assign(U, {});
         const bool fwd0 = !(A_.flags & FLAG_REVERSED);
         const int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1, chunk = 16;
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_valid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, waves * lds_first_));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_valid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         for (int u = 0; u < U; u++) {
             if (hdr[u].status != ST_OK) continue;   // (no valid order: both passes were scanned already, the lists stay empty)
             const int64_t R = hdr[u].num_orders;
@@ -1258,7 +1263,7 @@ class HipBackend : public Backend {
         HIP_CK(hipMalloc((void**)&d_cells, (size_t)count * (size_t)stride * sizeof(int32_t)));
         HIP_CK(hipMemcpy(d_idx, v.data() + first, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice));
         const int lds = (int)(first_work_bytes(Uin.n_seg, Uin.bkp_cap) + 4ll * (Uin.bkp_cap / 2 + 2) + 16);
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_order_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_order_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         hipLaunchKernelGGL(ambi_order_paths_kernel, dim3((unsigned)count), dim3(64), lds, stream_, A_, unit, fwd ? 1 : 0, (const int64_t*)d_idx, d_len,
                            d_cells, stride);
         HIP_CK(hipGetLastError());

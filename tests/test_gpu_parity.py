@@ -243,3 +243,40 @@ def test_run_length_exchange_payload(hip_lib, oracle, workdir):
 
 def test_max_sizes(hip_lib, oracle, workdir):
     ec.check_max_sizes(hip_lib, oracle, workdir)
+
+
+def test_two_batches_of_different_sizes_alive(hip_lib, oracle, workdir):
+    """Two resident batches at once -- a large-unit one uploaded first, a small-unit one second -- run alternately on two
+    streams (what bench.py's `pipelined` leg does): per-kernel launch attributes are process-wide, the second upload must
+    not take from the first what its launches need."""
+    import torch
+    specs = [[("wide", 19, 256, 512), ("wide", 17, 128, 256)], [("chain", 7, 40, 80), ("wide", 9, 40, 80), ("mixed", 8, 48, 100)]]
+    batches, graphs, expect = [], [], []
+    for k, group in enumerate(specs):
+        b = api.Batch(hip_lib)
+        exp = []
+        for i, (tier, K, nseg, njunc) in enumerate(group):
+            s = synth.make_sample(nseg, njunc, tier, K, seed=9500 + 10 * k + i)
+            lh, sols = s.write(workdir, "tb%d_%d" % (k, i))
+            g = api.Graph(hip_lib, lh)
+            graphs.append(g)
+            b.add_chromosome_sol(g, 0, sols[0])
+            exp.append(oracle.run_bfb(lh, sols, keep_orders=True)["chr"][0])
+        b.upload()
+        batches.append(b)
+        expect.append(exp)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        for k in (0, 1, 0, 1):
+            batches[k].run(0, streams[k].cuda_stream)
+        for k in (0, 1):
+            batches[k].wait(); batches[k].download()
+            for u, oc in enumerate(expect[k]):
+                r = batches[k].unit_result(u)
+                assert r["status"] == 0 and r["num_orders"] == oc["num_orders"], (rep, k, u, r)
+                assert batches[k].unit_orders(u, 0, r["num_orders"], r["n_nodes"]).tolist() == oc["orders"], (rep, k, u)
+                assert batches[k].unit_path(u, 1).tolist() == oc["path_indel"], (rep, k, u)
+    for b in batches:
+        b.close()
+    for g in graphs:
+        g.close()
