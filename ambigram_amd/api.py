@@ -64,6 +64,7 @@ def _declare(L):
         "ambi_batch_add_unit": (C.c_int, [vp, i32, i32, pd, i32, pi32, pi32, pi8, pi8, pd, i32, pi32, pi32, pi32, pi32, i32, i32]),
         "ambi_batch_size": (C.c_int, [vp, pi32]),
         "ambi_batch_configure": (C.c_int, [vp, i64, i32, i32, i32]),
+        "ambi_batch_debug_inject_validity": (C.c_int, [vp, i32, pi8, i64]),
         "ambi_batch_upload": (C.c_int, [vp]),
         "ambi_batch_run": (C.c_int, [vp, u32, vp]),
         "ambi_batch_wait": (C.c_int, [vp]),
@@ -299,6 +300,12 @@ class Batch:
 
     def configure(self, order_arena_bytes=-1, ideal_cap=0, first_budget=0, target_lanes=0):
         self._ck(self.lib.ambi_batch_configure(self.h, order_arena_bytes, ideal_cap, first_budget, target_lanes), "configure")
+
+    def debug_inject_validity(self, unit, verdicts):
+        """Diagnostics hook (include/ambigram_hip.h): verdict overrides for the 2*R order evaluations of one unit
+        (forward-seed orientation first); 1 valid, 0 invalid, negative status, 127 = evaluate as usual."""
+        v, vp = _arr(verdicts, np.int8)
+        self._ck(self.lib.ambi_batch_debug_inject_validity(self.h, unit, vp, len(v)), "debug_inject_validity")
 
     def upload(self):
         self._ck(self.lib.ambi_batch_upload(self.h), "upload")

@@ -143,6 +143,16 @@ struct BatchArgs {
     int32_t* blocks_done;        // [1] finished workgroups of the lean finish kernel (the last one reports n_pending and resets it)
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)
     int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)
+    // diagnostics hook (ambi_batch_debug_inject_validity): verdicts that REPLACE the outcome of evaluating an order, so that
+    // the control flow around the evaluation (scan budget, parallel search, minimum index, orientation flip, --all) can be
+    // driven to places no known input reaches.  nullptr in every ordinary run.
+    const int8_t* inject_valid;  // pool: per unit 2*R verdicts, first orientation "forward seed" then "reversed seed"; 127 = evaluate
+    const int64_t* inject_off;   // [U][2] {offset into the pool or -1, number of verdicts}
+    // --all (ambi_all_kernel): validity bitmaps of both passes, one bit per order
+    uint64_t* all_bits;          // pool of 64-order words
+    const int64_t* all_off;      // [U+1] first word of every unit's pass-0 map; its pass-1 map follows (ceil(R/64) words each)
+    int32_t* all_count;          // [U][2] valid orders per pass
+    int32_t* all_flags;          // [U]    bit 0: an order on which the reference's behaviour is undefined was met
 };
 
 // stage-level timing marks (diagnostics only; one predictable branch per mark when off)

@@ -188,6 +188,13 @@ int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ide
     if (target_lanes >= 64) b->cfg.target_lanes = target_lanes;
     return 0;
 }
+int ambi_batch_debug_inject_validity(ambi_batch_t* b, int32_t unit, const int8_t* verdicts, int64_t count) {
+    if (!b || unit < 0 || unit >= (int)b->hb.units.size() || count < 0 || (count > 0 && !verdicts)) return AMBI_ERR_ARG;
+    if (b->uploaded) return AMBI_ERR_STATE;
+    if (b->hb.inject_unit.size() < b->hb.units.size()) b->hb.inject_unit.resize(b->hb.units.size());
+    b->hb.inject_unit[unit].assign(verdicts, verdicts + count);
+    return 0;
+}
 int ambi_batch_upload(ambi_batch_t* b) {
     if (!b) return AMBI_ERR_ARG;
     if (b->hb.units.empty()) return AMBI_ERR_STATE;

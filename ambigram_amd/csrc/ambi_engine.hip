@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
     const int u = A.unit_base + (int)blockIdx.x;
     const UnitOut* out = unit_out(A.results, u);
     const int64_t nblocks = A.blk_off[blockIdx.x + 1] - A.blk_off[blockIdx.x];
-    if (out->status != ST_OK || out->order_off < 0 || (nblocks == 1 && A.build_in_emit)) {   // no rows to write / image built by the enumerate kernel
+    // (order_off, not status: the scan for the first valid order runs beside this kernel and rewrites the status; the
+    // plan kernel gave order_off >= 0 to exactly the units that have rows to write)
+    if (out->order_off < 0 || nblocks <= 0 || (nblocks == 1 && A.build_in_emit)) {   // no rows to write / image built by the enumerate kernel
         if (threadIdx.x == 0) A.unit_fallback[u] = 0;
         return;
     }
@@ -352,12 +354,12 @@ __global__ __launch_bounds__(64) void ambi_first_kernel(BatchArgs A) {
     stage_first(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
-// Slow path: units whose first-valid scan ran out of budget.  One wave per chunk of `chunk` consecutive orders.
+// Slow path: units whose first-valid scan ran out of budget.  One wave per chunk of `chunk` consecutive orders
+// (ambi_stages.hpp: stage_search_chunk / stage_resolve).
 struct SearchArgs {
     const int32_t* pending;      // [np] unit indices
     const int64_t* chunk_off;    // [np+1] prefix of chunk counts
-    int64_t* found;              // [np] min valid order index (init INT64_MAX)
-    int32_t* err;                // [np] negative status seen
+    SearchSlot* slots;           // [np] per pass: least valid index / least undefined index
     int32_t np, chunk, forward, wave_lds;
 };
 __global__ __launch_bounds__(256) void ambi_search_kernel(BatchArgs A, SearchArgs S) {
@@ -371,67 +373,51 @@ __global__ __launch_bounds__(256) void ambi_search_kernel(BatchArgs A, SearchArg
         const int p = lo, u = S.pending[p];
         const UnitIn& U = A.units[u];
         if (unit_out(A.results, u)->status != ST_PENDING) continue;   // resolved by the previous pass
-        const int64_t R = unit_out(A.results, u)->num_orders;
         const int64_t first = (c - S.chunk_off[p]) * S.chunk;
-        if (first >= *(volatile int64_t*)&S.found[p]) continue;   // an earlier valid order is already known
+        if (first >= search_limit(load_now_i64(&S.slots[p].found), load_now_i64(&S.slots[p].err_key))) continue;   // an earlier hit is already known
         FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
         load_first_work(g, A, u, W);
-        for (int64_t n = first; n < first + S.chunk && n < R; n++) {
-            if (n >= *(volatile int64_t*)&S.found[p]) break;
-            int L = 0;
-            int v = eval_indexed(g, A, u, W, n, S.forward != 0, &L);
-            if (v < 0) { if (g.tid() == 0) atomicMin(&S.err[p], v); break; }
-            if (v == 1) { if (g.tid() == 0) atomicMin((unsigned long long*)&S.found[p], (unsigned long long)n); break; }
-        }
-        g.sync();
+        stage_search_chunk(g, A, u, W, first, S.chunk, S.forward != 0, &S.slots[p]);
     }
+}
+__global__ void ambi_search_init_kernel(SearchSlot* slots, int np) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p < np) { slots[p].found = kSearchNone; slots[p].err_key = kSearchNone; }
 }
 // after a search pass: re-evaluate the winning order to materialise its bkp and fill the header
 __global__ __launch_bounds__(64) void ambi_resolve_kernel(BatchArgs A, SearchArgs S, int pass) {
     WaveGroup g;
-    const int p = blockIdx.x, u = S.pending[p];
-    UnitOut* out = unit_out(A.results, u);
-    if (out->status != ST_PENDING) return;
-    const UnitIn& U = A.units[u];
-    const int64_t R = out->num_orders;
-    const int64_t f = S.found[p];
-    if (S.err[p] < 0) { if (g.tid() == 0) out->status = S.err[p]; return; }
-    if (f == 0x7fffffffffffffffll) {
-        if (pass == 1 && g.tid() == 0) { out->status = ST_NO_VALID_ORDER; out->evaluated = (int32_t)(2 * R); }
-        return;
-    }
-    FirstWork W = carve_first(ambi_lds, U.n_seg, U.bkp_cap);
-    load_first_work(g, A, u, W);
-    int L = 0;
-    int v = eval_indexed(g, A, u, W, f, S.forward != 0, &L);
-    const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-    cell_t* dst = reinterpret_cast<cell_t*>(A.results + U.res_off + Lay.bkp);
-    for (int i = g.tid(); i < L; i += g.size()) dst[i] = W.bkp[i];
-    if (g.tid() == 0) {
-        out->status = (v == 1) ? ST_OK : ST_ERR_REF_UB;
-        out->first_valid = f; out->first_forward = S.forward; out->bkp_len = L;
-        out->evaluated = (int32_t)(pass * R + f + 1);
-    }
+    const int p = blockIdx.x;
+    stage_resolve(g, A, S.pending[p], ambi_lds, &S.slots[p], S.forward != 0, pass);
 }
 
-// --all (LGM.cpp:3672-3685): every order of one unit is evaluated in one orientation; valid[n] = 1 valid, 0 not,
-// 2 = the reference's behaviour is undefined on this order.  One wave per chunk of orders.
-__global__ __launch_bounds__(256) void ambi_valid_kernel(BatchArgs A, int u, int forward, int chunk, int wave_lds, uint8_t* valid) {
+// --all (LGM.cpp:3672-3695), fused enumerate + evaluate (ambi_stages.hpp: stage_all_chunk): one wave per 64 consecutive
+// orders of a unit, all units of the batch in ONE launch per pass; the orders are unranked from the automaton by the
+// lanes, never read from the table.  Output: one 64-bit word of the unit's validity bitmap per wave-chunk.
+// Work item c of the launch = word c of the concatenated pass-0 maps (all_off is also the chunk prefix, up to the
+// factor 2 for the two passes).  LDS per wave: first-work area + 64 unranked rows.
+__global__ __launch_bounds__(256) void ambi_all_kernel(BatchArgs A, int pass, int wave_lds, int64_t total_chunks) {
     const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     uint8_t* work = ambi_lds + (size_t)wave * wave_lds;
     WaveGroup g;
-    const UnitIn& U = A.units[u];
-    const int64_t R = unit_out(A.results, u)->num_orders;
-    const int64_t first = ((int64_t)blockIdx.x * wpb + wave) * chunk;
-    if (first >= R) return;
-    FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
-    load_first_work(g, A, u, W);
-    for (int64_t n = first; n < first + chunk && n < R; n++) {
-        int L = 0;
-        const int v = eval_indexed(g, A, u, W, n, forward != 0, &L);
-        if (g.tid() == 0) valid[n] = (uint8_t)(v == 1 ? 1 : (v == 0 ? 0 : 2));
+    for (int64_t c = (int64_t)blockIdx.x * wpb + wave; c < total_chunks; c += (int64_t)gridDim.x * wpb) {
+        // all_off[u] = 2 * (chunks of the units before u)
+        int lo = 0, hi = A.n_units;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.all_off[mid] <= 2 * c) lo = mid; else hi = mid; }
+        const int u = lo;
+        const int64_t R = unit_out(A.results, u)->num_orders;
+        if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;   // no orientation flip for this unit (LGM.cpp:3691-3695)
+        const UnitIn& U = A.units[u];
+        FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+        uint8_t* rows = work + first_work_bytes(U.n_seg, U.bkp_cap);
         g.sync();
+        load_first_work(g, A, u, W);
+        stage_all_chunk(g, A, u, W, rows, c - A.all_off[u] / 2, pass);
     }
+}
+__global__ __launch_bounds__(256) void ambi_all_finalize_kernel(BatchArgs A) {
+    const int u = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (u < A.n_units) all_finalize_unit(A, u);
 }
 // Paths of a list of orders of one unit (the valid ones, in print order): one wave per order, breakpoints in LDS,
 // the expanded path (absolute signed ids) straight to cells[j * stride ...], its length to lengths[j].
@@ -648,20 +634,29 @@ class HipBackend : public Backend {
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
     int emit_interleave_ = 1; // env AMBI_EMIT_INTERLEAVE=0: every wave a contiguous quarter of the work block instead of every fourth block
     int block_dfs_ = 1;       // env AMBI_BLOCK_DFS=0: no directory-free images (units whose directory does not fit take the general path)
-    std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit
+    std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit (filled when asked for)
+    std::vector<std::vector<uint64_t>> all_cache_;   // --all: a unit's bitmap words once fetched
+    std::vector<int64_t> all_off_, all_R_;
+    std::vector<int32_t> all_counts_;
+    uint64_t* d_all_bits_ = nullptr; int64_t* d_all_off_ = nullptr; int32_t* d_all_count_ = nullptr; int32_t* d_all_flags_ = nullptr;
+    int8_t* d_inject_ = nullptr; int64_t* d_inject_off_ = nullptr;
+    float all_kernel_ms_ = -1.f;
+    int64_t all_bits_cap_ = 0;
     bool all_done_ = false;
     int enum_grid_ = 2048;
 
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
-                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_};
+                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
+                        d_all_bits_, d_all_off_, d_all_count_, d_all_flags_, d_inject_, d_inject_off_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
         d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
+        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         h_npending_ = nullptr; h_needed_ = nullptr;
@@ -773,6 +768,8 @@ class HipBackend : public Backend {
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
         if ((rc = dalloc(&d_blk_img_, U * (size_t)block_lds_))) return rc;
         if ((rc = dalloc(&d_blk_hdr_, U * 8))) return rc;
+        HIP_CK(hipMemset(d_blk_hdr_, 0, U * 8 * sizeof(int32_t)));   // a header never written reads as "no image" (fits == 0)
+        HIP_CK(hipMemset(d_fallback_, 0, U * sizeof(int32_t)));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
@@ -839,6 +836,12 @@ class HipBackend : public Backend {
             HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
             HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         }
+        if (!hb.inject.empty()) {   // diagnostics hook: verdict overrides (ambi_batch_debug_inject_validity)
+            if ((rc = dalloc(&d_inject_, hb.inject.size()))) return rc;
+            if ((rc = dalloc(&d_inject_off_, 2 * U))) return rc;
+            HIP_CK(hipMemcpy(d_inject_, hb.inject.data(), hb.inject.size(), hipMemcpyHostToDevice));
+            HIP_CK(hipMemcpy(d_inject_off_, hb.inject_off.data(), 2 * U * sizeof(int64_t), hipMemcpyHostToDevice));
+        }
         uploaded_ = true; arena_checked_ = false;
         return 0;
     }
@@ -858,6 +861,8 @@ class HipBackend : public Backend {
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
+        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_;
+        A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_;
     }
     BatchArgs slice_args(int s) const {
         BatchArgs A = A_;
@@ -904,10 +909,13 @@ class HipBackend : public Backend {
         tick("ambi_prepare_kernel", s, 0, true);
         hipLaunchKernelGGL(ambi_prepare_kernel, dim3(A.n_units), dim3(64), lds_prepare_, st, A);
         tick("ambi_prepare_kernel", s, 0, false);
-        if (overlap_back_) (void)hipEventRecord(ev_prep_, st);   // the scan for the first valid order needs nothing later than this
         tick("ambi_plan_kernel", s, 1, true);
         hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
         tick("ambi_plan_kernel", s, 1, false);
+        // The scan for the first valid order starts BEHIND the plan kernel: the plan kernel reads UnitOut::status (and may
+        // turn it into ORDERS_CAPACITY), the scan overwrites it (PENDING / NO_VALID_ORDER / errors) -- the two must not
+        // overlap.  Everything that runs beside the scan (image build, enumerate) reads order_off / blk_off only.
+        if (overlap_back_) (void)hipEventRecord(ev_prep_, st);
     }
     void launch_build(int s, const BatchArgs& A) {   // block-emission images
         hipStream_t st = slice_stream(s);
@@ -1027,8 +1035,14 @@ class HipBackend : public Backend {
         // the lean finish stage handed over (full finish stage only)
         std::vector<int32_t> pend, refin;
         for (int u = 0; u < U; u++) {
-            if (hdr[u].status == ST_PENDING) pend.push_back(u);
-            else if (hdr[u].status == ST_REFINISH) refin.push_back(u);
+            if (hdr[u].status == ST_PENDING) {
+                if (hdr[u].order_off < 0) {   // cannot happen (the scan only takes units the plan kernel gave rows): never search a table that is not there
+                    const int32_t st = ST_ERR_ORDERS_CAPACITY;
+                    HIP_CK(hipMemcpy(reinterpret_cast<uint8_t*>(d_results_) + sizeof(UnitOut) * (size_t)u + offsetof(UnitOut, status), &st, sizeof(int32_t), hipMemcpyHostToDevice));
+                    continue;
+                }
+                pend.push_back(u);
+            } else if (hdr[u].status == ST_REFINISH) refin.push_back(u);
         }
         if (pend.empty() && refin.empty()) return 0;
         const int np = (int)pend.size(), nfin = np + (int)refin.size(), chunk = 16;
@@ -1036,34 +1050,31 @@ class HipBackend : public Backend {
         for (int p = 0; p < np; p++) coff[p + 1] = coff[p] + (hdr[pend[p]].num_orders + chunk - 1) / chunk;
         std::vector<int32_t> fin(pend);
         fin.insert(fin.end(), refin.begin(), refin.end());
-        int32_t* d_pend; int64_t* d_coff; int64_t* d_found; int32_t* d_err;
+        int32_t* d_pend; int64_t* d_coff; SearchSlot* d_slots;
         HIP_CK(hipMalloc((void**)&d_pend, nfin * sizeof(int32_t)));
         HIP_CK(hipMalloc((void**)&d_coff, (np + 1) * sizeof(int64_t)));
-        HIP_CK(hipMalloc((void**)&d_found, (np + 1) * sizeof(int64_t)));
-        HIP_CK(hipMalloc((void**)&d_err, (np + 1) * sizeof(int32_t)));
+        HIP_CK(hipMalloc((void**)&d_slots, (np + 1) * sizeof(SearchSlot)));
         HIP_CK(hipMemcpy(d_pend, fin.data(), nfin * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_CK(hipMemcpy(d_coff, coff.data(), (np + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1;
         HIP_CK(hipFuncSetAttribute((const void*)ambi_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         bool fwd = !(A_.flags & FLAG_REVERSED);
+        // both passes are queued back to back: a unit resolved by pass 0 is skipped by pass 1 (its status is no longer PENDING)
         for (int pass = 0; pass < 2 && np > 0; pass++) {
-            std::vector<int64_t> init(np, 0x7fffffffffffffffll);
-            HIP_CK(hipMemcpy(d_found, init.data(), np * sizeof(int64_t), hipMemcpyHostToDevice));
-            HIP_CK(hipMemset(d_err, 0, np * sizeof(int32_t)));
-            SearchArgs S{d_pend, d_coff, d_found, d_err, np, chunk, fwd ? 1 : 0, lds_first_};
+            hipLaunchKernelGGL(ambi_search_init_kernel, dim3((np + 255) / 256), dim3(256), 0, stream_, d_slots, np);
+            SearchArgs S{d_pend, d_coff, d_slots, np, chunk, fwd ? 1 : 0, lds_first_};
             int64_t nblk = (coff[np] + waves - 1) / waves;
             if (nblk > 65535 * 16) nblk = 65535 * 16;
             if (nblk < 1) nblk = 1;
             hipLaunchKernelGGL(ambi_search_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * lds_first_, stream_, A_, S);
             hipLaunchKernelGGL(ambi_resolve_kernel, dim3(np), dim3(64), lds_first_, stream_, A_, S, pass);
             HIP_CK(hipGetLastError());
-            HIP_CK(hipStreamSynchronize(stream_));
             fwd = !fwd;
         }
         hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend);
         HIP_CK(hipGetLastError());
         HIP_CK(hipStreamSynchronize(stream_));
-        (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_found); (void)hipFree(d_err);
+        (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_slots);
         return 0;
     }
 
@@ -1117,6 +1128,10 @@ class HipBackend : public Backend {
                 times_.push_back({nm, cnt ? (float)(sum / cnt) : -1.0f});
             }
             (void)hipGetLastError();   // an event pair that was never recorded reports an error above: not one of ours
+        }
+        if (timing_ && (A_.flags & FLAG_ALL) && all_kernel_ms_ >= 0) {   // both passes of the --all evaluation of the last run
+            if (!times_.empty() && !strcmp(times_.back().name, "ambi_all_kernel")) times_.pop_back();
+            times_.push_back({"ambi_all_kernel", all_kernel_ms_});
         }
         return 0;
     }
@@ -1194,65 +1209,91 @@ class HipBackend : public Backend {
     int slice_count() const override { return n_slices_; }
 
     // ---- --all (LGM.cpp:3672-3695): every valid order of every unit, in the reference's print order ----
-    // pass 0 = the first orientation (forward unless --reversed), pass 1 = the flipped one, run only when the LAST
-    // order of pass 0 is invalid (LGM.cpp:3691-3695).  Host-driven, at wait(): validity map per pass, index lists kept
-    // on the host; the paths are produced on demand by all_paths().
+    // pass 0 = the first orientation (forward unless --reversed), pass 1 = the flipped one, run only for units whose LAST
+    // order of pass 0 is invalid (LGM.cpp:3691-3695).  Device-side and batched: at wait() ONE launch per pass over all
+    // (unit, 64-order chunk) work items (ambi_all_kernel: fused unrank + evaluate), validity bitmaps of R bits per pass
+    // and unit stay in HBM, the host reads the per-unit counts (one copy) and a unit's bitmap only when its indices are
+    // asked for; the paths are produced on demand by all_paths().
     int compute_all() {
         const int U = (int)hb_.units.size();
         std::vector<UnitOut> hdr(U);
         HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));
-        all_idx_[0].assign(U, {}); all_idx_[1].assign(U, {});
-        const bool fwd0 = !(A_.flags & FLAG_REVERSED);
-        const int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1, chunk = 16;
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_valid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        all_off_.assign(U + 1, 0);
         for (int u = 0; u < U; u++) {
-            if (hdr[u].status != ST_OK) continue;   // (no valid order: both passes were scanned already, the lists stay empty)
-            const int64_t R = hdr[u].num_orders;
-            if (R <= 0 || hdr[u].order_off < 0) continue;
-            uint8_t* d_valid = nullptr;
-            HIP_CK(hipMalloc((void**)&d_valid, (size_t)R));
-            std::vector<uint8_t> v((size_t)R);
-            int evaluated = 0, status = hdr[u].status;
-            for (int pass = 0; pass < 2; pass++) {
-                const bool fwd = pass == 0 ? fwd0 : !fwd0;
-                int64_t nblk = (R + (int64_t)waves * chunk - 1) / ((int64_t)waves * chunk);
-                hipLaunchKernelGGL(ambi_valid_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * lds_first_, stream_, A_, u, fwd ? 1 : 0, chunk,
-                                   lds_first_, d_valid);
-                HIP_CK(hipGetLastError());
-                HIP_CK(hipMemcpyAsync(v.data(), d_valid, (size_t)R, hipMemcpyDeviceToHost, stream_));
-                HIP_CK(hipStreamSynchronize(stream_));
-                evaluated += (int)R;
-                for (int64_t n = 0; n < R; n++) {
-                    if (v[n] == 1) all_idx_[pass][u].push_back(n);
-                    else if (v[n] == 2) status = ST_ERR_REF_UB;   // the reference reads out of bounds here: refuse
-                }
-                if (v[R - 1] == 1) break;   // the flip happens only when the last order is invalid
-            }
-            (void)hipFree(d_valid);
-            // header: all orders of the executed passes were evaluated
-            HIP_CK(hipMemcpy(reinterpret_cast<uint8_t*>(d_results_) + sizeof(UnitOut) * (size_t)u + offsetof(UnitOut, evaluated), &evaluated,
-                             sizeof(int32_t), hipMemcpyHostToDevice));
-            if (status != hdr[u].status)
-                HIP_CK(hipMemcpy(reinterpret_cast<uint8_t*>(d_results_) + sizeof(UnitOut) * (size_t)u + offsetof(UnitOut, status), &status,
-                                 sizeof(int32_t), hipMemcpyHostToDevice));
+            const bool live = hdr[u].status == ST_OK && hdr[u].num_orders > 0 && hdr[u].num_orders < (int64_t)kCountSat;
+            all_off_[u + 1] = all_off_[u] + (live ? 2 * all_words(hdr[u].num_orders) : 0);
+        }
+        all_R_.resize(U);
+        for (int u = 0; u < U; u++) all_R_[u] = hdr[u].num_orders;
+        all_cache_.assign(U, {});
+        all_idx_[0].assign(U, {}); all_idx_[1].assign(U, {});
+        all_counts_.assign(2 * (size_t)U, 0);
+        const int64_t words = all_off_[U], chunks = words / 2;
+        if (d_all_bits_ && all_bits_cap_ < words) { (void)hipFree(d_all_bits_); d_all_bits_ = nullptr; }
+        if (!d_all_off_) { if (int rc = dalloc(&d_all_off_, (size_t)U + 1)) return rc; if (int rc = dalloc(&d_all_count_, 2 * (size_t)U)) return rc; if (int rc = dalloc(&d_all_flags_, (size_t)U)) return rc; }
+        if (!d_all_bits_) { HIP_CK(hipMalloc((void**)&d_all_bits_, (size_t)(words > 0 ? words : 1) * sizeof(uint64_t))); all_bits_cap_ = words; }
+        HIP_CK(hipMemcpyAsync(d_all_off_, all_off_.data(), (U + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+        HIP_CK(hipMemsetAsync(d_all_bits_, 0, (size_t)(words > 0 ? words : 1) * sizeof(uint64_t), stream_));
+        HIP_CK(hipMemsetAsync(d_all_count_, 0, 2 * (size_t)U * sizeof(int32_t), stream_));
+        HIP_CK(hipMemsetAsync(d_all_flags_, 0, (size_t)U * sizeof(int32_t), stream_));
+        bind(A_.flags);
+        all_kernel_ms_ = -1.f;
+        if (chunks > 0) {
+            const int wave_lds = (int)((lds_first_ + 64 * kFirstRowStride + 15) & ~15);
+            const int waves = (4 * wave_lds <= 64 * 1024) ? 4 : ((2 * wave_lds <= 150 * 1024) ? 2 : 1);
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+            int64_t nblk = (chunks + waves - 1) / waves;
+            if (nblk > (1 << 20)) nblk = 1 << 20;   // grid-stride beyond
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (timing_) { HIP_CK(hipEventCreate(&ea)); HIP_CK(hipEventCreate(&eb)); HIP_CK(hipEventRecord(ea, stream_)); }
+            for (int pass = 0; pass < 2; pass++)
+                hipLaunchKernelGGL(ambi_all_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * wave_lds, stream_, A_, pass, wave_lds, chunks);
+            if (timing_) HIP_CK(hipEventRecord(eb, stream_));
+            hipLaunchKernelGGL(ambi_all_finalize_kernel, dim3((U + 255) / 256), dim3(256), 0, stream_, A_);
+            HIP_CK(hipGetLastError());
+            HIP_CK(hipMemcpyAsync(all_counts_.data(), d_all_count_, 2 * (size_t)U * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+            HIP_CK(hipStreamSynchronize(stream_));
+            if (timing_) { (void)hipEventElapsedTime(&all_kernel_ms_, ea, eb); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); }
         }
         return 0;
     }
+    // valid order indices of one pass of a unit, from its bitmap (fetched once per unit)
+    int all_indices(int unit, int pass, const std::vector<int64_t>** out) {
+        if (all_cache_[unit].empty() && all_off_[unit + 1] > all_off_[unit]) {
+            all_cache_[unit].resize((size_t)(all_off_[unit + 1] - all_off_[unit]));
+            HIP_CK(hipMemcpy(all_cache_[unit].data(), d_all_bits_ + all_off_[unit], all_cache_[unit].size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            const int64_t nw = all_words(all_R_[unit]);
+            for (int ps = 0; ps < 2; ps++) {
+                auto& v = all_idx_[ps][unit];
+                v.clear();
+                for (int64_t w = 0; w < nw; w++) {
+                    uint64_t x = all_cache_[unit][(size_t)(ps * nw + w)];
+                    while (x) { v.push_back(w * 64 + __builtin_ctzll(x)); x &= x - 1; }
+                }
+            }
+        }
+        *out = &all_idx_[pass][unit];
+        return 0;
+    }
     int all_count(int unit, int pass, int64_t* count) override {
-        if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) { if (count) *count = 0; return unit < 0 || pass < 0 || pass > 1 ? ST_ERR_BAD_INPUT : 0; }
-        if (count) *count = (int64_t)all_idx_[pass][unit].size();
+        if (pass < 0 || pass > 1 || unit < 0) { if (count) *count = 0; return ST_ERR_BAD_INPUT; }
+        if (count) *count = (size_t)(2 * unit + pass) < all_counts_.size() ? (int64_t)all_counts_[2 * (size_t)unit + pass] : 0;
         return 0;
     }
     int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) override {
         if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
-        const auto& v = all_idx_[pass][unit];
+        const std::vector<int64_t>* vp = nullptr;
+        if (int rc = all_indices(unit, pass, &vp)) return rc;
+        const auto& v = *vp;
         if (first < 0 || count < 0 || first + count > (int64_t)v.size()) return ST_ERR_BAD_INPUT;
         for (int64_t i = 0; i < count; i++) idx[i] = v[first + i];
         return 0;
     }
     int all_paths(int unit, int pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells, int64_t stride) override {
         if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
-        const auto& v = all_idx_[pass][unit];
+        const std::vector<int64_t>* vp = nullptr;
+        if (int rc = all_indices(unit, pass, &vp)) return rc;
+        const auto& v = *vp;
         if (first < 0 || count < 0 || first + count > (int64_t)v.size() || stride <= 0) return ST_ERR_BAD_INPUT;
         if (count == 0) return 0;
         const UnitIn& Uin = hb_.units[unit];

@@ -123,6 +123,20 @@ void HostBatch::finalize() {
     result_bytes = off;
     ideal_slots = islots;
     scratch_ints = sints;
+    inject.clear(); inject_off.clear();
+    bool any = false;
+    for (auto& v : inject_unit) any = any || !v.empty();
+    if (any) {
+        inject_off.assign(2 * units.size(), -1);
+        for (size_t u = 0; u < units.size(); u++) {
+            inject_off[2 * u + 1] = 0;
+            if (u < inject_unit.size() && !inject_unit[u].empty()) {
+                inject_off[2 * u] = (int64_t)inject.size();
+                inject_off[2 * u + 1] = (int64_t)inject_unit[u].size();
+                inject.insert(inject.end(), inject_unit[u].begin(), inject_unit[u].end());
+            }
+        }
+    }
 }
 
 }  // namespace ambi

@@ -23,6 +23,10 @@ struct HostBatch {
     int64_t result_bytes = 0, ideal_slots = 0, scratch_ints = 0;
     int max_n = 0, max_m = 0, max_k = 0, max_bkp = 0, max_path = 0, max_out = 0;
     int ideal_cap = kDefaultIdealCap;
+    // diagnostics hook (ambi_batch_debug_inject_validity): verdict overrides per unit, see BatchArgs::inject_valid
+    std::vector<int8_t> inject;
+    std::vector<int64_t> inject_off;        // [U][2] {offset or -1, count}; filled by finalize()
+    std::vector<std::vector<int8_t>> inject_unit;
 
     // Raw unit: local ids 1..n_seg, junctions already restricted to the unit.  Returns unit index or negative Status.
     int add_unit(int n_seg, int seg_base, const double* cn_local /*[n_seg], id 1 first*/, int n_junc, const int32_t* j_src,

@@ -399,6 +399,16 @@ AMBI_HD void load_first_work(const G& g, const BatchArgs& A, int u, const FirstW
     g.sync();
 }
 
+// diagnostics hook (BatchArgs::inject_valid): the verdict of order nidx in the given orientation, or `v` itself
+AMBI_HD int injected_verdict(const BatchArgs& A, int u, int64_t R, int64_t nidx, bool forwardDir, int v) {
+    if (!A.inject_valid) return v;
+    const int64_t off = A.inject_off[2 * (int64_t)u], len = A.inject_off[2 * (int64_t)u + 1];
+    const int64_t at = (forwardDir ? 0 : R) + nidx;
+    if (off < 0 || at >= len) return v;
+    const int x = A.inject_valid[off + at];
+    return x == 127 ? v : x;
+}
+
 template <class G>
 AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     UnitOut* out = unit_out(A.results, u);
@@ -430,6 +440,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
             g.sync();
             int Lo = 0;
             int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo, A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
+            v = injected_verdict(A, u, R, nidx, forwardDir, v);
             evaluated++;
             if (v < 0) { status = v; found = -2; break; }
             if (v == 1) { found = nidx; found_fwd = forwardDir ? 1 : 0; L = Lo; status = ST_OK; break; }
@@ -468,7 +479,129 @@ AMBI_HD int eval_indexed(const G& g, const BatchArgs& A, int u, const FirstWork&
     for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * row_stride(K) + d];
     g.sync();
     InvMap inv{W.inv_src, W.inv_tgt};
-    return eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);
+    const int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);
+    return injected_verdict(A, u, out->num_orders, nidx, forwardDir, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parallel search for the first valid order (units whose sequential scan ran out of budget): the orders of a unit are
+// cut into chunks, one group per chunk, in any order and concurrently.  The reference's scan (LGM.cpp:3519-3696) stops
+// at the FIRST order that is valid -- or on which it reads out of bounds -- so the result is the minimum over the
+// chunks of {index of a valid order} and of {index of an undefined order}, whichever is smaller; orders behind a known
+// hit are skipped.  One pass = one orientation.
+// ---------------------------------------------------------------------------------------------
+struct SearchSlot {
+    int64_t found;      // least index of a valid order seen so far (kSearchNone: none)
+    int64_t err_key;    // least {index * 256 + (-status)} of an order that ended in an error status (kSearchNone: none)
+};
+constexpr int64_t kSearchNone = 0x7fffffffffffffffll;
+AMBI_HD void atomic_min_i64(int64_t* p, int64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);   // values are non-negative
+#else
+    if (v < *p) *p = v;
+#endif
+}
+AMBI_HD int64_t load_now_i64(const int64_t* p) { return *reinterpret_cast<const volatile int64_t*>(p); }
+// first index that can no longer be the answer of this pass
+AMBI_HD int64_t search_limit(int64_t found, int64_t err_key) {
+    const int64_t e = err_key == kSearchNone ? kSearchNone : (err_key >> 8);
+    return found < e ? found : e;
+}
+
+template <class G>
+AMBI_HD void stage_search_chunk(const G& g, const BatchArgs& A, int u, const FirstWork& W, int64_t first, int chunk, bool forward, SearchSlot* slot) {
+    const int64_t R = unit_out(A.results, u)->num_orders;
+    for (int64_t n = first; n < first + chunk && n < R; n++) {
+        const int64_t lim = (int64_t)g.bcast_u64((uint64_t)search_limit(load_now_i64(&slot->found), load_now_i64(&slot->err_key)), 0);
+        if (n >= lim) break;
+        int L = 0;
+        const int v = eval_indexed(g, A, u, W, n, forward, &L);
+        if (v < 0) { if (g.tid() == 0) atomic_min_i64(&slot->err_key, n * 256 + (int64_t)(-v)); break; }
+        if (v == 1) { if (g.tid() == 0) atomic_min_i64(&slot->found, n); break; }
+    }
+    g.sync();
+}
+
+// after a pass of the search: the unit's verdict, or nothing when the pass found nothing and the other orientation is
+// still to come.  `work`: first_work_bytes of group memory.
+template <class G>
+AMBI_HD void stage_resolve(const G& g, const BatchArgs& A, int u, uint8_t* work, const SearchSlot* slot, bool forward, int pass) {
+    UnitOut* out = unit_out(A.results, u);
+    if (out->status != ST_PENDING) return;
+    const UnitIn& U = A.units[u];
+    const int64_t R = out->num_orders;
+    const int64_t f = slot->found, ek = slot->err_key;
+    if (ek != kSearchNone && (ek >> 8) < f) {   // the reference meets the undefined order before any valid one
+        if (g.tid() == 0) { out->status = -(int32_t)(ek & 255); out->evaluated = (int32_t)(pass * R + (ek >> 8) + 1); }
+        return;
+    }
+    if (f == kSearchNone) {
+        if (pass == 1 && g.tid() == 0) { out->status = ST_NO_VALID_ORDER; out->evaluated = (int32_t)(2 * R); }
+        return;
+    }
+    FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+    load_first_work(g, A, u, W);
+    int L = 0;
+    const int v = eval_indexed(g, A, u, W, f, forward, &L);   // materialise the winner's breakpoints
+    const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    cell_t* dst = reinterpret_cast<cell_t*>(A.results + U.res_off + Lay.bkp);
+    for (int i = g.tid(); i < L; i += g.size()) dst[i] = W.bkp[i];
+    if (g.tid() == 0) {
+        out->status = (v == 1) ? ST_OK : ST_ERR_REF_UB;
+        out->first_valid = f; out->first_forward = forward ? 1 : 0; out->bkp_len = L;
+        out->evaluated = (int32_t)(pass * R + f + 1);
+    }
+    g.sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// --all (LGM.cpp:3672-3695): every order of a unit is evaluated in one orientation (pass 0: the first orientation,
+// pass 1: the flipped one, run only when the LAST order of pass 0 is invalid, :3691-3695).  Fused enumerate + evaluate:
+// a group takes the 64 consecutive orders [64c, 64c+64) of a unit, its threads UNRANK them from the order-ideal automaton
+// into group memory (the order table in HBM is not read), the group assembles them one after the other and leaves ONE
+// 64-bit word of the unit's validity bitmap.  `rows`: 64 * kFirstRowStride bytes of group memory.
+// ---------------------------------------------------------------------------------------------
+AMBI_HD int64_t all_words(int64_t R) { return (R + 63) >> 6; }
+AMBI_HD bool all_pass0_last_valid(const BatchArgs& A, int u, int64_t R) {
+    return R > 0 && ((A.all_bits[A.all_off[u] + ((R - 1) >> 6)] >> ((R - 1) & 63)) & 1ull) != 0;
+}
+template <class G>
+AMBI_HD void stage_all_chunk(const G& g, const BatchArgs& A, int u, const FirstWork& W, uint8_t* rows, int64_t c, int pass) {
+    const UnitOut* out = unit_out(A.results, u);
+    const UnitIn& U = A.units[u];
+    const int K = out->K;
+    const int64_t R = out->num_orders;
+    const bool fwd0 = !(A.flags & FLAG_REVERSED), forward = pass == 0 ? fwd0 : !fwd0;
+    const AutoView V = auto_view(unit_ideal_table(A, u));
+    const int64_t first = c * 64;
+    const int cnt = (int)(R - first < 64 ? R - first : 64);
+    for (int i = g.tid(); i < cnt; i += g.size()) (void)order_unrank(V, K, (uint64_t)(first + i), rows + (int64_t)i * kFirstRowStride);
+    g.sync();
+    const InvMap inv{W.inv_src, W.inv_tgt};
+    uint64_t word = 0;
+    int undefined = 0;
+    for (int i = 0; i < cnt; i++) {
+        int L = 0;
+        int v = eval_order(g, *W.dag, rows + (int64_t)i * kFirstRowStride, forward, inv, W.bkp, U.bkp_cap, &L);
+        v = injected_verdict(A, u, R, first + i, forward, v);
+        if (v == 1) word |= 1ull << i;
+        else if (v < 0) undefined = 1;
+        g.sync();
+    }
+    if (g.tid() == 0) {
+        A.all_bits[A.all_off[u] + (int64_t)pass * all_words(R) + c] = word;
+        if (word) atomic_add_i32(A.all_count + 2 * (int64_t)u + pass, popc64(word));
+        if (undefined) atomic_add_i32(A.all_flags + u, 1);
+    }
+}
+// header of a unit after both passes: all orders of the executed passes were evaluated; undefined orders refuse the unit
+AMBI_HD void all_finalize_unit(const BatchArgs& A, int u) {
+    UnitOut* out = unit_out(A.results, u);
+    if (A.all_off[u + 1] == A.all_off[u]) return;   // unit without a map (not reconstructed)
+    const int64_t R = out->num_orders;
+    out->evaluated = (int32_t)(all_pass0_last_valid(A, u, R) ? R : 2 * R);
+    if (A.all_flags[u]) out->status = ST_ERR_REF_UB;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -112,6 +112,15 @@ int ambi_batch_size(const ambi_batch_t* b, int32_t* n_units);
  * first-valid scan budget, number of lanes the enumerate kernel spreads the order-table rows over. */
 int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ideal_cap, int32_t first_budget, int32_t target_lanes);
 
+/* Diagnostics hook, not part of the drop-in path (the reference has nothing like it).  Replaces, for one unit, the
+ * OUTCOME of evaluating an order (getBFB's per-order body, LGM.cpp:3519-3658) by a given verdict, so that the control
+ * flow around it -- scan budget, parallel search for the minimum index, orientation flip (LGM.cpp:3686-3695), --all --
+ * can be exercised at places no known input reaches.  verdicts[0..R) = orders in the "forward seed"
+ * orientation, verdicts[R..2R) = "reversed seed"; 1 valid, 0 invalid, a negative AMBI_ERR_* code, 127 = evaluate as
+ * usual.  Call after the unit was added and before ambi_batch_upload; the breakpoints of a "valid" order are those the
+ * real assembly leaves. */
+int ambi_batch_debug_inject_validity(ambi_batch_t* b, int32_t unit, const int8_t* verdicts, int64_t count);
+
 /* Packs the units and copies the inputs to HBM on the current device (inputs stay resident across runs). */
 int ambi_batch_upload(ambi_batch_t* b);
 /* Enqueues one pass of the whole pipeline over the batch on `hip_stream` (a hipStream_t; NULL = default stream).

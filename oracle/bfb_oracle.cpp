@@ -648,6 +648,7 @@ void getBFB(const Graph& g, const std::vector<std::vector<int>>& orders, const D
                 std::vector<int> temp; expandBkp(bkpPath, temp);
                 log.push_back(formatPath(g, temp));
                 res.allPaths.push_back(temp);
+                res.allEvalIdx.push_back(res.evaluated - 1);
             } else {
                 log.push_back(formatPath(g, res.path));
                 break;

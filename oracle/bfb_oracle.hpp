@@ -114,6 +114,7 @@ void allTopologicalOrders(const Dag& dag, std::vector<std::vector<int>>& orders,
 struct BfbResult {
     std::vector<int> path;                         // first valid assembly (LGM.cpp:3660-3671)
     std::vector<std::vector<int>> allPaths;        // --all: every valid order, in print order
+    std::vector<long> allEvalIdx;                  // --all: for every entry of allPaths, the 0-based count of evaluations before it (pass * R + order index)
     std::vector<int> bkpFirst;                     // breakpoint path of the first valid order after imperfectFBI
     long firstValidOrder = -1;                     // index in `orders`
     int firstValidOrientationForward = -1;         // 1 forward seed, 0 reversed seed

@@ -94,6 +94,7 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
         o << ",\"bkp\":"; jarr(o, s.bfb.bkpFirst);
         o << ",\"path\":"; jarr(o, s.bfb.path);
         o << ",\"all_paths\":"; jarr2(o, s.bfb.allPaths);
+        o << ",\"all_eval_idx\":"; jarr(o, s.bfb.allEvalIdx);
         o << ",\"indel_printed\":" << (s.indelPrinted ? "true" : "false");
         o << ",\"path_indel\":"; jarr(o, s.pathAfterIndel);
         o << "}";

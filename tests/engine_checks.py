@@ -374,3 +374,85 @@ def check_max_sizes(lib, oracle, workdir):
     b.upload(); b.run(0); b.download()
     assert b.unit_result(0)["status"] == -14
     b.close(); g.close()
+
+
+def check_injected_validity(lib, oracle, workdir):
+    """Control flow around the per-order evaluation of getBFB (LGM.cpp:3519-3696) at places no known input reaches.
+
+    An exhaustive search (tests/tools/search_mixed_validity.py: every element set of up to 5 patterns/loops over 4 and 5
+    segments, both orientations, 360 000+ runs of the oracle) found NO unit whose orders differ in validity, so on real
+    inputs the first valid order is always order 0 of one of the two passes.  The scan budget, the parallel search for
+    the minimum index, the error-before-valid rule, the orientation flip and --all are therefore driven here through the
+    diagnostics hook ambi_batch_debug_inject_validity: verdicts are injected, everything else (orders, breakpoints,
+    paths) is the real thing and is compared with the oracle's --all output for the same order."""
+    from ambigram_amd import synth
+    s = synth.make_sample(48, 100, "wide", 9, seed=9100)
+    lh, sols = s.write(workdir, "inj")
+    of = oracle.run_bfb(lh, sols, all_=True)["chr"][0]
+    orv = oracle.run_bfb(lh, sols, all_=True, reversed_=True)["chr"][0]
+    R = of["num_orders"]
+    assert R == 70 and len(of["all_paths"]) == R and len(orv["all_paths"]) == R      # every order valid in both orientations
+    E = -12    # AMBI_ERR_REF_UB
+
+    def run(fwd, rev, flags=0, budget=4):
+        g = api.Graph(lib, lh)
+        b = api.Batch(lib)
+        b.configure(first_budget=budget)
+        b.add_chromosome_sol(g, 0, sols[0])
+        b.debug_inject_validity(0, list(fwd) + list(rev))
+        b.upload(); b.run(flags); b.download()
+        return g, b, b.unit_result(0)
+
+    zeros = [0] * R
+    mid = R // 2
+    cases = [
+        # (forward verdicts, reversed verdicts, expected (status, first_valid, first_forward, evaluated))
+        ("hit at 1 (inside the scan budget)", [0, 1] + [127] * (R - 2), zeros, (0, 1, 1, 2)),
+        ("hit mid-table, later orders valid too", [0] * mid + [1] * (R - mid), zeros, (0, mid, 1, mid + 1)),
+        ("hit at the last order", [0] * (R - 1) + [1], zeros, (0, R - 1, 1, R)),
+        ("flip, hit at 3", zeros, [0, 0, 0, 1] + [1] * (R - 4), (0, 3, 0, R + 4)),
+        ("flip, hit at the last order", zeros, [0] * (R - 1) + [1], (0, R - 1, 0, 2 * R)),
+        ("no valid order", zeros, zeros, (api.ST_NO_VALID_ORDER, -1, -1, 2 * R)),
+        ("valid at 5 before undefined at 10", [0] * 5 + [1] + [0] * 4 + [E] + [1] * (R - 11), zeros, (0, 5, 1, 6)),
+        ("undefined at 5 before valid at 10", [0] * 5 + [E] + [0] * 4 + [1] * (R - 10), zeros, (E, -1, -1, 6)),
+        ("undefined in the flipped pass before its first valid order", zeros, [0] * 20 + [E] + [0] * 9 + [1] * (R - 30), (E, -1, -1, R + 21)),
+        ("valid and undefined in the same chunk, valid first", [0] * 33 + [1, E] + [0] * (R - 35), zeros, (0, 33, 1, 34)),
+    ]
+    for name, fwd, rev, want in cases:
+        for budget in (4, 64, 1):
+            g, b, r = run(fwd, rev, budget=budget)
+            got = (r["status"], r["first_valid"], r["first_forward"], r["evaluated"])
+            if want[0] < 0:
+                assert got[0] == want[0] and got[3] == want[3], (name, budget, got, want)
+            else:
+                assert got == want, (name, budget, got, want)
+            if want[0] == 0:      # the winner's path is the oracle's path of that very order and orientation
+                ref = (of if want[2] == 1 else orv)["all_paths"][want[1]]
+                assert b.unit_path(0, 0).tolist() == ref, (name, budget)
+            b.close(); g.close()
+    # --all: bitmaps, counts, flip rule and `evaluated` with mixed verdicts
+    import random
+    rng = random.Random(5)
+    for last_valid in (True, False):
+        fwd = [rng.randint(0, 1) for _ in range(R)]
+        rev = [rng.randint(0, 1) for _ in range(R)]
+        fwd[0] = 1                       # the default-mode scan finds order 0 (the unit's ordinary results)
+        fwd[-1] = 1 if last_valid else 0
+        g, b, r = run(fwd, rev, flags=api.FLAG_ALL, budget=64)
+        assert r["status"] == 0 and r["evaluated"] == (R if last_valid else 2 * R), (last_valid, r)
+        i0 = b.all_orders(0, 0).tolist()
+        i1 = b.all_orders(0, 1).tolist()
+        assert i0 == [i for i in range(R) if fwd[i]], last_valid
+        assert i1 == ([] if last_valid else [i for i in range(R) if rev[i]]), last_valid
+        got = b.all_paths(0, 0, 0, len(i0), 4096)
+        assert [p.tolist() for p in got] == [of["all_paths"][i] for i in i0]
+        if i1:
+            got = b.all_paths(0, 1, 0, len(i1), 4096)
+            assert [p.tolist() for p in got] == [orv["all_paths"][i] for i in i1]
+        b.close(); g.close()
+    # --all with an undefined order: the unit is refused
+    fwd = [1] * R
+    fwd[40] = E
+    g, b, r = run(fwd, [1] * R, flags=api.FLAG_ALL, budget=64)
+    assert r["status"] == E, r
+    b.close(); g.close()

@@ -4,6 +4,8 @@
 // stage logic, the packing, the result-blob layout and the C ABI against the oracle without a GPU, and lets the
 // sanitizers run over the kernel code on the CPU.  It is built into tests/hostsim/libambigram_hostsim.so only;
 // the product library libambigram_hip.so does not contain it and nothing in ambigram_amd/ loads it by default.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -73,6 +75,8 @@ class HostSimBackend : public Backend {
         A_.blk_off = blk_off_.data(); A_.rows_per_lane = rows_per_lane_.data();
         A_.n_pending = &n_pending_; A_.orders_needed = &orders_needed_;
         A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
+        A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
+        A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
     }
 
     void enumerate_all() {
@@ -139,9 +143,14 @@ class HostSimBackend : public Backend {
         }
     }
 
-    // slow path of the first-valid search: all orders, forward pass then flipped pass (LGM.cpp:3519-3696)
+    // slow path of the first-valid search (LGM.cpp:3519-3696): the engine's own chunked search (stage_search_chunk /
+    // stage_resolve), the chunks taken in the order AMBI_HOSTSIM_SEARCH_ORDER asks for -- "asc" (default), "desc" (a late
+    // chunk always reports before an early one) or "shuffle" -- which is what concurrency on the GPU amounts to.
     void search_pending() {
         HostGroup g;
+        const char* ord = getenv("AMBI_HOSTSIM_SEARCH_ORDER");
+        const int mode = !ord ? 0 : (!strcmp(ord, "desc") ? 1 : (!strcmp(ord, "shuffle") ? 2 : 0));
+        const int chunk = 16;
         for (size_t u = 0; u < units_.size(); u++) {
             UnitOut* out = unit_out(A_.results, (int)u);
             if (out->status != ST_PENDING) continue;
@@ -149,25 +158,20 @@ class HostSimBackend : public Backend {
             std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
             FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
             load_first_work(g, A_, (int)u, W);
-            const int64_t R = out->num_orders;
+            const int64_t R = out->num_orders, nchunks = (R + chunk - 1) / chunk;
+            std::vector<int64_t> order((size_t)nchunks);
+            for (int64_t c = 0; c < nchunks; c++) order[(size_t)c] = mode == 1 ? nchunks - 1 - c : c;
+            if (mode == 2) { uint64_t x = 88172645463325252ull + u; for (int64_t c = nchunks - 1; c > 0; c--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(order[(size_t)c], order[(size_t)(x % (uint64_t)(c + 1))]); } }
             bool fwd = !(A_.flags & FLAG_REVERSED);
-            int status = ST_NO_VALID_ORDER; int64_t found = -1; int L = 0; int64_t evaluated = 0; int found_fwd = -1;
-            for (int pass = 0; pass < 2 && found < 0; pass++) {
-                for (int64_t n = 0; n < R; n++) {
-                    int Lo = 0;
-                    int v = eval_indexed(g, A_, (int)u, W, n, fwd, &Lo);
-                    evaluated++;
-                    if (v < 0) { status = v; found = -2; break; }
-                    if (v == 1) { found = n; found_fwd = fwd ? 1 : 0; L = Lo; status = ST_OK; break; }
+            for (int pass = 0; pass < 2 && out->status == ST_PENDING; pass++) {
+                SearchSlot slot{kSearchNone, kSearchNone};
+                for (int64_t c : order) {
+                    if (c * chunk >= search_limit(slot.found, slot.err_key)) continue;   // as ambi_search_kernel
+                    stage_search_chunk(g, A_, (int)u, W, c * chunk, chunk, fwd, &slot);
                 }
-                if (found == -2) break;
-                if (found < 0) fwd = !fwd;
-            }
-            out->status = status; out->evaluated = (int32_t)evaluated;
-            if (status == ST_OK) {
-                UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-                memcpy(A_.results + U.res_off + Lay.bkp, W.bkp, (size_t)L * 2);
-                out->first_valid = found; out->first_forward = found_fwd; out->bkp_len = L;
+                std::vector<uint8_t> work2((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
+                stage_resolve(g, A_, (int)u, work2.data(), &slot, fwd, pass);
+                fwd = !fwd;
             }
         }
     }
@@ -210,41 +214,48 @@ class HostSimBackend : public Backend {
         if (flags & FLAG_ALL) compute_all();
         return 0;
     }
-    // --all: same protocol as the HIP backend (validity of every order per pass, lists on the host)
+    // --all: the engine's fused unrank + evaluate stage (stage_all_chunk), one 64-order chunk after the other; bitmaps,
+    // counts and flags as the HIP backend keeps them
     std::vector<std::vector<int64_t>> all_idx_[2];
+    std::vector<uint64_t> all_bits_; std::vector<int64_t> all_off_; std::vector<int32_t> all_count_, all_flags_;
     void compute_all() {
         HostGroup g;
         const int Un = (int)units_.size();
         all_idx_[0].assign(Un, {}); all_idx_[1].assign(Un, {});
-        const bool fwd0 = !(A_.flags & FLAG_REVERSED);
+        all_off_.assign(Un + 1, 0);
         for (int u = 0; u < Un; u++) {
-            UnitOut* out = unit_out(A_.results, u);
-            if (out->status != ST_OK || out->num_orders <= 0 || out->order_off < 0) continue;
-            const UnitIn& U = units_[u];
-            std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
-            FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
-            load_first_work(g, A_, u, W);
-            const int64_t R = out->num_orders;
-            int evaluated = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                const bool fwd = pass == 0 ? fwd0 : !fwd0;
-                int last = 0;
-                for (int64_t n = 0; n < R; n++) {
-                    int L = 0;
-                    const int v = eval_indexed(g, A_, u, W, n, fwd, &L);
-                    if (v == 1) all_idx_[pass][u].push_back(n);
-                    else if (v < 0) out->status = ST_ERR_REF_UB;
-                    last = v;
-                }
-                evaluated += (int)R;
-                if (last == 1) break;
+            const UnitOut* out = unit_out(A_.results, u);
+            const bool live = out->status == ST_OK && out->num_orders > 0 && out->num_orders < (int64_t)kCountSat;
+            all_off_[u + 1] = all_off_[u] + (live ? 2 * all_words(out->num_orders) : 0);
+        }
+        all_bits_.assign((size_t)all_off_[Un] + 1, 0); all_count_.assign(2 * (size_t)Un, 0); all_flags_.assign((size_t)Un, 0);
+        A_.all_bits = all_bits_.data(); A_.all_off = all_off_.data(); A_.all_count = all_count_.data(); A_.all_flags = all_flags_.data();
+        for (int pass = 0; pass < 2; pass++) {
+            for (int u = 0; u < Un; u++) {
+                if (all_off_[u + 1] == all_off_[u]) continue;
+                const UnitIn& U = units_[u];
+                const int64_t R = unit_out(A_.results, u)->num_orders;
+                if (pass == 1 && all_pass0_last_valid(A_, u, R)) continue;
+                std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap)), rows(64 * kFirstRowStride);
+                FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+                load_first_work(g, A_, u, W);
+                for (int64_t c = 0; c < all_words(R); c++) stage_all_chunk(g, A_, u, W, rows.data(), c, pass);
             }
-            out->evaluated = evaluated;
+        }
+        for (int u = 0; u < Un; u++) {
+            all_finalize_unit(A_, u);
+            if (all_off_[u + 1] == all_off_[u]) continue;
+            const int64_t nw = all_words(unit_out(A_.results, u)->num_orders);
+            for (int ps = 0; ps < 2; ps++)
+                for (int64_t w = 0; w < nw; w++) {
+                    uint64_t x = all_bits_[(size_t)(all_off_[u] + ps * nw + w)];
+                    while (x) { all_idx_[ps][u].push_back(w * 64 + __builtin_ctzll(x)); x &= x - 1; }
+                }
         }
     }
     int all_count(int unit, int pass, int64_t* count) override {
         if (pass < 0 || pass > 1 || unit < 0) return ST_ERR_BAD_INPUT;
-        if (count) *count = unit < (int)all_idx_[pass].size() ? (int64_t)all_idx_[pass][unit].size() : 0;
+        if (count) *count = (size_t)(2 * unit + pass) < all_count_.size() ? (int64_t)all_count_[2 * (size_t)unit + pass] : 0;
         return 0;
     }
     int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) override {

@@ -30,6 +30,12 @@ def test_random_decompositions_default_budget(hip_lib, oracle, workdir):
     ec.check_random_decompositions(hip_lib, oracle, workdir, range(200, 260))
 
 
+def test_injected_validity(hip_lib, oracle, workdir):
+    """first_valid > 0 / minimum index over concurrent chunks / error-before-valid / orientation flip / --all bitmaps,
+    with injected verdicts (no known input has mixed validity: DESIGN.md section 2)."""
+    ec.check_injected_validity(hip_lib, oracle, workdir)
+
+
 def test_edge_cases(hip_lib, oracle, workdir):
     ec.check_edge_cases(hip_lib, oracle, workdir)
 

@@ -1,5 +1,7 @@
 """CPU-only: the engine's SPMD stage code (the source the HIP kernels instantiate), the packing, the result-blob
 layout and the C ABI, executed on the 1-thread host group, against the oracle."""
+import pytest
+
 import engine_checks as ec
 
 
@@ -43,6 +45,14 @@ def test_large_lattice(hostsim_lib, oracle, workdir):
 def test_all_mode(hostsim_lib, oracle, workdir):
     st = ec.check_all_mode(hostsim_lib, oracle, workdir)
     assert st["multi"] > 0, st
+
+
+@pytest.mark.parametrize("search_order", ["asc", "desc", "shuffle"])
+def test_injected_validity(hostsim_lib, oracle, workdir, monkeypatch, search_order):
+    """first_valid > 0, minimum-index search, error-before-valid, orientation flip, --all bitmaps -- with injected
+    verdicts; the chunks of the parallel search are taken in ascending, descending and shuffled order."""
+    monkeypatch.setenv("AMBI_HOSTSIM_SEARCH_ORDER", search_order)
+    ec.check_injected_validity(hostsim_lib, oracle, workdir)
 
 
 def test_mixed_batch(hostsim_lib, oracle, workdir):
