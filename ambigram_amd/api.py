@@ -57,6 +57,7 @@ def _declare(L):
         "ambi_graph_read_juncs": (C.c_int, [vp, C.c_char_p]),
         "ambi_graph_log": (i64, [vp, C.c_char_p, i64]),
         "ambi_graph_props": (C.c_int, [vp, pi32, pi32, C.c_char_p, i64]),
+        "ambi_graph_components": (C.c_int, [vp, pi32, i32, pi32, i32]),
         "ambi_batch_create": (C.c_int, [_P(vp)]),
         "ambi_batch_destroy": (None, [vp]),
         "ambi_batch_add_chromosome": (C.c_int, [vp, vp, i32, i32, pi32, pi32, i32]),
@@ -225,6 +226,33 @@ class Graph:
         buf = C.create_string_buffer(256)
         self.lib.ambi_graph_props(self.h, C.byref(ins), C.byref(con), buf, 256)
         return ins.value, con.value, buf.value.decode()
+
+    def components(self):
+        """Components collected by read_juncs (readComponents, LGM.cpp:5096-5156)."""
+        ids, offs = np.zeros(1 << 16, np.int32), np.zeros(1 << 12, np.int32)
+        n = self.lib.ambi_graph_components(self.h, ids.ctypes.data_as(_P(C.c_int32)), len(ids), offs.ctypes.data_as(_P(C.c_int32)), len(offs))
+        return [ids[offs[c]:offs[c + 1]].tolist() for c in range(n)]
+
+    def chrom_name(self, seg_id):
+        buf = C.create_string_buffer(256)
+        self.lib.ambi_graph_chrom_name(self.h, seg_id, buf, 256)
+        return buf.value.decode()
+
+    def dump(self):
+        """The parsed graph in the shape of the reference-made fixtures tests/golden/graph_*.json."""
+        s, j = self.segments(), self.junctions()
+        sign = {1: "+", -1: "-"}
+        num = lambda x: int(x) if float(x).is_integer() else float(x)
+        return {
+            "ok": True, "err": "",
+            "segs": [[int(s["id"][i]), int(s["chr"][i]), self.chrom_name(int(s["id"][i])), int(s["start"][i]), int(s["end"][i]),
+                      num(s["cov"][i]), num(s["cn"][i])] for i in range(self.n_seg)],
+            "juncs": [[int(j["src"][i]), sign[int(j["sdir"][i])], int(j["tgt"][i]), sign[int(j["tdir"][i])], num(j["cov"][i]),
+                       num(j["cn"][i]), int(j["inferred"][i]), int(j["bounded"][i])] for i in range(self.n_junc)],
+            "sources": [self.chromosome(c)[0] for c in range(self.n_chr)],
+            "sinks": [self.chromosome(c)[1] for c in range(self.n_chr)],
+            "log": self.log(),
+        }
 
     def format_path(self, path):
         a, p = _arr(path, np.int32)

@@ -134,6 +134,17 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
     copy_text(g->g.main_chr, main_chr, cap);
     return 0;
 }
+int ambi_graph_components(const ambi_graph_t* g, int32_t* ids, int32_t ids_cap, int32_t* offsets, int32_t off_cap) {
+    if (!g) return AMBI_ERR_ARG;
+    int32_t at = 0, c = 0;
+    for (auto& comp : g->g.components) {
+        if (offsets && c < off_cap) offsets[c] = at;
+        for (int32_t v : comp) { if (ids && at < ids_cap) ids[at] = v; at++; }
+        c++;
+    }
+    if (offsets && c < off_cap) offsets[c] = at;
+    return c;
+}
 
 // ---- batch ----
 int ambi_batch_create(ambi_batch_t** out) {

@@ -129,8 +129,11 @@ def planted_mixed(rng, s, e, K, cn_choices=(1, 2)):
 
 
 def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperfect=0, n_del=0, n_dup=0,
-                translocations=0, name=None, prop=None, cn_choices=(1, 2), near_inv=0):
-    """Build one synthetic sample. `tier` in {chain, wide, skew, mixed}. For wide, K must be odd (K = 2k+1)."""
+                translocations=0, name=None, prop=None, cn_choices=(1, 2), near_inv=0, trx_insertions=0):
+    """Build one synthetic sample. `tier` in {chain, wide, skew, mixed}. For wide, K must be odd (K = 2k+1).
+    `translocations`: single inter-chromosome junctions (concatenation groups of translocationBFB, LGM.cpp:4099-4119);
+    `trx_insertions`: PAIRS of junctions that leave the main (first) chromosome and come back to it (insertion groups,
+    LGM.cpp:4120-4190), in random orientation and written from either side."""
     rng = random.Random(seed)
     name = name or "syn_n%d_m%d_%s_K%d_s%d" % (n_seg, n_junc, tier, K, seed)
     # chromosome ranges
@@ -229,6 +232,25 @@ def make_sample(n_seg=64, n_junc=128, tier="chain", K=9, seed=0, n_chr=1, imperf
         c0 = t % (n_chr - 1)
         (s0, e0), (s1, e1) = ranges[c0], ranges[c0 + 1]
         add(rng.randint(s0, e0), '+', rng.randint(s1, e1), '+', 1)
+    # insertion groups: main chromosome i -> other chromosome [x..y] -> main chromosome i+1
+    for t in range(trx_insertions):
+        if n_chr < 2:
+            break
+        (s0, e0) = ranges[0]
+        c = 1 + rng.randrange(n_chr - 1)
+        (s1, e1) = ranges[c]
+        i = rng.randint(s0, e0 - 1)
+        x = rng.randint(s1, e1)
+        y = rng.randint(x, e1)
+        if rng.random() < 0.5:
+            out, back = (i, '+', x, '+'), (y, '+', i + 1, '+')     # the stretch x..y inserted forward
+        else:
+            out, back = (i, '+', y, '-'), (x, '-', i + 1, '+')     # inserted reverse-complemented
+        for (a, ad, b, bd) in (out, back):
+            if rng.random() < 0.5:                                  # the same junction written from the other side
+                flip = {'+': '-', '-': '+'}
+                a, ad, b, bd = b, flip[bd], a, flip[ad]
+            add(a, ad, b, bd, 1)
     # padding: distant head-to-head inversions  H:i:+ H:j:-  (|i-j| >= 6) inside a chromosome.  The reference ignores
     # them in getJuncCN/getIndelBias, but indelBFB collects, groups and looks every one of them up in the path
     # (LGM.cpp:3750-3818).  Head-to-head junctions cannot chain with one another in its deque grouping (an edge
@@ -278,5 +300,5 @@ def config_sample(config, index=0, tier="chain", K=9):
     if config == 3:
         return make_sample(64, 128, tier, K, seed)
     if config == 4:
-        return make_sample(1024, 2048, tier, K, seed, n_chr=8, translocations=1, prop="PROP C2:chr1:chr2 M:chr1")
+        return make_sample(1024, 2048, tier, K, seed, n_chr=8, translocations=1, trx_insertions=3, prop="PROP C2:chr1:chr2 M:chr1")
     raise ValueError(config)

@@ -82,6 +82,10 @@ int ambi_graph_read_juncs(ambi_graph_t* g, const char* juncs_path);
 int64_t ambi_graph_log(const ambi_graph_t* g, char* buf, int64_t cap);
 /* PROP line: ins_mode / con_mode as in localhap.cpp:72-75, main chromosome name copied into main_chr[cap] */
 int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode, char* main_chr, int64_t cap);
+/* Components collected by ambi_graph_read_juncs (the `res` of readComponents, LocalGenomicMap.cpp:5096-5156, after its
+ * sort/unique): component c = ids[offsets[c] .. offsets[c+1]).  Returns the number of components; copies at most
+ * ids_cap ids and off_cap offsets (offsets needs count+1 entries). */
+int ambi_graph_components(const ambi_graph_t* g, int32_t* ids, int32_t ids_cap, int32_t* offsets, int32_t off_cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch of units.  A unit = one chromosome of one sample = one iteration of the loop localhap.cpp:111-265:

@@ -757,8 +757,9 @@ bool indelBFB(const Graph& gc, std::vector<int>& path, int startSegID, int endSe
 // Iterators become (container, index) pairs: container -1 = res, otherwise paths[chrId].
 // ------------------------------------------------------------------------------------------
 void translocationBFB(const Graph& g, std::vector<std::vector<int>>& paths, std::vector<int>& res,
-                      const std::string& mainChr, std::vector<std::string>& log) {
+                      const std::string& mainChr, std::vector<std::string>& log, std::vector<std::string>* trace) {
     log.push_back("BFB with translocation:");
+    auto note = [&](const char* what) { if (trace) trace->push_back(what); };
     auto segOf = [&](int v) -> const Seg* { for (auto& s : g.segs) if (s.id == std::abs(v)) return &s; return nullptr; };
     auto chrIdOf = [&](int v) { return segOf(v)->chrId; };
     auto chromOf = [&](int v) { return segOf(v)->chrom; };
@@ -798,15 +799,16 @@ void translocationBFB(const Graph& g, std::vector<std::vector<int>>& paths, std:
         if (group.size() == 2) {   // concatenation
             long pos1 = rfind(res, group[0]);
             if (pos1 < 0) { complementAll(group); pos1 = rfind(res, group[0]); }
-            if (pos1 < 0) continue;
+            if (pos1 < 0) { note("concat-skip"); continue; }
             res.erase(res.begin() + pos1 + 1, res.end());
             int id = chrIdOf(group[1]);
-            if (id < 0 || id >= (int)paths.size()) continue;
+            if (id < 0 || id >= (int)paths.size()) { note("concat-skip"); continue; }
             long pos2 = findFrom(paths[id], 0, group[1]);
             if (pos2 == (long)paths[id].size()) { complementAll(paths[id]); pos2 = findFrom(paths[id], 0, group[1]); }
-            if (pos2 == (long)paths[id].size()) continue;
+            if (pos2 == (long)paths[id].size()) { note("concat-skip"); continue; }
             res.insert(res.end(), paths[id].begin() + pos2, paths[id].end());
             startPos = 0;
+            note("concat");
         } else {   // insertion
             if (vid(group.front()) > vid(group.back())) complementAll(group);
             struct It { int c; long i; };
@@ -834,14 +836,16 @@ void translocationBFB(const Graph& g, std::vector<std::vector<int>>& paths, std:
             };
             long flag;
             attempt(flag);
-            if (pos.size() < group.size() || pos.back().i == (long)res.size()) { complementAll(group); attempt(flag); }
-            if (pos.size() < group.size() || pos.back().i == (long)res.size()) continue;
+            bool retried = false;
+            if (pos.size() < group.size() || pos.back().i == (long)res.size()) { complementAll(group); attempt(flag); retried = true; }
+            if (pos.size() < group.size() || pos.back().i == (long)res.size()) { note("insert-skip"); continue; }
             std::vector<int> temp;
             for (size_t i = 1; i + 1 < pos.size(); i += 2) {
                 const std::vector<int>& pp = paths[pos[i].c];
                 if (pos[i].i <= pos[i + 1].i) temp.insert(temp.end(), pp.begin() + pos[i].i, pp.begin() + pos[i + 1].i + 1);
             }
-            if (temp.empty()) continue;
+            if (temp.empty()) { note("insert-skip"); continue; }
+            note(retried ? "insert-retry" : "insert");
             long a = pos.front().i + 1, b = pos.back().i;
             if (a <= b) res.erase(res.begin() + a, res.begin() + b);
             res.insert(res.begin() + a, temp.begin(), temp.end());
@@ -995,7 +999,7 @@ RunResult runBfb(const RunOptions& opt) {
     if (props.insMode == 2 || props.conMode == 2) {
         if (props.mainChr.empty()) { R.err = "BFB-TRX without M:<chr> (reference segfaults)"; return R; }
         R.trxRun = true;
-        translocationBFB(g, R.paths, R.trxPath, props.mainChr, R.log);
+        translocationBFB(g, R.paths, R.trxPath, props.mainChr, R.log, &R.trxTrace);
         synthesizeOutputJuncs(R.trxPath, R.outJuncs, false);
     }
     R.ok = true;

@@ -136,8 +136,10 @@ bool indelBFB(const Graph& g, std::vector<int>& path, int startID, int endID, st
 // LGM.cpp:3411-3429
 std::string formatPath(const Graph& g, const std::vector<int>& path);
 // LGM.cpp:4052-4193
+// `trace` (optional, test diagnostics): which branch every junction group took: "concat", "concat-skip", "insert",
+// "insert-retry" (second attempt with the reverse-complemented group succeeded), "insert-skip"
 void translocationBFB(const Graph& g, std::vector<std::vector<int>>& paths, std::vector<int>& res,
-                      const std::string& mainChr, std::vector<std::string>& log);
+                      const std::string& mainChr, std::vector<std::string>& log, std::vector<std::string>* trace = nullptr);
 
 struct OutJunc { int u, v; int count; };           // localhap.cpp:267-293
 void synthesizeOutputJuncs(const std::vector<int>& path, std::vector<OutJunc>& out, bool increase);
@@ -172,7 +174,7 @@ struct RunResult {
     std::vector<std::string> log;                  // stdout lines, in order
     std::vector<ChrStage> chr;
     std::vector<std::vector<int>> paths;
-    std::vector<int> trxPath; bool trxRun = false;
+    std::vector<int> trxPath; bool trxRun = false; std::vector<std::string> trxTrace;
     std::vector<OutJunc> outJuncs;
     std::vector<int> targetCN;
     int pathLen = 0, cnSum = 0, maxCN = 0, numInv = 0;

@@ -70,6 +70,7 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
     for (size_t i = 0; i < R.log.size(); i++) { if (i) o << ','; jstr(o, R.log[i]); }
     o << "],\"paths\":"; jarr2(o, R.paths);
     o << ",\"trx_run\":" << (R.trxRun ? "true" : "false") << ",\"trx_path\":"; jarr(o, R.trxPath);
+    o << ",\"trx_trace\":["; for (size_t i = 0; i < R.trxTrace.size(); i++) { if (i) o << ','; jstr(o, R.trxTrace[i]); } o << "]";
     o << ",\"target_cn\":"; jarr(o, R.targetCN);
     o << ",\"recon_seconds\":" << R.reconSeconds << ",\"path_len\":" << R.pathLen << ",\"cn_sum\":" << R.cnSum << ",\"max_cn\":" << R.maxCN << ",\"num_inv\":" << R.numInv;
     o << ",\"out_juncs\":[";
@@ -142,13 +143,49 @@ char* oracle_ilp_json(const char* lh, const char* juncs, int chr, int junc_info,
     return dup(o.str());
 }
 
+// translocationBFB (LGM.cpp:4052-4193) alone on given per-chromosome paths: `paths` = chromosomes separated by ';', signed
+// segment ids separated by ','.  The graph's PROP line names the main chromosome.  JSON: result path, printed line, trace,
+// and the per-chromosome paths as the call left them (they may have been reverse-complemented in place).
+char* oracle_translocation_json(const char* lh, const char* paths) {
+    Graph g; std::string err;
+    std::ostringstream o;
+    bool ok = readGraph(lh, g, err) && calculateHapDepth(g, err);
+    if (!ok) { o << "{\"ok\":false}"; return dup(o.str()); }
+    calculateCopyNum(g);
+    Props props;
+    readBFBProps(lh, props);
+    std::vector<std::vector<int>> pp;
+    for (auto& chr : split(paths, ';')) {
+        pp.emplace_back();
+        for (auto& t : split(chr.c_str(), ',')) if (!t.empty()) pp.back().push_back(atoi(t.c_str()));
+    }
+    std::vector<int> res; std::vector<std::string> log, trace;
+    translocationBFB(g, pp, res, props.mainChr, log, &trace);
+    o << "{\"ok\":true,\"path\":"; jarr(o, res);
+    o << ",\"line\":"; jstr(o, log.empty() ? std::string() : log.back());
+    o << ",\"paths\":"; jarr2(o, pp);
+    o << ",\"trace\":["; for (size_t i = 0; i < trace.size(); i++) { if (i) o << ','; jstr(o, trace[i]); } o << "]}";
+    return dup(o.str());
+}
+
 // Parsed-graph dump (after calculateHapDepth/calculateCopyNum), same JSON shape as oracle/_ref's ref_graph_dump.
-char* oracle_graph_dump(const char* lh) {
+static char* graph_dump_impl(const char* lh, const char* juncs);
+char* oracle_graph_dump(const char* lh) { return graph_dump_impl(lh, nullptr); }
+// the same after readComponents(juncs) (LGM.cpp:5096-5156); the components come as an extra "components" member
+char* oracle_graph_dump_juncs(const char* lh, const char* juncs) { return graph_dump_impl(lh, juncs); }
+static char* graph_dump_impl(const char* lh, const char* juncs) {
     Graph g; std::string err;
     std::ostringstream o;
     o.precision(17);
     bool ok = readGraph(lh, g, err) && calculateHapDepth(g, err);
     if (ok) calculateCopyNum(g);
+    std::vector<std::vector<int>> components;
+    if (ok && juncs) {
+        for (size_t i = 0; i < g.sourceIds.size(); i++)
+            for (int j = g.sourceIds[i]; j <= g.sinkIds[i]; j++) g.segs[j - 1].partition = (int)i;
+        std::vector<std::string> clog;
+        readComponents(g, juncs, components, clog);
+    }
     o << "{\"ok\":" << (ok ? "true" : "false") << ",\"err\":"; jstr(o, err);
     o << ",\"segs\":[";
     for (size_t i = 0; i < g.segs.size(); i++) {
@@ -165,6 +202,7 @@ char* oracle_graph_dump(const char* lh) {
     }
     o << "],\"sources\":"; jarr(o, g.sourceIds);
     o << ",\"sinks\":"; jarr(o, g.sinkIds);
+    if (juncs) { o << ",\"components\":"; jarr2(o, components); }
     o << ",\"log\":[";
     for (size_t i = 0; i < g.log.size(); i++) { if (i) o << ','; jstr(o, g.log[i]); }
     o << "]}";

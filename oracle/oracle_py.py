@@ -58,8 +58,14 @@ def run_bfb(lh, sols, juncs="", reversed_=False, all_=False, junc_info=False, ke
     return out
 
 
-def graph_dump(lh):
-    return _take(lib().oracle_graph_dump(lh.encode()))
+def graph_dump(lh, juncs=None):
+    """Parsed graph (after calculateCopyNum); with `juncs` also after readComponents, plus its components."""
+    if juncs is None:
+        return _take(lib().oracle_graph_dump(lh.encode()))
+    L = lib()
+    L.oracle_graph_dump_juncs.restype = ctypes.c_void_p
+    L.oracle_graph_dump_juncs.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    return _take(L.oracle_graph_dump_juncs(lh.encode(), juncs.encode()))
 
 
 def ilp(lh, chr_=0, juncs="", junc_info=False, literal=False):
@@ -75,12 +81,22 @@ def ilp(lh, chr_=0, juncs="", junc_info=False, literal=False):
     return out
 
 
-def ref_graph_dump(lh):
-    """Parsed graph from the REAL reference graph model (oracle/_ref, container-only). None if unavailable."""
+def translocation(lh, paths):
+    """translocationBFB (LGM.cpp:4052-4193) alone: `paths` = list of per-chromosome paths (signed segment ids)."""
+    L = lib()
+    L.oracle_translocation_json.restype = ctypes.c_void_p
+    L.oracle_translocation_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    txt = ";".join(",".join(str(v) for v in p) for p in paths)
+    return _take(L.oracle_translocation_json(lh.encode(), txt.encode()))
+
+
+def ref_graph_dump(lh, juncs=None):
+    """Parsed graph from the REAL reference graph model (oracle/_ref, container-only). None if unavailable.
+    With `juncs`: after the graph-level effects of readComponents, driven through the reference's graph API."""
     exe = os.path.join(_HERE, "_ref", "ref_graph_dump")
     if not os.path.exists(exe):
         return None
-    out = subprocess.run([exe, lh], capture_output=True, text=True)
+    out = subprocess.run([exe, lh] + ([juncs] if juncs else []), capture_output=True, text=True)
     if out.returncode != 0:
         return {"ok": False, "err": "reference exited %d" % out.returncode}
     return json.loads(out.stdout.strip().splitlines()[-1])

@@ -5,10 +5,18 @@
 // API -- Graph(const char*) (Graph.cpp:36-49), calculateHapDepth (:312), calculateCopyNum (:369), getSegments,
 // getJunctions -- and prints the parsed graph as JSON in the shape of oracle_graph_dump() so the restated reader
 // (#1-#3 of SURVEY 8a) is pinned against the reference itself.  No reference source is copied into this repo.
+// With a second argument (a .juncs file) it also drives the GRAPH-LEVEL effects of LocalGenomicMap::readComponents
+// (LGM.cpp:5096-5156) through the reference's own graph API: for every strand / partition break of a line it builds the
+// probe junction, asks Graph::findJunction (Graph.cpp:501-511) and either Graph::addJunction (coverage =
+// Graph::getAvgCoverage(), copy number 1) or raises the found junction's copy number to 2 -- the calls LGM.cpp:5133-5141
+// makes, in that order.  The loop around those calls is this driver's (LocalGenomicMap.cpp itself cannot be compiled
+// here), so what this pins is the reference's matching rule, duplicate handling, coverage value and junction order.
 // LocalGenomicMap.cpp (the BFB stages) is NOT buildable here: it includes <coin/CbcModel.hpp> and
 // <coin/OsiClpSolverInterface.hpp>, which the image lacks.
+#include <fstream>
 #include <iostream>
 #include <sstream>
+#include <vector>
 
 #include "Graph.hpp"
 
@@ -22,6 +30,33 @@ int main(int argc, char** argv) {
     Graph* g = new Graph(argv[1]);
     g->calculateHapDepth();
     g->calculateCopyNum();
+    if (argc > 2) {
+        // partitions as localhap.cpp:90-98 sets them: segment ids source..sink of chromosome n
+        std::vector<Segment*>& src = *g->getMSources();
+        std::vector<Segment*>& snk = *g->getMSinks();
+        for (size_t n = 0; n < src.size(); n++)
+            for (int id = src[n]->getId(); id <= snk[n]->getId(); id++) g->getSegmentById(id)->setPartition((int)n);
+        std::ifstream in(argv[2]);
+        std::string text;
+        while (std::getline(in, text)) {
+            std::istringstream ls(text);
+            std::vector<int> ids; std::vector<char> strands;
+            std::string tok;
+            while (ls >> tok) { ids.push_back(std::stoi(tok.substr(0, tok.size() - 1))); strands.push_back(tok[tok.size() - 1]); }
+            for (size_t k = 1; k < ids.size(); k++) {
+                const bool brk = g->getSegmentById(ids[k - 1])->getPartition() != g->getSegmentById(ids[k])->getPartition() ||
+                                 strands[k - 1] != strands[k];
+                // (LGM.cpp:5118 compares with the segment at the last break; every token since that break lies on its
+                // chromosome -- a change would have been a break -- so comparing with the previous token is the same test)
+                if (!brk) continue;
+                Junction* probe = new Junction(g->getSegmentById(ids[k - 1]), g->getSegmentById(ids[k]), strands[k - 1], strands[k],
+                                               g->getAvgCoverage(), 1, 1, false, true, false);
+                Junction* hit = g->findJunction(probe);
+                if (hit == NULL) g->addJunction(ids[k - 1], strands[k - 1], ids[k], strands[k], g->getAvgCoverage(), 1, 1, false, true, false);
+                else if (hit->getWeight()->getCopyNum() < 2) hit->getWeight()->setCopyNum(2);
+            }
+        }
+    }
     std::cout.rdbuf(old);
 
     std::ostringstream o;

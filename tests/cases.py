@@ -35,6 +35,14 @@ def synthetic_cases(workdir, small_only=True):
     s = synth.make_sample(96, 200, "chain", 5, seed=11, n_chr=3, translocations=1, prop="PROP C2:chr1:chr2 M:chr1", name="multi3")
     lh, sols = s.write(workdir)
     out.append((s.name, lh, sols))
+    # BFB-TRX with insertion groups (junction pairs that leave the main chromosome and come back: LGM.cpp:4120-4190),
+    # alone and mixed with a concatenation; both PROP spellings
+    for seed in range(6):
+        s = synth.make_sample(72 + 8 * seed, 150, ("chain", "mixed", "wide")[seed % 3], 5, seed=40 + seed, n_chr=3 + seed % 2,
+                              translocations=seed % 2, trx_insertions=1 + seed % 3,
+                              prop=("PROP I2:chr1:chr2 M:chr1", "PROP C2:chr1:chr3 M:chr1")[seed % 2], name="trxins%d" % seed)
+        lh, sols = s.write(workdir)
+        out.append((s.name, lh, sols))
     return out
 
 

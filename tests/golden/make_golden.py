@@ -17,6 +17,12 @@ CASES = {
     "readme6": os.path.join(ROOT, "tests", "data", "readme6.lh"),
     "trx_c2": os.path.join(ROOT, "tests", "data", "trx_c2.lh"),
     "quirks": os.path.join(ROOT, "tests", "data", "quirks.lh"),
+    "quirks2": os.path.join(ROOT, "tests", "data", "quirks2.lh"),     # CRLF, virus segments, recomputed AVG_PLOIDY, 3 chromosomes
+}
+# (.lh, .juncs): the graph after the graph-level effects of readComponents, driven through the reference's graph API
+JUNCS_CASES = {
+    "readme6__juncs": (os.path.join(ROOT, "tests", "data", "readme6.lh"), os.path.join(ROOT, "tests", "data", "readme6.juncs")),
+    "quirks2__juncs": (os.path.join(ROOT, "tests", "data", "quirks2.lh"), os.path.join(ROOT, "tests", "data", "quirks2.juncs")),
 }
 
 
@@ -33,6 +39,12 @@ def main():
         f.write(s.lh_text)
     for name, path in cases.items():
         d = oracle_py.ref_graph_dump(path)
+        assert d and d["ok"], (name, d)
+        with open(os.path.join(out_dir, "graph_%s.json" % name), "w") as f:
+            json.dump(d, f, indent=0, sort_keys=True)
+        print("wrote graph_%s.json: %d segs, %d juncs" % (name, len(d["segs"]), len(d["juncs"])))
+    for name, (lh, juncs) in JUNCS_CASES.items():
+        d = oracle_py.ref_graph_dump(lh, juncs)
         assert d and d["ok"], (name, d)
         with open(os.path.join(out_dir, "graph_%s.json" % name), "w") as f:
             json.dump(d, f, indent=0, sort_keys=True)

@@ -60,3 +60,15 @@ def test_all_mode_prints_every_valid_order(oracle, workdir):
     c = r["chr"][0]
     assert c["num_orders"] == 6 and len(c["all_paths"]) >= 1
     assert c["all_paths"][0] == c["path"]
+
+
+def test_synthetic_cases_reach_the_insertion_branch(oracle, workdir):
+    """the multi-chromosome parity cases really run translocationBFB's insertion branch (LGM.cpp:4120-4190), not only the
+    concatenation one (VERDICT r1 weak #2)"""
+    import cases
+    from collections import Counter
+    seen = Counter()
+    for name, lh, sols in cases.synthetic_cases(workdir):
+        if name.startswith("trxins"):
+            seen.update(oracle.run_bfb(lh, sols)["trx_trace"])
+    assert seen["insert"] >= 10 and seen["concat"] >= 2, seen

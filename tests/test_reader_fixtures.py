@@ -1,0 +1,119 @@
+"""The PRODUCT's .lh / .juncs reader (ambigram_amd/csrc/lh_graph.cpp behind ambi_graph_*) against fixtures written by the
+REAL reference graph model compiled in the build container (tests/golden/make_golden.py -> oracle/_ref/ref_graph_dump:
+Graph.cpp:109-237 reader, :312-405 copy-number maths, :489-511/:592-597 duplicate rule, and -- for the *__juncs fixtures --
+Graph::findJunction / addJunction / getAvgCoverage as LocalGenomicMap::readComponents calls them, LGM.cpp:5133-5141).
+
+The reader is host code: the same source is linked into the host-simulation library (CPU run, every round) and into
+libambigram_hip.so (the `gpu` run checks the shipped binary)."""
+import json
+import os
+
+import pytest
+
+from ambigram_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+PLAIN = [("readme6", "tests/data/readme6.lh"), ("trx_c2", "tests/data/trx_c2.lh"), ("quirks", "tests/data/quirks.lh"),
+         ("quirks2", "tests/data/quirks2.lh"), ("syn24", "tests/golden/syn24.lh")]
+WITH_JUNCS = [("readme6__juncs", "tests/data/readme6.lh", "tests/data/readme6.juncs"),
+              ("quirks2__juncs", "tests/data/quirks2.lh", "tests/data/quirks2.juncs")]
+
+
+def _gold(name):
+    return json.load(open(os.path.join(GOLD, "graph_%s.json" % name)))
+
+
+def _check_plain(lib):
+    for name, lh in PLAIN:
+        g = api.Graph(lib, os.path.join(ROOT, lh))
+        assert g.dump() == _gold(name), name
+        g.close()
+
+
+def _check_juncs(lib):
+    for name, lh, juncs in WITH_JUNCS:
+        g = api.Graph(lib, os.path.join(ROOT, lh))
+        g.read_juncs(os.path.join(ROOT, juncs))
+        got, want = g.dump(), _gold(name)
+        # the reference driver captures the graph's stdout only; readComponents' own "a -> b" echo lines are the product's
+        got["log"] = [l for l in got["log"] if " -> " not in l]
+        assert got == want, name
+        g.close()
+
+
+def test_product_reader_against_reference_fixtures(hostsim_lib):
+    _check_plain(hostsim_lib)
+
+
+def test_product_juncs_reader_against_reference_fixtures(hostsim_lib):
+    _check_juncs(hostsim_lib)
+
+
+@pytest.mark.gpu
+def test_shipped_reader_against_reference_fixtures(hip_lib):
+    _check_plain(hip_lib)
+    _check_juncs(hip_lib)
+
+
+@pytest.mark.parametrize("name,lh,juncs", WITH_JUNCS)
+def test_oracle_juncs_reader_against_reference_fixtures(oracle, name, lh, juncs):
+    got = oracle.graph_dump(os.path.join(ROOT, lh), os.path.join(ROOT, juncs))
+    got.pop("components")
+    got["log"] = [l for l in got["log"] if " -> " not in l]
+    assert got == _gold(name)
+
+
+def test_components_hand_derived(hostsim_lib, oracle):
+    """readComponents on the README's .juncs example (README.md:173-177), walked by hand through LGM.cpp:5096-5156:
+
+      line 1  6+ 6- 5- 4- 3- 2- 2+   i=1: strands differ -> break, run [6] too short (i-lastIdx = 1 < 2, :5121), lastIdx=1
+                                     i=6: '-' -> '+'     -> break, run 6- 5- 4- 3- 2- has 5 ids -> component {2,3,4,5,6} (:5122-5125)
+                                     tail: [2+] alone, size-lastIdx = 1 -> nothing (:5145)
+      line 2  2- 2+ 3+ 4+ 5+ 6+ 6-   i=1: break, run [2-] too short; i=6: break, run 2+..6+ -> {2,3,4,5,6} again; tail [6-] nothing
+      line 3  6+ 6- 5- 4- 3-         i=1: break, run [6+] too short; tail 6- 5- 4- 3- -> component {3,4,5,6} (:5145-5150)
+      sort + unique (:5153-5155)     -> [[2,3,4,5,6], [3,4,5,6]]
+
+    Junction effects (:5127-5141): the breaks are 6+ -> 6- (three times) and 2- -> 2+ (twice).  2- -> 2+ is in the .lh
+    with copy number 2 (not < 2: untouched).  6+ -> 6- is NOT in the .lh (the file has 6- -> 6+, which is neither the
+    same edge nor its complement: the complement of 6+ -> 6- is itself) -> added with the graph's average coverage
+    (AVG_WHOLE_HOST_DP 30 * purity 1 / ploidy 2 * ploidy 2 = 30) and copy number 1 the first time, raised to 2 the
+    second time, untouched the third."""
+    lh, juncs = os.path.join(ROOT, "tests/data/readme6.lh"), os.path.join(ROOT, "tests/data/readme6.juncs")
+    g = api.Graph(hostsim_lib, lh)
+    g.read_juncs(juncs)
+    assert g.components() == [[2, 3, 4, 5, 6], [3, 4, 5, 6]]
+    j = g.junctions()
+    assert g.n_junc == 5
+    assert (int(j["src"][4]), int(j["sdir"][4]), int(j["tgt"][4]), int(j["tdir"][4]), float(j["cov"][4]), float(j["cn"][4])) == (6, 1, 6, -1, 30.0, 2.0)
+    assert [float(x) for x in j["cn"][:4]] == [2.0, 1.0, 2.0, 2.0]
+    g.close()
+    assert oracle.graph_dump(lh, juncs)["components"] == [[2, 3, 4, 5, 6], [3, 4, 5, 6]]
+
+
+def test_props_hand_derived(hostsim_lib, workdir):
+    """readBFBProps (LGM.cpp:3941-3987) walked by hand.  Tokens after PROP: 'M:x' -> mainChr = substr(2) (:3951-3952);
+    'I<d>:a:b' -> insMode = d, names from position 3 (:3954-3957); 'I:a:b' -> insMode = 2 (:3958); same for 'C' (:3965-3976).
+    Modes start at 0 (localhap.cpp:72-74) and a later PROP token of the same kind overwrites the mode."""
+    cases = [("PROP I2:chr3:chr5 M:chr3", (2, 0, "chr3")),
+             ("PROP C2:chr2:chr6 M:chr2", (0, 2, "chr2")),
+             ("PROP I:chr1:chr9 C:chr1:chr4 M:chr1 S:3:9", (2, 2, "chr1")),
+             ("PROP M:chrX", (0, 0, "chrX")),
+             ("", (0, 0, "")),
+             # TRX-BFB (modes 1) is the reference's undefined-behaviour path (Graph.cpp:25-34): parsed, then refused
+             ("PROP I1:chr3:chr5 M:chr3", -9),
+             ("PROP I:chr1:chr9 C1:chr1:chr4 M:chr1", -9)]
+    base = open(os.path.join(ROOT, "tests/data/readme6.lh")).read()
+    for i, (line, want) in enumerate(cases):
+        p = os.path.join(workdir, "props%d.lh" % i)
+        with open(p, "w") as f:
+            f.write(base + (line + "\n" if line else ""))
+        if isinstance(want, int):
+            with pytest.raises(api.AmbiError) as e:
+                api.Graph(hostsim_lib, p)
+            assert e.value.code == want, line
+            continue
+        g = api.Graph(hostsim_lib, p)
+        assert g.props() == want, line
+        g.close()
