@@ -991,10 +991,19 @@ class HipBackend : public Backend {
                 total += slice_bytes_[s];
             }
             if (total > arena_bytes_) {
-                HIP_CK(hipFree(d_arena_));
-                d_arena_ = nullptr;
-                arena_bytes_ = total;
-                HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
+                // the new arena first, the old one goes only when that worked: a failed growth leaves the batch as it was,
+                // and the units whose tables do not fit the old arena end with ORDERS_CAPACITY (plan kernel), one by one
+                uint8_t* fresh = nullptr;
+                if (hipMalloc((void**)&fresh, (size_t)total) == hipSuccess) {
+                    (void)hipFree(d_arena_);
+                    d_arena_ = fresh;
+                    arena_bytes_ = total;
+                } else {
+                    (void)hipGetLastError();
+                    fprintf(stderr, "ambigram_hip: order-table arena of %lld bytes not available; keeping %lld bytes (units beyond it report ORDERS_CAPACITY)\n",
+                            (long long)total, (long long)arena_bytes_);
+                    for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(15); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(15); }
+                }
                 bind(flags);
             }
             arena_checked_ = true;

@@ -13,6 +13,7 @@
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <sys/wait.h>
 #include <string>
 #include <vector>
 
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
     Args A = parse(argc, argv);
     if (A.help) {
         std::cout << "Local Haplotype constructer\nUsage:\n  Ambigram --op bfb --in_lh <file> --lp_prefix <name> [--juncdb <file> --junc_info true] "
-                     "[--reversed true] [--all true]\n";
+                     "[--reversed true] [--all true] [--solver_timeout <seconds>]\n";
         return 0;
     }
     const std::string op = A.kv.count("op") ? A.kv["op"] : "";
@@ -99,60 +100,91 @@ int main(int argc, char** argv) {
     std::vector<std::vector<int32_t>> paths(n_chr);
     std::vector<OutJ> out_acc;
     int num_inv = 0;
+    // Two batches for the whole sample, every chromosome a unit:
+    //   probe batch   -- localhap.cpp:136-170 for all chromosomes at once: junction CNs, bias, getIndelBias, shortcut;
+    //   solve         -- per chromosome, in order: ILP model -> <prefix>.lp/.mps -> `cbc` -> <prefix>.sol (the reference
+    //                    reuses the same file names for every chromosome, so each .sol is taken in right after its solve);
+    //   reconstruct batch -- localhap.cpp:222-262 for all chromosomes at once.
+    // This program's own stdout lines come out in the reference's order (per chromosome: the three ILP progress lines, then
+    // the path lines); they are held back until the reconstruct batch is done, so only the solver's own chatter, which
+    // the reference interleaves between them, moves to the front.
+    ambi_batch_t* probe; ambi_batch_create(&probe);
+    for (int c = 0; c < n_chr; c++)
+        if ((rc = ambi_batch_add_chromosome(probe, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
+    if ((rc = ambi_batch_upload(probe)) != 0 || (rc = ambi_batch_run(probe, 0, nullptr)) != 0 || (rc = ambi_batch_download(probe)) != 0)
+        return die(std::string("engine: ") + ambi_error_string(rc));
+    ambi_batch_t* b; ambi_batch_create(&b);
+    std::vector<std::string> head(n_chr);   // lines the reference prints before a chromosome's path lines
+    const double solver_timeout = A.kv.count("solver_timeout") ? atof(A.kv["solver_timeout"].c_str()) : 0;   // extension: seconds, 0 = none
     for (int c = 0; c < n_chr; c++) {
         int32_t s, e;
         ambi_graph_chromosome(g, c, &s, &e);
         const int n = e - s + 1;
-        // localhap.cpp:136-170: junction CNs, bias, getIndelBias, shortcut -- a solution-less probe of this chromosome
-        ambi_batch_t* probe; ambi_batch_create(&probe);
-        if ((rc = ambi_batch_add_chromosome(probe, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
-        if ((rc = ambi_batch_upload(probe)) != 0 || (rc = ambi_batch_run(probe, 0, nullptr)) != 0 || (rc = ambi_batch_download(probe)) != 0)
-            return die(std::string("engine: ") + ambi_error_string(rc));
-        ambi_unit_result_t pr; ambi_batch_unit_result(probe, 0, &pr);
+        ambi_unit_result_t pr; ambi_batch_unit_result(probe, c, &pr);
         std::vector<double> junc_cn(2 * (n + 1)), seg_cn(n + 1);
         std::vector<int32_t> inv(n + 1);
-        ambi_batch_unit_prepare(probe, 0, junc_cn.data(), seg_cn.data(), nullptr, inv.data());
+        ambi_batch_unit_prepare(probe, c, junc_cn.data(), seg_cn.data(), nullptr, inv.data());
+        // getIndelBias of chromosome c has edited its segment CNs (localhap.cpp:147); the ILP of chromosome c sees the
+        // edits of chromosomes <= c only (its loop bound is the CN sum over ALL segments, LGM.cpp:4708-4711)
         for (int i = 1; i <= n; i++) { cn_all[s - 1 + i - 1] = seg_cn[i]; if (inv[i] >= 0) num_inv++; }
-        ambi_batch_t* b; ambi_batch_create(&b);
         if (pr.status == AMBI_ST_SHORTCUT) {
-            ambi_batch_add_chromosome(b, g, c, 0, nullptr, nullptr, 0);
-        } else {
-            double max_cn = 0;
-            for (double v : cn_all) max_cn += v;
-            ambi_ilp_t* ilp = nullptr;
-            if ((rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp)) != 0) return die(ambi_error_string(rc));
-            std::cout << "Declare done" << std::endl << "ILP formula done" << std::endl << "Variable constrains done" << std::endl;
-            ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());   // LGM.cpp:4749-4750: both side files
-            ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
-            ambi_ilp_destroy(ilp);
-            std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181
-            std::cout.flush();
-            const int solver_rc = system(cmd.c_str());   // the reference ignores the exit status too; a missing .sol is caught below
-            (void)solver_rc;
-            rc = ambi_batch_add_chromosome_sol(b, g, c, ("./" + prefix + ".sol").c_str());
-            if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:187-190
-            if (rc < 0) return die(ambi_error_string(rc));
+            if ((rc = ambi_batch_add_chromosome(b, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
+            continue;
         }
-        ambi_batch_destroy(probe);
-        if ((rc = ambi_batch_upload(b)) != 0 ||
-            (rc = ambi_batch_run(b, (reversed ? AMBI_FLAG_REVERSED : 0u) | (all ? AMBI_FLAG_ALL : 0u), nullptr)) != 0 ||
-            (rc = ambi_batch_download(b)) != 0)
-            return die(std::string("engine: ") + ambi_error_string(rc));
-        ambi_unit_result_t r; ambi_batch_unit_result(b, 0, &r);
-        if (r.status < 0 || r.status == AMBI_ST_NO_VALID_ORDER) return die(std::string("bfb: ") + ambi_error_string(r.status));
+        double max_cn = 0;
+        for (double v : cn_all) max_cn += v;
+        ambi_ilp_t* ilp = nullptr;
+        if ((rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp)) != 0) return die(ambi_error_string(rc));
+        head[c] = "Declare done\nILP formula done\nVariable constrains done\n";
+        ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());   // LGM.cpp:4749-4750: both side files
+        ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
+        ambi_ilp_destroy(ilp);
+        (void)remove(("./" + prefix + ".sol").c_str());        // a stale .sol of an earlier chromosome or run must not pass for this solve
+        std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181
+        if (solver_timeout > 0) { char t[64]; snprintf(t, sizeof(t), "timeout -k 5 %.0f ", solver_timeout); cmd = t + cmd; }
+        std::cout.flush();
+        const int solver_rc = system(cmd.c_str());
+        // the reference ignores the exit status (a missing .sol is what it notices, localhap.cpp:187-190); say what happened
+        if (solver_rc != 0) {
+            const int code = WIFEXITED(solver_rc) ? WEXITSTATUS(solver_rc) : -1;
+            if (solver_timeout > 0 && code == 124) std::cerr << "ILP error: cbc did not finish within " << solver_timeout << " s (chromosome " << c << ")" << std::endl;
+            else std::cerr << "ILP warning: `" << cmd << "` ended with status " << code << std::endl;
+        }
+        rc = ambi_batch_add_chromosome_sol(b, g, c, ("./" + prefix + ".sol").c_str());
+        if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:187-190
+        if (rc < 0) return die(ambi_error_string(rc));
+    }
+    ambi_batch_destroy(probe);
+    if ((rc = ambi_batch_upload(b)) != 0 ||
+        (rc = ambi_batch_run(b, (reversed ? AMBI_FLAG_REVERSED : 0u) | (all ? AMBI_FLAG_ALL : 0u), nullptr)) != 0 ||
+        (rc = ambi_batch_download(b)) != 0)
+        return die(std::string("engine: ") + ambi_error_string(rc));
+    int refused = 0;
+    for (int c = 0; c < n_chr; c++) {
+        std::cout << head[c];
+        ambi_unit_result_t r; ambi_batch_unit_result(b, c, &r);
+        if (r.status < 0 || r.status == AMBI_ST_NO_VALID_ORDER) {
+            // where the reference would print this chromosome's path.  AMBI_ERR_REF_UB: the reference itself reads past the
+            // end of its breakpoint vector on this input (LGM.cpp:3436-3442) -- whatever it prints there is not defined by
+            // its source, so nothing is printed here; the other chromosomes follow, the exit status is 1.
+            std::cout.flush();
+            std::cerr << "bfb: chromosome " << c << ": " << ambi_error_string(r.status) << std::endl;
+            refused++;
+            continue;
+        }
         std::vector<int32_t> p(r.path_len), q(r.path_indel_len);
-        ambi_batch_unit_path(b, 0, 0, p.data(), r.path_len);
-        ambi_batch_unit_path(b, 0, 1, q.data(), r.path_indel_len);
+        ambi_batch_unit_path(b, c, 0, p.data(), r.path_len);
+        ambi_batch_unit_path(b, c, 1, q.data(), r.path_indel_len);
         if (all && r.status == AMBI_ST_OK) {
             // --all: one line per valid order; the flipped orientation only if the last order was invalid (LGM.cpp:3672-3695)
             const int64_t stride = 2ll * r.path_len + 64;
             for (int pass = 0; pass < 2; pass++) {
                 int64_t nv = 0;
-                ambi_batch_all_count(b, 0, pass, &nv);
+                ambi_batch_all_count(b, c, pass, &nv);
                 for (int64_t lo = 0; lo < nv; lo += 64) {
                     const int64_t cnt = nv - lo < 64 ? nv - lo : 64;
                     std::vector<int32_t> len((size_t)cnt), cells((size_t)(cnt * stride));
-                    if ((rc = ambi_batch_all_paths(b, 0, pass, lo, cnt, len.data(), cells.data(), stride)) != 0)
+                    if ((rc = ambi_batch_all_paths(b, c, pass, lo, cnt, len.data(), cells.data(), stride)) != 0)
                         return die(std::string("bfb --all: ") + ambi_error_string(rc));
                     for (int64_t j = 0; j < cnt; j++) {
                         if (len[j] < 0) return die(std::string("bfb --all: ") + ambi_error_string(len[j]));
@@ -167,10 +199,11 @@ int main(int argc, char** argv) {
         else if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(g, q) << std::endl;
         paths[c] = q;
         std::vector<int32_t> ju(r.n_out_junc), jv(r.n_out_junc), jc(r.n_out_junc);
-        ambi_batch_unit_out_juncs(b, 0, ju.data(), jv.data(), jc.data(), r.n_out_junc);
+        ambi_batch_unit_out_juncs(b, c, ju.data(), jv.data(), jc.data(), r.n_out_junc);
         for (int k = 0; k < r.n_out_junc; k++) merge_steps(out_acc, ju[k], jv[k], jc[k], true);   // localhap.cpp:267-289
-        ambi_batch_destroy(b);
     }
+    ambi_batch_destroy(b);
+    if (refused) return die("bfb: " + std::to_string(refused) + " chromosome(s) without a path");
     int path_len = 0, cn_sum = 0, max_cn_i = 0;
     for (auto& p : paths) path_len += (int)p.size();
     for (double v : cn_all) { cn_sum += v; max_cn_i = (max_cn_i > v) ? max_cn_i : v; }   // localhap.cpp:290-293 (int fed with doubles)

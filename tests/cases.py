@@ -35,6 +35,24 @@ def synthetic_cases(workdir, small_only=True):
     s = synth.make_sample(96, 200, "chain", 5, seed=11, n_chr=3, translocations=1, prop="PROP C2:chr1:chr2 M:chr1", name="multi3")
     lh, sols = s.write(workdir)
     out.append((s.name, lh, sols))
+    # copy numbers left to the engine's reader (CN <= 0 in the file -> calculateHapDepth / calculateCopyNum, Graph.cpp:312-405):
+    # every third SEG and JUNC loses its CN column value; AVG_PLOIDY is given so that the reference's ratio is initialised
+    for seed in range(2):
+        s = synth.make_sample(40, 80, ("chain", "wide")[seed], 7, seed=60 + seed, imperfect=seed, n_del=1, name="cnle0_%d" % seed)
+        out_lines, k = [], 0
+        for line in s.lh_text.splitlines():
+            if line.startswith("AVG_TUMOR_PLOIDY"):
+                out_lines.append("AVG_PLOIDY 2")
+            if line.startswith(("SEG ", "JUNC ")):
+                k += 1
+                if k % 3 == 0:
+                    t = line.split(" ")
+                    t[4 if t[0] == "JUNC" else 3] = "-1" if k % 2 else "0"
+                    line = " ".join(t)
+            out_lines.append(line)
+        s.lh_text = "\n".join(out_lines) + "\n"
+        lh, sols = s.write(workdir)
+        out.append((s.name, lh, sols))
     # BFB-TRX with insertion groups (junction pairs that leave the main chromosome and come back: LGM.cpp:4120-4190),
     # alone and mixed with a concatenation; both PROP spellings
     for seed in range(6):

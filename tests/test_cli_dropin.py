@@ -104,3 +104,65 @@ def test_cli_two_chromosome_trx(cli, oracle, tmp_path):
 
 def test_cli_errors(cli, tmp_path):
     check_errors(cli, str(tmp_path))
+
+
+def test_cli_with_a_solver_that_reads_the_lp(cli, tmp_path):
+    """End to end with a REAL solve: the .lp this CLI writes is read back by an independent LP-format parser and solved
+    as a MILP (HiGHS via scipy; Cbc is not in the image), the .sol goes through the reference's token scan, and the
+    README example comes out as README.md:122 prints it."""
+    cwd = str(tmp_path)
+    bindir = os.path.join(cwd, "bin")
+    os.makedirs(bindir)
+    exe = os.path.join(bindir, "cbc")
+    with open(exe, "w") as f:
+        f.write("#!/bin/sh\npython3 %s \"$@\" | sed 's/^/fake cbc: /'\n" % os.path.join(ROOT, "tests", "tools", "cbc_highs.py"))
+    os.chmod(exe, os.stat(exe).st_mode | stat.S_IEXEC)
+    r = run_cli(cli, cwd, bindir, "--op", "bfb", "--in_lh", os.path.join(DATA, "readme6.lh"), "--lp_prefix", "solved")
+    assert r.returncode == 0, r.stderr
+    assert "optimal" in r.stdout
+    assert r.stdout.splitlines()[-1] == "1+2+3+4+5+6+|6-5-4-3-2-|2+3+4+|4-3-|3+4+|4-3-2-|2+3+4+5+6+|6-5-4-3-2-1-"   # README.md:122
+    sol = open(os.path.join(cwd, "solved.sol")).read()
+    assert sol.startswith("Optimal - objective value")
+    picked = {int(l.split()[1][1:]): float(l.split()[2]) for l in sol.splitlines()[1:] if int(l.split()[1][1:]) < 42}
+    assert picked == {26: 1, 29: 1, 31: 1, 33: 1}       # l(1,6), l(2,4), l(2,6), l(3,4): SURVEY.md appendix B.4
+
+
+def test_cli_solver_failures(cli, tmp_path):
+    """solver plumbing around localhap.cpp:179-190: a solver that exits non-zero without a .sol, one that never
+    returns (--solver_timeout, an extension flag), and a stale .sol left by an earlier run must not be taken."""
+    cwd = str(tmp_path)
+    bindir = os.path.join(cwd, "bin")
+    os.makedirs(bindir)
+    exe = os.path.join(bindir, "cbc")
+    lh = os.path.join(DATA, "readme6.lh")
+
+    def script(body):
+        with open(exe, "w") as f:
+            f.write("#!/bin/sh\n" + body + "\n")
+        os.chmod(exe, os.stat(exe).st_mode | stat.S_IEXEC)
+
+    with open(os.path.join(cwd, "f.sol"), "w") as f:       # stale solution from "an earlier run"
+        f.write(open(os.path.join(DATA, "readme6.sol")).read())
+    script("exit 7")
+    r = run_cli(cli, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "f")
+    assert r.returncode == 1 and "status 7" in r.stderr and "ILP error: cannot open file ./f.sol" in r.stderr
+    script("sleep 30")
+    r = run_cli(cli, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "f", "--solver_timeout", "1")
+    assert r.returncode == 1 and "did not finish within 1 s" in r.stderr and "cannot open file ./f.sol" in r.stderr
+
+
+def test_cli_many_chromosomes_one_batch(cli, oracle, tmp_path):
+    """BASELINE config 4 shape through the CLI: 8 chromosomes, a concatenation and insertion groups (BFB-TRX) -- one probe
+    batch, one reconstruct batch; stdout equals the oracle's line for line."""
+    from ambigram_amd import synth
+    cwd = str(tmp_path)
+    s = synth.make_sample(256, 520, "chain", 5, seed=4004, n_chr=8, translocations=1, trx_insertions=3, prop="PROP C2:chr1:chr2 M:chr1", name="c4small")
+    lh, sols = s.write(cwd)
+    bindir = os.path.join(cwd, "bin")
+    fake_cbc(bindir, sols)
+    r = run_cli(cli, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "c4")
+    assert r.returncode == 0, r.stderr
+    got = [l for l in r.stdout.splitlines() if not l.startswith("fake cbc")]
+    want = oracle.run_bfb(lh, sols)
+    assert got == want["log"]
+    assert "insert" in want["trx_trace"]

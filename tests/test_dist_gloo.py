@@ -6,6 +6,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent('''
@@ -30,12 +32,14 @@ WORKER = textwrap.dedent('''
         batch.add_chromosome_sol(g, 0, sols[0])
     batch.upload(); batch.run(0); batch.download()
     n_units = batch.size()
-    assert n_units == N // world
+    assert n_units == len(mine)
     cells_needed = sum(batch.unit_result(u)["path_indel_len"] for u in range(n_units))
-    px = PathExchange(n_units, cells_needed, "cpu", world=world, rank=rank)
-    batch.pack_paths(1, px.lengths.data_ptr(), px.cells.data_ptr(), px.cell_cap, px.total.data_ptr())
-    px.exchange()
-    got = px.collect()
+    got = None
+    if N %% world == 0:                       # the cell form needs the same unit count on every rank
+        px = PathExchange(n_units, cells_needed, "cpu", world=world, rank=rank)
+        batch.pack_paths(1, px.lengths.data_ptr(), px.cells.data_ptr(), px.cell_cap, px.total.data_ptr())
+        px.exchange()
+        got = px.collect()
     # the same gather in run-length form (what bench.py does): pack -> all_gather of the counts + gather of the runs ->
     # rank 0 expands every rank's runs
     n_runs, n_cells = RunExchange.probe(batch, n_units, "cpu")
@@ -46,33 +50,39 @@ WORKER = textwrap.dedent('''
     rx.expand()
     got_runs = rx.collect()
     if rank == 0:
-        assert got_runs == got, "run-length exchange differs from the cell exchange"
-        json.dump(got, open(os.path.join(tmp, "gathered.json"), "w"))
-        json.dump({"runs": [int(x) for x in rx.counts_all.view(world, 2, n_units)[:, 1, :].sum(1)], "cells": [int(x) for x in rx.counts_all.view(world, 2, n_units)[:, 0, :].sum(1)]},
+        assert len(got_runs) == world and all(len(p) == rx.unit_cap for p in got_runs)
+        assert got is None or got_runs == got, "run-length exchange differs from the cell exchange"
+        json.dump(got_runs, open(os.path.join(tmp, "gathered.json"), "w"))
+        json.dump({"runs": [int(x) for x in rx.counts_all.view(world, 2, rx.unit_cap)[:, 1, :].sum(1)], "cells": [int(x) for x in rx.counts_all.view(world, 2, rx.unit_cap)[:, 0, :].sum(1)]},
                   open(os.path.join(tmp, "payload.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()
 ''')
 
 
-def test_two_rank_gather_matches_oracle(oracle, hostsim_lib, workdir):
-    tmp = os.path.join(workdir, "dist")
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_matches_oracle(oracle, hostsim_lib, workdir, world):
+    """world 2: 5 + 5 samples, cell form and run-length form agree; world 4: 3 + 3 + 2 + 2 samples -- ranks with fewer
+    units than the agreed capacity send empty unit slots (the padding path of RunExchange)."""
+    tmp = os.path.join(workdir, "dist%d" % world)
     os.makedirs(tmp, exist_ok=True)
     lib_path = os.path.join(ROOT, "tests", "hostsim", "libambigram_hostsim.so")
     script = os.path.join(tmp, "worker.py")
     with open(script, "w") as f:
         f.write(WORKER % dict(root=ROOT, lib=lib_path, tmp=tmp))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r))) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     import json
     from ambigram_amd import synth
     from ambigram_amd.dist import shard
     got = json.load(open(os.path.join(tmp, "gathered.json")))
-    assert len(got) == 2
-    for r in range(2):
-        for k, i in enumerate(shard(10, r, 2)):
+    assert len(got) == world
+    for r in range(world):
+        mine = shard(10, r, world)
+        assert all(p == [] for p in got[r][len(mine):])          # unused unit slots of a rank are empty
+        for k, i in enumerate(mine):
             s = synth.make_sample(40, 80, ("chain", "wide", "mixed")[i % 3], 7, seed=3000 + i, n_del=i % 2)
             lh, sols = s.write(tmp, "o%d" % i)
             want = oracle.run_bfb(lh, sols)["chr"][0]["path_indel"]

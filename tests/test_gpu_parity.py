@@ -151,12 +151,14 @@ def test_cli_on_gpu(hip_lib, oracle, tmp_path):
     import test_cli_dropin as t
     exe = os.path.join(t.ROOT, "ambigram_amd", "bin", "Ambigram")
     assert os.path.exists(exe), "build the CLI first (__graft_entry__.build)"
-    d1, d2, d3 = tmp_path / "a", tmp_path / "b", tmp_path / "c"
-    for d in (d1, d2, d3):
+    d1, d2, d3, d4, d5 = (tmp_path / x for x in "abcde")
+    for d in (d1, d2, d3, d4, d5):
         d.mkdir()
     t.check_readme(exe, str(d1), oracle)
     t.check_trx(exe, str(d2), oracle)
     t.check_errors(exe, str(d3))
+    t.test_cli_many_chromosomes_one_batch(exe, oracle, d4)       # 8 chromosomes: one probe batch + one reconstruct batch
+    t.test_cli_with_a_solver_that_reads_the_lp(exe, d5)          # the written .lp solved for real (HiGHS stand-in for cbc)
 
 
 def test_large_lattice(hip_lib, oracle, workdir):
