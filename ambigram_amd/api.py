@@ -62,6 +62,9 @@ def _declare(L):
         "ambi_batch_destroy": (None, [vp]),
         "ambi_batch_add_chromosome": (C.c_int, [vp, vp, i32, i32, pi32, pi32, i32]),
         "ambi_batch_add_chromosome_sol": (C.c_int, [vp, vp, i32, C.c_char_p]),
+        "ambi_batch_add_chromosome_sol_block": (C.c_int, [vp, vp, i32, C.c_char_p, i32, i32]),
+        "ambi_graph_recalculate": (C.c_int, [vp]),
+        "ambi_ilp_build_sc": (C.c_int, [vp, i32, i32, pd, pd, _P(vp)]),
         "ambi_batch_add_unit": (C.c_int, [vp, i32, i32, pd, i32, pi32, pi32, pi8, pi8, pd, i32, pi32, pi32, pi32, pi32, i32, i32]),
         "ambi_batch_size": (C.c_int, [vp, pi32]),
         "ambi_batch_configure": (C.c_int, [vp, i64, i32, i32, i32]),
@@ -597,6 +600,105 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
     return res
 
 
+def reconstruct_sc(lib, lhs, sols, reversed_=False, all_=False, first_budget=0):
+    """Host-side mirror of `Ambigram --op sc_bfb` (localhap.cpp:390-679) with the external `cbc` call replaced by the
+    given joint .sol files (one per chromosome of the first graph that has a fold-back inversion, in order).
+    All graphs x chromosomes run as ONE batch of units.  Returns a dict shaped like the oracle's run_sc_bfb dump."""
+    graphs = [Graph(lib, p) for p in lhs]
+    G = len(graphs)
+    log = ["sc_bfb"]
+    for g in graphs:
+        log += g.log()
+    n0 = len(graphs[0].log())
+    rc = lib.ambi_graph_recalculate(graphs[0].h)                  # localhap.cpp:438-439
+    if rc != 0:
+        raise AmbiError(lib, rc, "recalculate")
+    log += graphs[0].log()[n0:]
+    g0 = graphs[0]
+    probe = Batch(lib)                                            # which chromosomes reach the ILP: the FIRST graph decides (:505)
+    for c in range(g0.n_chr):
+        probe.add_chromosome(g0, c, [], [])
+    probe.upload(); probe.run(0); probe.download()
+    shortcut = [probe.unit_result(c)["status"] == ST_SHORTCUT for c in range(g0.n_chr)]
+    probe.close()
+    b = Batch(lib)
+    if first_budget:
+        b.configure(first_budget=first_budget)
+    unit_of, cursor, sol_of = {}, 0, {}
+    for c in range(g0.n_chr):
+        if shortcut[c]:
+            continue
+        if cursor >= len(sols):
+            raise RuntimeError("missing .sol for chromosome %d" % c)
+        sol_of[c] = sols[cursor]
+        cursor += 1
+        for k, g in enumerate(graphs):
+            rc = lib.ambi_batch_add_chromosome_sol_block(b.h, g.h, c, sol_of[c].encode(), k, G)
+            if rc < 0:
+                raise AmbiError(lib, rc, "add_chromosome_sol_block")
+            unit_of[(c, k)] = rc
+    res = dict(ok=True, err="", log=log, paths=[[] for _ in range(G)], trx_paths=[[] for _ in range(G)], chr=[])
+    if unit_of:
+        b.upload(); b.run((FLAG_REVERSED if reversed_ else 0) | (FLAG_ALL if all_ else 0)); b.download()
+    for c in range(g0.n_chr):
+        s, e = g0.chromosome(c)
+        stages = []
+        if shortcut[c]:                                           # reference path for every graph, nothing printed (:505-512)
+            for k in range(G):
+                res["paths"][k].append(list(range(s, e + 1)))
+                stages.append(dict(shortcut=True, infeasible=False))
+            res["chr"].append(stages)
+            continue
+        log += ["Declare done"] + ["ILP formula done"] * G + ["Variable constrains done"]
+        first = b.unit_result(unit_of[(c, 0)])
+        if first["status"] == ST_INFEASIBLE:                      # :543-551
+            log.append("ILP is unsolvable.")
+            for k in range(G):
+                res["paths"][k].append(list(range(s, e + 1)))
+                stages.append(dict(shortcut=False, infeasible=True))
+            res["chr"].append(stages)
+            continue
+        for k, g in enumerate(graphs):
+            u = unit_of[(c, k)]
+            r = b.unit_result(u)
+            if r["status"] != ST_OK:
+                res["ok"] = False
+                res["err"] = "graph %d chromosome %d: %s" % (k, c, lib.ambi_error_string(r["status"]).decode())
+                res["paths"][k].append([])
+                stages.append(dict(status=r["status"]))
+                continue
+            path, path_ind = b.unit_path(u, 0), b.unit_path(u, 1)
+            pat, loop, _ = b.unit_dag(u, r["n_nodes"])
+            stages.append(dict(shortcut=False, infeasible=False, num_orders=r["num_orders"], first_valid=r["first_valid"],
+                               first_forward=r["first_forward"], evaluated=r["evaluated"], bkp=b.unit_bkp(u).tolist(),
+                               node2pat=[[] if x[0] == 0 else x for x in pat.tolist()], node2loop=[[] if x[0] == 0 else x for x in loop.tolist()],
+                               path=path.tolist(), path_indel=path_ind.tolist(), indel_printed=bool(r["indel_printed"])))
+            if all_:
+                for pass_ in (0, 1):
+                    idx = b.all_orders(u, pass_)
+                    for lo in range(0, len(idx), 64):
+                        for p_all in b.all_paths(u, pass_, lo, min(64, len(idx) - lo), 2 * len(path) + 64):
+                            log.append(g.format_path(p_all))
+            else:
+                log.append(g.format_path(path))
+            if r["indel_printed"]:
+                log += ["BFB path with insertion, deletion, or duplication:", g.format_path(path_ind)]
+            res["paths"][k].append(path_ind.tolist())
+        res["chr"].append(stages)
+    ins, con, main_chr = g0.props()
+    if res["ok"] and (ins == 2 or con == 2):                      # :661-664, every graph
+        for k, g in enumerate(graphs):
+            log.append("BFB with translocation:")
+            trx, new_paths = g.translocation_bfb([np.array(p, np.int32) for p in res["paths"][k]])
+            res["paths"][k] = [p.tolist() for p in new_paths]
+            res["trx_paths"][k] = trx.tolist()
+            log.append(g.format_path(trx))
+    b.close()
+    for g in graphs:
+        g.close()
+    return res
+
+
 class IlpModel:
     """ILP of one chromosome (BFB_ILP, LGM.cpp:4397-4752) built on the host in closed form."""
 
@@ -617,8 +719,24 @@ class IlpModel:
                                     float(max_cn_total), 1 if juncs_info else 0, C.byref(self.h))
         if rc != 0:
             raise AmbiError(lib, rc, "ilp_build")
+        self._sizes()
+
+    @classmethod
+    def joint(cls, lib, graph0, chr_, seg_cn, fold_cn):
+        """Joint model of `--op sc_bfb` (BFB_ILP_SC, LGM.cpp:4754-5093): seg_cn / fold_cn are G x n arrays (graph-major)."""
+        self = cls.__new__(cls)
+        self.lib, self.h, self.kernel_ms = lib, C.c_void_p(), None
+        sc = np.ascontiguousarray(seg_cn, np.float64)
+        fc = np.ascontiguousarray(fold_cn, np.float64)
+        rc = lib.ambi_ilp_build_sc(graph0.h, chr_, sc.shape[0], sc.ctypes.data_as(_P(C.c_double)), fc.ctypes.data_as(_P(C.c_double)), C.byref(self.h))
+        if rc != 0:
+            raise AmbiError(lib, rc, "ilp_build_sc")
+        self._sizes()
+        return self
+
+    def _sizes(self):
         r, z, c, i = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
-        lib.ambi_ilp_sizes(self.h, C.byref(r), C.byref(z), C.byref(c), C.byref(i))
+        self.lib.ambi_ilp_sizes(self.h, C.byref(r), C.byref(z), C.byref(c), C.byref(i))
         self.n_rows, self.nnz, self.n_cols, self.n_int = r.value, z.value, c.value, i.value
 
     def arrays(self):

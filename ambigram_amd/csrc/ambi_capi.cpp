@@ -134,6 +134,13 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
     copy_text(g->g.main_chr, main_chr, cap);
     return 0;
 }
+int ambi_graph_recalculate(ambi_graph_t* g) {
+    if (!g) return AMBI_ERR_ARG;
+    int rc = hap_depth(g->g);
+    if (rc != LH_OK) return rc;
+    copy_num(g->g);
+    return 0;
+}
 int ambi_graph_components(const ambi_graph_t* g, int32_t* ids, int32_t ids_cap, int32_t* offsets, int32_t off_cap) {
     if (!g) return AMBI_ERR_ARG;
     int32_t at = 0, c = 0;
@@ -171,6 +178,14 @@ int ambi_batch_add_chromosome_sol(ambi_batch_t* b, const ambi_graph_t* g, int32_
     int rc = read_sol(sol_path, s);
     if (rc != LH_OK) return rc;
     return b->hb.add_graph_chr(g->g, chr, &s);
+}
+int ambi_batch_add_chromosome_sol_block(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, const char* sol_path, int32_t block, int32_t n_blocks) {
+    if (!b || !g || !sol_path || n_blocks < 1 || block < 0 || block >= n_blocks) return AMBI_ERR_ARG;
+    if (b->uploaded) return AMBI_ERR_STATE;
+    SolFile s;
+    int rc = read_sol(sol_path, s);
+    if (rc != LH_OK) return rc;
+    return b->hb.add_graph_chr(g->g, chr, &s, block, n_blocks);
 }
 int ambi_batch_add_unit(ambi_batch_t* b, int32_t n_seg, int32_t seg_base, const double* seg_cn, int32_t n_junc,
                         const int32_t* j_src, const int32_t* j_tgt, const int8_t* j_sdir, const int8_t* j_tdir,
@@ -426,6 +441,16 @@ int ambi_ilp_build_device(const ambi_graph_t* g, int32_t chr, const double* seg_
                                     p->m.col.data(), p->m.val.data(), kernel_ms);
     if (rc) return rc;
     *out = p.release();
+    return 0;
+}
+int ambi_ilp_build_sc(const ambi_graph_t* g0, int32_t chr, int32_t n_graphs, const double* seg_cn, const double* fold_cn, ambi_ilp_t** out) {
+    if (!g0 || !seg_cn || !fold_cn || !out || n_graphs < 1 || chr < 0 || chr >= g0->g.n_chr()) return AMBI_ERR_ARG;
+    const int s = g0->g.source_ids[chr], e = g0->g.sink_ids[chr];
+    std::vector<std::pair<int, int>> evolution;     // localhap.cpp:430-434: every pair i < j
+    for (int i = 0; i < n_graphs; i++) for (int j = i + 1; j < n_graphs; j++) evolution.push_back({i, j});
+    ambi_ilp* p = new ambi_ilp();
+    ambi::build_bfb_ilp_sc(s, e, n_graphs, seg_cn, fold_cn, evolution, p->m);
+    *out = p;
     return 0;
 }
 void ambi_ilp_destroy(ambi_ilp_t* p) { delete p; }

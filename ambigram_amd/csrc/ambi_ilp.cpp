@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <set>
+#include <utility>
 
 namespace ambi {
 
@@ -114,6 +115,105 @@ void build_bfb_ilp(int s, int e, const double* seg_cn, const double* fold_cn, in
     for (int c = num_el; c < num_var - 1; c++) m.obj[c] = 1;
     m.col_lo[num_var - 1] = m.col_up[num_var - 1] = bias;
     m.obj[num_var - 1] = -1;
+}
+
+// Joint model of G graphs over the same chromosome (LocalGenomicMap::BFB_ILP_SC, LGM.cpp:4754-5093): per graph g the
+// rows of BFB_ILP without the bias row and without the .juncs row, on the column block [g*numComp, (g+1)*numComp); the
+// +-epsilon column of a row pair is numElements + idx/2 where idx is the RUNNING ROW COUNTER (LGM.cpp:4815, :4821, :4858,
+// :4864) -- for g = 0 that is epsilon 2k / 2k+1 of segment k as in BFB_ILP, for g > 0 the counter has also run over the
+// nesting rows of the graphs before, so those epsilons land further up (inside the block the reference sets aside for
+// the linking epsilons; the matrix is reproduced as the reference builds it).  Then, for every pair (i, j) of the
+// `evolution` lists and every element, the two rows  x_i - x_j +- eps  with eps = cnt/2, cnt starting at
+// 2*(numElements + 2*n*G) (LGM.cpp:5032-5072).  Bounds: loops <= CN sum of THIS graph's segments start..end (:5012-5027).
+void build_bfb_ilp_sc(int s, int e, int G, const double* seg_cn, const double* fold_cn, const std::vector<std::pair<int, int>>& evolution,
+                      IlpModel& m) {
+    const double INF = DBL_MAX;
+    const Tri T(s, e);
+    const int n = T.n, num_pat = T.num_pat, num_comp = 2 * num_pat;
+    const int num_el = num_comp * G, num_eps = n * 2 * G + (G * (G - 1)) * num_comp;
+    const int num_var = num_el + num_eps;
+    m = IlpModel();
+    m.n_cols = num_var;
+    m.n_int = num_el;
+    m.row_ptr.push_back(0);
+    int64_t idx = 0;
+    auto put = [&](int c, double v) { m.col.push_back(c); m.val.push_back(v); };
+    auto end_row = [&](double lo, double up) { m.row_ptr.push_back((int64_t)m.col.size()); m.row_lo.push_back(lo); m.row_up.push_back(up); idx++; };
+    m.col_lo.assign(num_var, 0); m.col_up.assign(num_var, INF); m.obj.assign(num_var, 0);
+    for (int g = 0; g < G; g++) {
+        const int off = g * num_comp;
+        const double* cn = seg_cn + (size_t)g * n;
+        const double* fold = fold_cn + (size_t)g * n;
+        auto P = [&](int a, int b) { return off + T.P(a, b); };
+        auto L = [&](int a, int b) { return off + T.L(a, b); };
+        for (int i = s; i <= e; i++) {
+            const int k = i - s;
+            for (int rep = 0; rep < 2; rep++) {
+                for (int a = s; a <= i; a++) for (int b = i; b <= e; b++) put(P(a, b), 1);
+                for (int a = s; a <= i; a++) for (int b = i; b <= e; b++) put(L(a, b), 2);
+                put(num_el + (int)(idx / 2), rep == 0 ? 1 : -1);
+                if (rep == 0) end_row(cn[k], INF); else end_row(-INF, cn[k]);
+            }
+            for (int rep = 0; rep < 2; rep++) {
+                if (i > s) for (int a = s; a < i; a++) put(P(a, i), 0.5);
+                if (i < e) for (int b = i; b <= e; b++) put(P(i, b), 0.5);
+                else if (i > s) put(P(i, i), 0.5);
+                for (int a = s; a < i; a++) put(L(a, i), 1);
+                for (int b = i; b <= e; b++) put(L(i, b), 1);
+                put(num_el + (int)(idx / 2), rep == 0 ? 1 : -1);
+                if (rep == 0) end_row(fold[k], INF); else end_row(-INF, fold[k]);
+            }
+        }
+        for (int a = s; a <= e; a++) for (int b = a; b <= e; b++) {          // LGM.cpp:4867-4911
+            if (a > s || b < e) {
+                for (int j = s; j < a; j++) put(P(j, b), 1);
+                for (int j = b + 1; j <= e; j++) put(P(a, j), 1);
+                put(P(a, b), -1); end_row(0, INF);
+            }
+            if (a < b) {
+                for (int j = a; j < b; j++) put(P(a, j), 1);
+                for (int j = a + 1; j <= b; j++) put(P(j, b), 1);
+                put(P(a, b), 1); end_row(0, 2);
+            }
+        }
+        for (int a = s; a <= e; a++) for (int b = a; b <= e; b++) {          // :4914-4940
+            if (a > s || b < e) {
+                for (int j = s; j < a; j++) { put(P(j, b), 1); put(L(j, b), 1); }
+                for (int j = b + 1; j <= e; j++) { put(P(a, j), 1); put(L(a, j), 1); }
+                put(L(a, b), -1); end_row(0, INF);
+            }
+        }
+        for (int a = s; a <= e; a++) for (int b = a + 1; b <= e; b++) {      // :4943-4974
+            for (int rep = 0; rep < 2; rep++) {
+                for (int j = a; j < b; j++) put(L(a, j), 1);
+                for (int j = a + 1; j <= b; j++) put(L(j, b), 1);
+                put(rep == 0 ? L(a, b) : P(a, b), 1); end_row(0, 2);
+            }
+        }
+        for (int a = s; a <= e; a++) for (int b = a + 1; b <= e; b++) {      // :4977-5008
+            for (int j = a; j < b; j++) put(L(a, j), 1);
+            for (int j = a + 1; j <= b; j++) put(P(j, b), 1);
+            put(P(a, b), 1); end_row(0, 2);
+            for (int j = a; j < b; j++) put(P(a, j), 1);
+            for (int j = a + 1; j <= b; j++) put(L(j, b), 1);
+            put(P(a, b), 1); end_row(0, 2);
+        }
+        double max_cn = 0;
+        for (int k = 0; k < n; k++) max_cn += cn[k];
+        for (int c = 0; c < num_pat; c++) m.col_up[off + c] = 1;
+        for (int c = num_pat; c < num_comp; c++) m.col_up[off + c] = max_cn;
+    }
+    int64_t cnt = ((int64_t)num_el + (int64_t)n * 2 * G) * 2;
+    for (auto& pr : evolution) {
+        for (int c = 0; c < num_comp; c++) {      // patterns k = 0..numPat-1, then loops: column order within a block
+            for (int rep = 0; rep < 2; rep++) {
+                put(c + num_comp * pr.first, 1); put(c + num_comp * pr.second, -1); put((int)(cnt / 2), rep == 0 ? 1 : -1);
+                if (rep == 0) end_row(0, INF); else end_row(-INF, 0);
+                cnt++;
+            }
+        }
+    }
+    for (int c = num_el; c < num_var; c++) m.obj[c] = 1;
 }
 
 // The same model as ROW DESCRIPTORS (ambi_ilp_rows.hpp): everything except col/val, which the caller fills entry by

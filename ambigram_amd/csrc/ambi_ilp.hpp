@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace ambi {
@@ -28,6 +29,12 @@ struct IlpModel {
 void build_bfb_ilp(int start_id, int end_id, const double* seg_cn, const double* junc_cn_fold /*[n] fold-back CN of id start..end*/,
                    int bias, double max_cn_total, const std::vector<std::vector<int32_t>>& components, bool juncs_info,
                    IlpModel& m);
+
+// Joint model of G graphs sharing one chromosome (`--op sc_bfb`: LocalGenomicMap::BFB_ILP_SC, LGM.cpp:4754-5093).
+// seg_cn / fold_cn: G x n, graph-major (graph 0 after its getIndelBias, localhap.cpp:497; the others as read);
+// evolution: the (i, j) pairs of localhap.cpp:417-434 in its iteration order.
+void build_bfb_ilp_sc(int start_id, int end_id, int n_graphs, const double* seg_cn, const double* fold_cn,
+                      const std::vector<std::pair<int, int>>& evolution, IlpModel& m);
 
 // Row-descriptor form of the same model (ambi_ilp_rows.hpp): fills everything of `m` except the entries (col/val are
 // sized and zeroed); entry j of row r is ilp_row_entry(rows[r], ...), written by the device kernel or the host loop.

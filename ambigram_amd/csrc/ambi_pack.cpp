@@ -65,7 +65,7 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
     return (int)units.size() - 1;
 }
 
-int HostBatch::add_graph_chr(const LhGraph& g, int chr, const SolFile* sol) {
+int HostBatch::add_graph_chr(const LhGraph& g, int chr, const SolFile* sol, int block, int n_blocks) {
     if (chr < 0 || chr >= g.n_chr()) return ST_ERR_BAD_INPUT;
     const int s = g.source_ids[chr], e = g.sink_ids[chr];
     if (s < 1 || e > g.n_seg() || s > e) return ST_ERR_BAD_INPUT;
@@ -87,7 +87,15 @@ int HostBatch::add_graph_chr(const LhGraph& g, int chr, const SolFile* sol) {
     if (sol) {
         infeasible = sol->infeasible ? 1 : 0;
         std::map<int, int> value;
-        for (size_t i = 0; i < sol->col.size(); i++) value[sol->col[i]] = sol->val[i];
+        const int num_comp = n * (n + 1);   // 2 * numPat columns per graph
+        for (size_t i = 0; i < sol->col.size(); i++) {
+            int x = sol->col[i];
+            if (n_blocks > 0) {              // joint solution: columns of this graph's block, epsilons (x >= numComp*G) excluded (localhap.cpp:536)
+                if (x < 0 || x >= num_comp * n_blocks || x / num_comp != block) continue;
+                x -= block * num_comp;
+            }
+            value[x] = sol->val[i];
+        }
         for (auto& kv : value) {
             int il, a, b;
             if (kv.second <= 0) continue;
@@ -95,7 +103,7 @@ int HostBatch::add_graph_chr(const LhGraph& g, int chr, const SolFile* sol) {
             el_loop.push_back(il); el_a.push_back(a - base); el_b.push_back(b - base); el_cn.push_back(kv.second);
         }
     }
-    int has_comp = 0;
+    int has_comp = n_blocks > 0 ? 1 : 0;
     for (auto& c : g.components)
         if (!c.empty() && c[0] >= 1 && c[0] <= g.n_seg() && g.seg_partition[c[0] - 1] == chr) has_comp = 1;
     int u = add_unit(n, base, cn.data(), (int)js.size(), js.data(), jt.data(), jsd.data(), jtd.data(), jc.data(),

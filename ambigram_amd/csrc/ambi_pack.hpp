@@ -34,7 +34,10 @@ struct HostBatch {
                  const int32_t* e_is_loop, const int32_t* e_a, const int32_t* e_b, const int32_t* e_cn, int infeasible,
                  int has_components);
     // One chromosome of a parsed .lh plus the .sol columns of that chromosome (localhap.cpp:111-232).
-    int add_graph_chr(const LhGraph& g, int chr, const SolFile* sol);
+    // block / n_blocks: `--op sc_bfb` (localhap.cpp:540-566): the solution of graph `block` sits in the columns
+    // [block*numComp, (block+1)*numComp) of a joint .sol; such a unit never takes the no-fold-back shortcut (that decision
+    // is the caller's, from the first graph alone, localhap.cpp:505-512).
+    int add_graph_chr(const LhGraph& g, int chr, const SolFile* sol, int block = 0, int n_blocks = 0);
     void finalize();                          // computes result/ideal/scratch offsets
     int64_t header_bytes() const { return int64_t(sizeof(UnitOut)) * (int64_t)units.size(); }
 };

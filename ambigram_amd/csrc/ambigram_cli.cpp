@@ -66,18 +66,190 @@ void merge_steps(std::vector<OutJ>& acc, int u, int v, double c, bool increase) 
 
 int die(const std::string& msg) { std::cerr << msg << std::endl; return 1; }
 
+// `--op sc_bfb` (localhap.cpp:390-679): --in_lh is a comma-separated list of .lh files over the same segmentation; one
+// joint ILP per chromosome (BFB_ILP_SC), the block k*numComp..(k+1)*numComp of its solution belongs to graph k.  All
+// graphs x chromosomes are ONE reconstruct batch.  --juncdb / --junc_info are accepted and ignored, as in the reference.
+int run_sc_bfb(Args& A) {
+    auto t_begin = std::chrono::steady_clock::now();
+    const std::string lh_list = A.kv["in_lh"], prefix = A.kv["lp_prefix"];
+    const bool reversed = truthy(A.kv["reversed"]), all = truthy(A.kv["all"]);
+    std::vector<std::string> files;
+    { std::stringstream ss(lh_list); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) files.push_back(t); }   // strtok_r(.., ","): empty fields skipped
+    if (files.empty()) return die("Cannot open file ");
+    const int G = (int)files.size();
+    std::vector<ambi_graph_t*> gs(G, nullptr);
+    int rc;
+    for (int k = 0; k < G; k++) {
+        rc = ambi_graph_read_lh(files[k].c_str(), &gs[k]);
+        if (rc == AMBI_ERR_OPEN) return die("Cannot open file " + files[k]);
+        if (rc != 0) return die(std::string("input error: ") + ambi_error_string(rc));
+        size_t printed = 0;
+        print_log(gs[k], &printed);
+    }
+    {   // localhap.cpp:438-439: calculateHapDepth / calculateCopyNum a second time on the first graph
+        int64_t before = ambi_graph_log(gs[0], nullptr, 0);
+        if ((rc = ambi_graph_recalculate(gs[0])) != 0) return die(ambi_error_string(rc));
+        size_t printed = (size_t)before;
+        print_log(gs[0], &printed);
+    }
+    ambi_graph_t* g0 = gs[0];
+    int32_t n_seg, n_junc, n_chr, ins_mode, con_mode;
+    char main_chr[256];
+    ambi_graph_sizes(g0, &n_seg, &n_junc, &n_chr);
+    ambi_graph_props(g0, &ins_mode, &con_mode, main_chr, sizeof(main_chr));   // PROP of the first file (lhRawFn is cut at the first comma)
+    for (int k = 1; k < G; k++) {
+        int32_t ns, nj, nc;
+        ambi_graph_sizes(gs[k], &ns, &nj, &nc);
+        if (ns != n_seg || nc != n_chr) return die("sc_bfb: the graphs do not share one segmentation");
+    }
+    // probe batch: every graph x chromosome -- fold-back CNs of every graph (BFB_ILP_SC calls getJuncCN per graph,
+    // LGM.cpp:4794), the first graph's getIndelBias (localhap.cpp:497) and its shortcut decision (:505)
+    ambi_batch_t* probe; ambi_batch_create(&probe);
+    for (int c = 0; c < n_chr; c++) for (int k = 0; k < G; k++)
+        if ((rc = ambi_batch_add_chromosome(probe, gs[k], c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
+    if ((rc = ambi_batch_upload(probe)) != 0 || (rc = ambi_batch_run(probe, 0, nullptr)) != 0 || (rc = ambi_batch_download(probe)) != 0)
+        return die(std::string("engine: ") + ambi_error_string(rc));
+    std::vector<std::vector<double>> cn(G, std::vector<double>(n_seg));
+    for (int k = 0; k < G; k++) ambi_graph_segments(gs[k], nullptr, nullptr, nullptr, nullptr, nullptr, cn[k].data());
+    ambi_batch_t* b; ambi_batch_create(&b);
+    std::vector<std::string> head(n_chr);
+    std::vector<int> first_unit(n_chr, -1);   // unit of (chromosome c, graph 0) in the reconstruct batch; graph k follows at +k
+    std::vector<char> plain(n_chr, 0);
+    const double solver_timeout = A.kv.count("solver_timeout") ? atof(A.kv["solver_timeout"].c_str()) : 0;
+    int units = 0;
+    for (int c = 0; c < n_chr; c++) {
+        int32_t s, e;
+        ambi_graph_chromosome(g0, c, &s, &e);
+        const int n = e - s + 1;
+        std::vector<double> seg(G * (size_t)n), fold(G * (size_t)n), junc_cn(2 * (n + 1)), seg_cn(n + 1);
+        ambi_unit_result_t pr0{};
+        for (int k = 0; k < G; k++) {
+            ambi_unit_result_t pr; ambi_batch_unit_result(probe, c * G + k, &pr);
+            if (k == 0) pr0 = pr;
+            ambi_batch_unit_prepare(probe, c * G + k, junc_cn.data(), seg_cn.data(), nullptr, nullptr);
+            if (k == 0) for (int i = 1; i <= n; i++) cn[0][s - 1 + i - 1] = seg_cn[i];   // getIndelBias edits the first graph only
+            for (int i = 0; i < n; i++) { seg[(size_t)k * n + i] = cn[k][s - 1 + i]; fold[(size_t)k * n + i] = junc_cn[2 * (i + 1) + 1]; }
+        }
+        if (pr0.status == AMBI_ST_SHORTCUT) { plain[c] = 1; continue; }   // no fold-back in the first graph: reference paths, nothing printed (:505-512)
+        ambi_ilp_t* ilp = nullptr;
+        if ((rc = ambi_ilp_build_sc(g0, c, G, seg.data(), fold.data(), &ilp)) != 0) return die(ambi_error_string(rc));
+        head[c] = "Declare done\n";
+        for (int k = 0; k < G; k++) head[c] += "ILP formula done\n";
+        head[c] += "Variable constrains done\n";
+        ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());
+        ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
+        ambi_ilp_destroy(ilp);
+        (void)remove(("./" + prefix + ".sol").c_str());
+        std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:527-529
+        if (solver_timeout > 0) { char t[64]; snprintf(t, sizeof(t), "timeout -k 5 %.0f ", solver_timeout); cmd = t + cmd; }
+        std::cout.flush();
+        const int solver_rc = system(cmd.c_str());
+        if (solver_rc != 0) std::cerr << "ILP warning: `" << cmd << "` ended with status " << (WIFEXITED(solver_rc) ? WEXITSTATUS(solver_rc) : -1) << std::endl;
+        first_unit[c] = units;
+        for (int k = 0; k < G; k++) {
+            rc = ambi_batch_add_chromosome_sol_block(b, gs[k], c, ("./" + prefix + ".sol").c_str(), k, G);
+            if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:533-536
+            if (rc < 0) return die(ambi_error_string(rc));
+            units++;
+        }
+    }
+    ambi_batch_destroy(probe);
+    if (units > 0 && ((rc = ambi_batch_upload(b)) != 0 ||
+                      (rc = ambi_batch_run(b, (reversed ? AMBI_FLAG_REVERSED : 0u) | (all ? AMBI_FLAG_ALL : 0u), nullptr)) != 0 ||
+                      (rc = ambi_batch_download(b)) != 0))
+        return die(std::string("engine: ") + ambi_error_string(rc));
+    std::vector<std::vector<std::vector<int32_t>>> paths(G, std::vector<std::vector<int32_t>>(n_chr));
+    int refused = 0;
+    for (int c = 0; c < n_chr; c++) {
+        int32_t s, e;
+        ambi_graph_chromosome(g0, c, &s, &e);
+        auto reference_path = [&](int k) { paths[k][c].clear(); for (int i = s; i <= e; i++) paths[k][c].push_back(i); };
+        if (plain[c]) { for (int k = 0; k < G; k++) reference_path(k); continue; }
+        std::cout << head[c];
+        ambi_unit_result_t r0; ambi_batch_unit_result(b, first_unit[c], &r0);
+        if (r0.status == AMBI_ST_INFEASIBLE) {   // localhap.cpp:543-551
+            std::cout << "ILP is unsolvable.\n";
+            for (int k = 0; k < G; k++) reference_path(k);
+            continue;
+        }
+        for (int k = 0; k < G; k++) {
+            const int u = first_unit[c] + k;
+            ambi_unit_result_t r; ambi_batch_unit_result(b, u, &r);
+            if (r.status != AMBI_ST_OK) {
+                std::cout.flush();
+                std::cerr << "sc_bfb: graph " << k << " chromosome " << c << ": " << ambi_error_string(r.status) << std::endl;
+                refused++;
+                continue;
+            }
+            std::vector<int32_t> p(r.path_len), q(r.path_indel_len);
+            ambi_batch_unit_path(b, u, 0, p.data(), r.path_len);
+            ambi_batch_unit_path(b, u, 1, q.data(), r.path_indel_len);
+            if (all) {
+                const int64_t stride = 2ll * r.path_len + 64;
+                for (int pass = 0; pass < 2; pass++) {
+                    int64_t nv = 0;
+                    ambi_batch_all_count(b, u, pass, &nv);
+                    for (int64_t lo = 0; lo < nv; lo += 64) {
+                        const int64_t cnt = nv - lo < 64 ? nv - lo : 64;
+                        std::vector<int32_t> len((size_t)cnt), cells((size_t)(cnt * stride));
+                        if ((rc = ambi_batch_all_paths(b, u, pass, lo, cnt, len.data(), cells.data(), stride)) != 0) return die(std::string("sc_bfb --all: ") + ambi_error_string(rc));
+                        for (int64_t j = 0; j < cnt; j++) {
+                            if (len[j] < 0) return die(std::string("sc_bfb --all: ") + ambi_error_string(len[j]));
+                            std::vector<int32_t> pj(cells.begin() + j * stride, cells.begin() + j * stride + len[j]);
+                            std::cout << path_text(gs[k], pj) << std::endl;
+                        }
+                    }
+                }
+            } else
+                std::cout << path_text(gs[k], p) << std::endl;
+            if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(gs[k], q) << std::endl;
+            paths[k][c] = q;
+        }
+    }
+    ambi_batch_destroy(b);
+    if (refused) return die("sc_bfb: " + std::to_string(refused) + " unit(s) without a path");
+    int path_len = 0, cn_sum = 0, max_cn_i = 0;
+    for (int k = 0; k < G; k++) {   // localhap.cpp:654-660
+        for (auto& p : paths[k]) path_len += (int)p.size();
+        for (double v : cn[k]) { cn_sum += v; max_cn_i = (max_cn_i > v) ? max_cn_i : v; }
+    }
+    if (ins_mode == 2 || con_mode == 2) {   // :661-664: every graph
+        if (!main_chr[0]) return die("BFB-TRX needs PROP M:<chr>");
+        for (int k = 0; k < G; k++) {
+            std::cout << "BFB with translocation:\n";
+            std::vector<int64_t> offs(n_chr + 1, 0);
+            for (int c = 0; c < n_chr; c++) offs[c + 1] = offs[c] + (int64_t)paths[k][c].size();
+            std::vector<int32_t> flat((size_t)offs[n_chr] + 1), out((size_t)offs[n_chr] * 2 + 16);
+            for (int c = 0; c < n_chr; c++) std::copy(paths[k][c].begin(), paths[k][c].end(), flat.begin() + offs[c]);
+            int len = ambi_translocation_bfb(gs[k], flat.data(), offs.data(), n_chr, out.data(), (int32_t)out.size());
+            if (len < 0) return die(ambi_error_string(len));
+            out.resize(len);
+            std::cout << path_text(gs[k], out) << std::endl;
+        }
+    }
+    {   // time.csv (localhap.cpp:666-678): name of the first file up to its first '.', first graph's sizes, sums over all graphs
+        auto t_end = std::chrono::steady_clock::now();
+        std::ofstream tf("time.csv", std::ios_base::app);
+        tf << files[0].substr(0, files[0].find(".")) << "," << n_seg << "," << 0 << "," << n_junc << "," << cn_sum << "," << path_len << ","
+           << max_cn_i << "," << std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_begin).count() / 1000000.0 << "\n";
+    }
+    for (auto* g : gs) ambi_graph_destroy(g);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     Args A = parse(argc, argv);
     if (A.help) {
-        std::cout << "Local Haplotype constructer\nUsage:\n  Ambigram --op bfb --in_lh <file> --lp_prefix <name> [--juncdb <file> --junc_info true] "
+        std::cout << "Local Haplotype constructer\nUsage:\n  Ambigram --op bfb|sc_bfb --in_lh <file[,file...]> --lp_prefix <name> [--juncdb <file> --junc_info true] "
                      "[--reversed true] [--all true] [--solver_timeout <seconds>]\n";
         return 0;
     }
     const std::string op = A.kv.count("op") ? A.kv["op"] : "";
     std::cout << op << std::endl;   // localhap.cpp:47
-    if (op != "bfb") return die(op == "sc_bfb" ? "sc_bfb is not supported by the MI355X engine yet" : "unknown --op");
+    if (op == "sc_bfb") return run_sc_bfb(A);
+    if (op != "bfb") return 0;   // the reference does nothing for any other op (localhap.cpp:49, :390)
     auto t_begin = std::chrono::steady_clock::now();
     const std::string lh = A.kv["in_lh"], prefix = A.kv["lp_prefix"], juncs = A.kv.count("juncdb") ? A.kv["juncdb"] : "";
     const bool junc_info = truthy(A.kv["junc_info"]), reversed = truthy(A.kv["reversed"]), all = truthy(A.kv["all"]);

@@ -78,7 +78,7 @@ bool LhGraph::add_junction(int src, int sdir, int tgt, int tdir, double cov, dou
     return true;
 }
 
-static int hap_depth(LhGraph& g) {   // Graph.cpp:312-367
+int hap_depth(LhGraph& g) {   // Graph.cpp:312-367
     if (g.avg_ploidy < 0) {
         if (g.avg_tumor_ploidy < 0 || g.purity < 0) return LH_ERR_PLOIDY;
         g.avg_ploidy = g.purity * g.avg_tumor_ploidy + (1 - g.purity) * 2;
@@ -100,7 +100,7 @@ static int hap_depth(LhGraph& g) {   // Graph.cpp:312-367
     return LH_OK;
 }
 
-static void copy_num(LhGraph& g) {   // Graph.cpp:369-405: only entries with CN <= 0 are (re)computed
+void copy_num(LhGraph& g) {   // Graph.cpp:369-405: only entries with CN <= 0 are (re)computed
     for (int i = 0; i < g.n_seg(); i++) {
         if (g.seg_cn[i] > 0) continue;
         double c;

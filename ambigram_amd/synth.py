@@ -302,3 +302,21 @@ def config_sample(config, index=0, tier="chain", K=9):
     if config == 4:
         return make_sample(1024, 2048, tier, K, seed, n_chr=8, translocations=1, trx_insertions=3, prop="PROP C2:chr1:chr2 M:chr1")
     raise ValueError(config)
+
+
+def joint_sol_texts(samples):
+    """`--op sc_bfb`: the joint .sol of several samples with the same segmentation, one text per chromosome: the columns of
+    sample k are shifted into block k (x + k * numComp, numComp = n(n+1) for a chromosome of n segments; localhap.cpp:540-566)."""
+    out = []
+    for c, (s, e) in enumerate(samples[0].chr_ranges):
+        n = e - s + 1
+        num_comp = n * (n + 1)
+        lines = ["Optimal - objective value 0.00000000"]
+        for k, smp in enumerate(samples):
+            assert smp.chr_ranges == samples[0].chr_ranges
+            for line in smp.sol_texts[c].splitlines()[1:]:
+                t = line.split()
+                col = int(t[0]) + k * num_comp
+                lines.append("%7d x%-7d %15s %15s" % (col, col, t[2], t[3]))
+        out.append("\n".join(lines) + "\n")
+    return out

@@ -85,6 +85,9 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
 /* Components collected by ambi_graph_read_juncs (the `res` of readComponents, LocalGenomicMap.cpp:5096-5156, after its
  * sort/unique): component c = ids[offsets[c] .. offsets[c+1]).  Returns the number of components; copies at most
  * ids_cap ids and off_cap offsets (offsets needs count+1 entries). */
+/* calculateHapDepth + calculateCopyNum once more (`--op sc_bfb` does that to its first graph, localhap.cpp:438-439): entries
+ * whose copy number is still <= 0 are recomputed and echoed again; new lines are appended to the graph's log. */
+int ambi_graph_recalculate(ambi_graph_t* g);
 int ambi_graph_components(const ambi_graph_t* g, int32_t* ids, int32_t ids_cap, int32_t* offsets, int32_t off_cap);
 
 /* ------------------------------------------------------------------------------------------------
@@ -104,6 +107,11 @@ int ambi_batch_add_chromosome(ambi_batch_t* b, const ambi_graph_t* g, int32_t ch
                               const int32_t* val, int32_t infeasible);
 /* Same, reading the .sol text (localhap.cpp:184-212).  A missing file returns AMBI_ERR_SOL_OPEN. */
 int ambi_batch_add_chromosome_sol(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, const char* sol_path);
+/* `--op sc_bfb` (localhap.cpp:390-679): several graphs share ONE joint .sol per chromosome; graph `block` of `n_blocks`
+ * owns the columns [block*numComp, (block+1)*numComp) (localhap.cpp:540-566).  The unit reconstructs with that block's
+ * elements and never takes the no-fold-back shortcut by itself (the driver decides it from the first graph, :505-512). */
+int ambi_batch_add_chromosome_sol_block(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, const char* sol_path, int32_t block,
+                                        int32_t n_blocks);
 /* Raw unit: LOCAL segment ids 1..n_seg (absolute id = local + seg_base), junctions with both ends inside the unit,
  * elements (is_loop, a, b, cn) of the decomposition. */
 int ambi_batch_add_unit(ambi_batch_t* b, int32_t n_seg, int32_t seg_base, const double* seg_cn, int32_t n_junc,
@@ -237,6 +245,13 @@ int ambi_ilp_build(const ambi_graph_t* g, int32_t chr, const double* seg_cn, con
  * fill kernel, for the roofline (algorithmic bytes = 12 * nnz). */
 int ambi_ilp_build_device(const ambi_graph_t* g, int32_t chr, const double* seg_cn, const double* junc_cn, int32_t bias,
                           double max_cn_total, int32_t juncs_info, float* kernel_ms, ambi_ilp_t** out);
+/* Joint model of `--op sc_bfb` (LocalGenomicMap::BFB_ILP_SC, LocalGenomicMap.cpp:4754-5093) for chromosome `chr` of
+ * n_graphs graphs with the same segmentation: seg_cn / fold_cn are n_graphs x n (graph-major; n = segments of the
+ * chromosome): the segment copy numbers (first graph after its getIndelBias, localhap.cpp:497) and the fold-back copy
+ * numbers juncCN[i][1] of every graph's own getJuncCN (LocalGenomicMap.cpp:4794).  Linking rows for every pair of graphs
+ * (localhap.cpp:430-434).  The matrix is the one the reference builds, including its use of the running row counter in
+ * the epsilon columns (LocalGenomicMap.cpp:4815) -- see DESIGN.md. */
+int ambi_ilp_build_sc(const ambi_graph_t* g0, int32_t chr, int32_t n_graphs, const double* seg_cn, const double* fold_cn, ambi_ilp_t** out);
 void ambi_ilp_destroy(ambi_ilp_t* p);
 int ambi_ilp_sizes(const ambi_ilp_t* p, int64_t* n_rows, int64_t* nnz, int32_t* n_cols, int32_t* n_int);
 /* CSR copy-out; infinity is +-DBL_MAX (OsiClp getInfinity()); any pointer may be NULL */

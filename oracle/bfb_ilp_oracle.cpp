@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <set>
 #include <string>
 
@@ -141,6 +142,128 @@ void buildBfbIlp(const Graph& g, int startSegID, int endSegID, const std::vector
     for (int c = 0; c < numVariables; c++) m.obj[c] = (c < numElements) ? 0 : (c < numVariables - 1 ? 1 : -1);
     m.numInt = numElements;
     (void)idx;
+}
+
+// LocalGenomicMap::BFB_ILP_SC (LGM.cpp:4754-5093), restated literally: std::map<std::string,int> variableIdx with the
+// per-graph "+= numComp" shift (:4784-4791), the running row counter `idx` in the epsilon column of the segment rows
+// (:4815, :4821, :4858, :4864), `cnt` for the linking epsilons (:5031-5072).  juncCNs[g] = getJuncCN of graph g.
+void buildBfbIlpSc(const std::vector<const Graph*>& graphs, int startSegID, int endSegID, const std::vector<std::vector<double>>& juncCNs,
+                   const std::vector<std::vector<int>>& evolution, IlpModel& m) {
+    const double INF = DBL_MAX;
+    const int numGraphs = (int)graphs.size();
+    std::vector<std::vector<int>> patterns;
+    for (int a = startSegID; a <= endSegID; a++)
+        for (int b = a; b <= endSegID; b++) patterns.push_back({a, b});
+    const std::vector<std::vector<int>>& loops = patterns;
+    int numPatTmp = 0;
+    std::map<std::string, int> variableIdx = makeVariableIdx(startSegID, endSegID, &numPatTmp);
+    auto ps = [](int a, int b) { return "p:" + std::to_string(a) + "," + std::to_string(b); };
+    auto ls = [](int a, int b) { return "l:" + std::to_string(a) + "," + std::to_string(b); };
+    const int numSegments = endSegID - startSegID + 1;
+    const int numElements = (int)variableIdx.size() * numGraphs;
+    const int numEpsilons = numSegments * 2 * numGraphs + (numGraphs * (numGraphs - 1)) * (int)variableIdx.size();
+    const int numVariables = numElements + numEpsilons, numPat = (int)patterns.size(), numLoop = (int)loops.size();
+    const int numComp = numPat + numLoop;
+    m = IlpModel();
+    m.numCols = numVariables;
+    m.rowPtr.push_back(0);
+    m.colLo.assign(numVariables, 0); m.colUp.assign(numVariables, 0); m.obj.assign(numVariables, 0);
+    int idx = 0;
+    auto put = [&](int c, double v) { m.colIdx.push_back(c); m.val.push_back(v); };
+    auto endRow = [&](double lo, double up) { m.rowPtr.push_back((int64_t)m.colIdx.size()); m.rowLo.push_back(lo); m.rowUp.push_back(up); idx++; };
+    for (int n = 0; n < numGraphs; n++) {
+        std::vector<const Seg*> segs;
+        for (auto& sg : graphs[n]->segs) if (startSegID <= sg.id && sg.id <= endSegID) segs.push_back(&sg);
+        if (n > 0)
+            for (int i = 0; i < numPat; i++) { variableIdx[ps(patterns[i][0], patterns[i][1])] += numComp; variableIdx[ls(patterns[i][0], patterns[i][1])] += numComp; }
+        const std::vector<double>& juncCN = juncCNs[n];
+        for (int i = startSegID; i <= endSegID; i++) {
+            std::vector<std::pair<int, double>> c1;
+            for (int j = 0; j < numPat; j++) if (patterns[j][0] <= i && i <= patterns[j][1]) c1.push_back({variableIdx[ps(patterns[j][0], patterns[j][1])], 1});
+            for (int j = 0; j < numLoop; j++) if (loops[j][0] <= i && i <= loops[j][1]) c1.push_back({variableIdx[ls(loops[j][0], loops[j][1])], 2});
+            for (auto& e : c1) put(e.first, e.second);
+            put(numElements + idx / 2, 1); endRow(segs[i - startSegID]->cn, INF);
+            for (auto& e : c1) put(e.first, e.second);
+            put(numElements + idx / 2, -1); endRow(-INF, segs[i - startSegID]->cn);
+            std::vector<double> coef(numElements, 0.0);
+            for (int j = 0; j < numLoop; j++) if (loops[j][0] == i || loops[j][1] == i) coef[variableIdx[ls(loops[j][0], loops[j][1])]] += 1;
+            for (int j = 0; j < numPat; j++)
+                for (int k = 0; k < numPat; k++)
+                    if ((patterns[j][0] == i && patterns[k][0] == i) || (patterns[j][1] == i && patterns[k][1] == i)) {
+                        int diff1 = patterns[j][0] - patterns[j][1], diff2 = patterns[k][0] - patterns[k][1];
+                        if (std::abs(diff1) > std::abs(diff2)) {
+                            coef[variableIdx[ps(patterns[j][0], patterns[j][1])]] = 0.5;
+                            coef[variableIdx[ps(patterns[k][0], patterns[k][1])]] = 0.5;
+                        }
+                    }
+            std::vector<std::pair<int, double>> c5;
+            for (int q = 0; q < numElements; q++) if (coef[q] > 0.1) c5.push_back({q, coef[q]});
+            for (auto& e : c5) put(e.first, e.second);
+            put(numElements + idx / 2, 1); endRow(juncCN[i * 2 + 1], INF);
+            for (auto& e : c5) put(e.first, e.second);
+            put(numElements + idx / 2, -1); endRow(-INF, juncCN[i * 2 + 1]);
+        }
+        for (int i = 0; i < numPat; i++) {   // LGM.cpp:4867-4911
+            std::vector<std::pair<int, double>> c8, c9;
+            bool flag1 = false, flag2 = false;
+            for (int j = startSegID; j < patterns[i][0]; j++) { flag1 = true; c8.push_back({variableIdx[ps(j, patterns[i][1])], 1}); }
+            for (int j = patterns[i][1] + 1; j <= endSegID; j++) { flag1 = true; c8.push_back({variableIdx[ps(patterns[i][0], j)], 1}); }
+            for (int j = patterns[i][0]; j < patterns[i][1]; j++) { flag2 = true; c9.push_back({variableIdx[ps(patterns[i][0], j)], 1}); }
+            for (int j = patterns[i][0] + 1; j <= patterns[i][1]; j++) { flag2 = true; c9.push_back({variableIdx[ps(j, patterns[i][1])], 1}); }
+            if (flag1) { for (auto& e : c8) put(e.first, e.second); put(variableIdx[ps(patterns[i][0], patterns[i][1])], -1); endRow(0, INF); }
+            if (flag2) { for (auto& e : c9) put(e.first, e.second); put(variableIdx[ps(patterns[i][0], patterns[i][1])], 1); endRow(0, 2); }
+        }
+        for (int i = 0; i < numLoop; i++) {   // :4914-4940
+            std::vector<std::pair<int, double>> c9;
+            bool flag = false;
+            for (int j = startSegID; j < loops[i][0]; j++) { flag = true; c9.push_back({variableIdx[ps(j, loops[i][1])], 1}); c9.push_back({variableIdx[ls(j, loops[i][1])], 1}); }
+            for (int j = loops[i][1] + 1; j <= endSegID; j++) { flag = true; c9.push_back({variableIdx[ps(loops[i][0], j)], 1}); c9.push_back({variableIdx[ls(loops[i][0], j)], 1}); }
+            if (flag) { for (auto& e : c9) put(e.first, e.second); put(variableIdx[ls(loops[i][0], loops[i][1])], -1); endRow(0, INF); }
+        }
+        for (int i = 0; i < numLoop; i++) {   // :4943-4974
+            std::vector<std::pair<int, double>> c10;
+            bool flag = false;
+            for (int j = loops[i][0]; j < loops[i][1]; j++) { flag = true; c10.push_back({variableIdx[ls(loops[i][0], j)], 1}); }
+            for (int j = loops[i][0] + 1; j <= loops[i][1]; j++) { flag = true; c10.push_back({variableIdx[ls(j, loops[i][1])], 1}); }
+            if (flag) {
+                for (auto& e : c10) put(e.first, e.second); put(variableIdx[ls(patterns[i][0], patterns[i][1])], 1); endRow(0, 2);
+                for (auto& e : c10) put(e.first, e.second); put(variableIdx[ps(patterns[i][0], patterns[i][1])], 1); endRow(0, 2);
+            }
+        }
+        for (int i = 0; i < numPat; i++) {   // :4977-5008
+            std::vector<std::pair<int, double>> c10, c11;
+            bool flag = false;
+            for (int j = patterns[i][0]; j < patterns[i][1]; j++) { flag = true; c10.push_back({variableIdx[ls(patterns[i][0], j)], 1}); c11.push_back({variableIdx[ps(patterns[i][0], j)], 1}); }
+            for (int j = patterns[i][0] + 1; j <= patterns[i][1]; j++) { flag = true; c10.push_back({variableIdx[ps(j, patterns[i][1])], 1}); c11.push_back({variableIdx[ls(j, patterns[i][1])], 1}); }
+            if (flag) {
+                const int key = variableIdx[ps(patterns[i][0], patterns[i][1])];
+                for (auto& e : c10) put(e.first, e.second); put(key, 1); endRow(0, 2);
+                for (auto& e : c11) put(e.first, e.second); put(key, 1); endRow(0, 2);
+            }
+        }
+        double maxCN = 0;
+        for (auto* sg : segs) maxCN += sg->cn;
+        for (int i = 0; i < numPat; i++) { int c = variableIdx[ps(patterns[i][0], patterns[i][1])]; m.colLo[c] = 0; m.colUp[c] = 1; }
+        for (int i = 0; i < numLoop; i++) { int c = variableIdx[ls(loops[i][0], loops[i][1])]; m.colLo[c] = 0; m.colUp[c] = maxCN; }
+    }
+    int cnt = (numElements + numSegments * 2 * numGraphs) * 2;
+    for (auto& kv : variableIdx) kv.second = kv.second % numComp;
+    for (size_t i = 0; i < evolution.size(); i++)
+        for (int j : evolution[i]) {
+            for (int k = 0; k < numPat; k++) {
+                const int c = variableIdx[ps(patterns[k][0], patterns[k][1])];
+                put(c + numComp * (int)i, 1); put(c + numComp * j, -1); put(cnt / 2, 1); endRow(0, INF); cnt++;
+                put(c + numComp * (int)i, 1); put(c + numComp * j, -1); put(cnt / 2, -1); endRow(-INF, 0); cnt++;
+            }
+            for (int k = 0; k < numLoop; k++) {
+                const int c = variableIdx[ls(loops[k][0], loops[k][1])];
+                put(c + numComp * (int)i, 1); put(c + numComp * j, -1); put(cnt / 2, 1); endRow(0, INF); cnt++;
+                put(c + numComp * (int)i, 1); put(c + numComp * j, -1); put(cnt / 2, -1); endRow(-INF, 0); cnt++;
+            }
+        }
+    for (int i = 0; i < numEpsilons; i++) { m.colLo[numElements + i] = 0; m.colUp[numElements + i] = INF; }
+    for (int i = 0; i < numVariables; i++) m.obj[i] = i < numElements ? 0 : 1;
+    m.numInt = numElements;
 }
 
 }  // namespace oracle

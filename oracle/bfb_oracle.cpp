@@ -1006,4 +1006,117 @@ RunResult runBfb(const RunOptions& opt) {
     return R;
 }
 
+// ------------------------------------------------------------------------------------------
+// whole `--op sc_bfb` run  (localhap.cpp:390-679)
+// ------------------------------------------------------------------------------------------
+ScResult runScBfb(const std::vector<std::string>& lhs, const RunOptions& opt) {
+    ScResult R;
+    R.log.push_back("sc_bfb");
+    std::vector<Graph> graphs(lhs.size());
+    for (size_t k = 0; k < lhs.size(); k++) {   // :402-414
+        if (!readGraph(lhs[k], graphs[k], R.err)) return R;
+        if (!calculateHapDepth(graphs[k], R.err)) return R;
+        calculateCopyNum(graphs[k]);
+        for (auto& l : graphs[k].log) R.log.push_back(l);
+        graphs[k].log.clear();
+    }
+    const int numGraphs = (int)graphs.size();
+    if (numGraphs == 0) { R.err = "no .lh"; return R; }
+    std::vector<std::vector<int>> evolution(numGraphs);   // :430-434 (the `edges` option is hard-wired to "")
+    for (int i = 0; i < numGraphs; i++) for (int j = i + 1; j < numGraphs; j++) evolution[i].push_back(j);
+    Graph& g = graphs[0];
+    if (!calculateHapDepth(g, R.err)) return R;   // :438-439: a second time on the first graph
+    calculateCopyNum(g);
+    for (auto& l : g.log) R.log.push_back(l);
+    g.log.clear();
+    Props props;
+    readBFBProps(lhs[0], props);                  // lhRawFn was cut at the first comma by strtok_r (:405-407)
+    if (props.insMode == 1 || props.conMode == 1) { R.err = "TRX-BFB (I1/C1) not supported"; return R; }
+    for (size_t i = 0; i < g.sourceIds.size(); i++)
+        for (int j = g.sourceIds[i]; j <= g.sinkIds[i]; j++) {
+            if (j - 1 < 0 || j - 1 >= (int)g.segs.size()) { R.err = "segment ids must be 1..N"; return R; }
+            g.segs[j - 1].partition = (int)i;
+        }
+    R.paths.assign(numGraphs, {});
+    std::vector<int> targetCN(g.segs.size(), 0);
+    size_t solCursor = 0;
+    for (size_t n = 0; n < g.sourceIds.size(); n++) {
+        int startID = g.sourceIds[n], endID = g.sinkIds[n];
+        int numPat = 0;
+        std::map<std::string, int> variableIdx = makeVariableIdx(startID, endID, &numPat);
+        int numComp = (int)variableIdx.size();
+        Inversions inversions; std::vector<double> juncCN;
+        getJuncCN(g, startID, endID, inversions, juncCN);
+        (void)computeBias(g, startID, endID, inversions, juncCN);
+        getIndelBias(g, startID, endID);          // :497, on the FIRST graph only
+        double inversionCNSum = 0;
+        for (int i = 0; i <= endID; i++) inversionCNSum += juncCN[i * 2 + 1];
+        std::vector<ChrStage> stages(numGraphs);
+        if (std::abs(inversionCNSum) < 0.000001) {   // :505-512: decided by the first graph; nothing is printed
+            for (int k = 0; k < numGraphs; k++) {
+                std::vector<int> temp;
+                for (int i = startID; i <= endID; i++) temp.push_back(i);
+                R.paths[k].push_back(temp);
+                stages[k].shortcut = true;
+            }
+            R.chr.push_back(stages);
+            continue;
+        }
+        R.log.push_back("Declare done");             // BFB_ILP_SC: LGM.cpp:4773, :5010 (once per graph), :5084
+        for (int k = 0; k < numGraphs; k++) R.log.push_back("ILP formula done");
+        R.log.push_back("Variable constrains done");
+        if (solCursor >= opt.solPerChr.size()) { R.err = "missing .sol for chromosome " + std::to_string(n); return R; }
+        Sol sol;
+        if (!readSol(opt.solPerChr[solCursor++], sol)) { R.err = "ILP error: cannot open file"; return R; }
+        std::vector<int> elementCN((size_t)numComp * numGraphs, 0);
+        for (auto& c : sol.cols) if (c.first >= 0 && c.first < numComp * numGraphs) elementCN[c.first] = c.second;   // :536
+        if (sol.infeasible) {                         // :543-551
+            R.log.push_back("ILP is unsolvable.");
+            for (int k = 0; k < numGraphs; k++) {
+                std::vector<int> temp;
+                for (int i = startID; i <= endID; i++) temp.push_back(i);
+                R.paths[k].push_back(temp);
+                stages[k].infeasible = true;
+            }
+            R.chr.push_back(stages);
+            continue;
+        }
+        for (int k = 0; k < numGraphs; k++) {         // :554-621
+            ChrStage& st = stages[k];
+            st.startID = startID; st.endID = endID;
+            for (auto& kv : variableIdx) kv.second = kv.second % numComp + k * numComp;   // :557-562 (p: i + k*numComp, l: i + numComp/2 + k*numComp)
+            for (auto iter = variableIdx.begin(); iter != variableIdx.end(); iter++)       // :565-576 (accumulated, never read)
+                if (elementCN[iter->second] > 0) {
+                    const std::string& key = iter->first;
+                    int idx1 = stoi(key.substr(2, key.find(",") - 2)), idx2 = stoi(key.substr(key.find(",") + 1));
+                    for (int i = idx1 - 1; i < idx2; i++) targetCN[i] += (key[0] == 'p') ? elementCN[iter->second] : elementCN[iter->second] * 2;
+                }
+            constructDAG(variableIdx, elementCN, st.dag);
+            std::vector<std::vector<int>> orders;
+            allTopologicalOrders(st.dag, orders, opt.maxOrders);
+            st.numOrders = (long)orders.size();
+            Inversions graphInversions;               // :603-604: of graph k
+            getJuncCN(graphs[k], startID, endID, graphInversions, st.juncCN);
+            getBFB(graphs[k], orders, st.dag, graphInversions, opt.reversed, opt.all, st.bfb, R.log);
+            std::vector<int> path = st.bfb.path;
+            st.indelPrinted = indelBFB(graphs[k], path, startID, endID, R.log);
+            st.pathAfterIndel = path;
+            R.paths[k].push_back(path);
+        }
+        R.chr.push_back(stages);
+    }
+    for (int k = 0; k < numGraphs; k++) {             // :654-660
+        for (auto& p : R.paths[k]) R.pathLen += (int)p.size();
+        for (auto& sg : graphs[k].segs) { R.cnSum += sg.cn; R.maxCN = (R.maxCN > sg.cn) ? R.maxCN : sg.cn; }
+    }
+    R.trxPaths.assign(numGraphs, {});
+    if (props.insMode == 2 || props.conMode == 2) {   // :661-664, every graph
+        if (props.mainChr.empty()) { R.err = "BFB-TRX without M:<chr> (reference segfaults)"; return R; }
+        for (int k = 0; k < numGraphs; k++) translocationBFB(graphs[k], R.paths[k], R.trxPaths[k], props.mainChr, R.log);
+    }
+    R.nSeg = (int)g.segs.size(); R.nJunc = (int)g.juncs.size();
+    R.ok = true;
+    return R;
+}
+
 }  // namespace oracle

@@ -183,6 +183,18 @@ struct RunResult {
 };
 RunResult runBfb(const RunOptions& opt);
 
+// ---- whole `--op sc_bfb` run (localhap.cpp:390-679): several .lh files (single cells / sub-clones with the same
+// segmentation) share one joint ILP per chromosome; solPerChr = the joint .sol of every chromosome that reaches the ILP.
+struct ScResult {
+    bool ok = false; std::string err;
+    std::vector<std::string> log;                              // stdout lines, in order
+    std::vector<std::vector<std::vector<int>>> paths;          // [graph][chromosome]
+    std::vector<std::vector<int>> trxPaths;                    // [graph], when PROP asks for BFB-TRX
+    std::vector<std::vector<ChrStage>> chr;                    // [chromosome][graph] stage dumps of reconstructed units
+    int pathLen = 0, cnSum = 0, maxCN = 0, nSeg = 0, nJunc = 0;
+};
+ScResult runScBfb(const std::vector<std::string>& lhs, const RunOptions& opt);
+
 // ---- ILP rows (LGM.cpp:4397-4752), semantic form ------------------------------------------
 struct IlpModel {
     int numCols = 0;
@@ -193,5 +205,9 @@ struct IlpModel {
 void buildBfbIlp(const Graph& g, int startID, int endID, const std::vector<double>& juncCN,
                  const std::vector<std::vector<int>>& components, bool juncsInfo, int bias, IlpModel& m,
                  bool literalHotLoop = false);
+// LGM.cpp:4754-5093 (`--op sc_bfb`): the joint model of several graphs over one chromosome, literal restatement
+void buildBfbIlpSc(const std::vector<const Graph*>& graphs, int startID, int endID, const std::vector<std::vector<double>>& juncCNs,
+                   const std::vector<std::vector<int>>& evolution, IlpModel& m);
+
 
 }  // namespace oracle

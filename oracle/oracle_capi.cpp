@@ -168,6 +168,77 @@ char* oracle_translocation_json(const char* lh, const char* paths) {
     return dup(o.str());
 }
 
+// `--op sc_bfb` (localhap.cpp:390-679): lhs and sols comma separated; flags as oracle_run_bfb.
+char* oracle_run_sc_bfb(const char* lhs, const char* sols, int flags, long long maxOrders) {
+    RunOptions opt;
+    opt.solPerChr = split(sols, ',');
+    opt.reversed = flags & 1; opt.all = flags & 2;
+    if (maxOrders > 0) opt.maxOrders = (size_t)maxOrders;
+    ScResult R = runScBfb(split(lhs, ','), opt);
+    std::ostringstream o;
+    o << "{\"ok\":" << (R.ok ? "true" : "false") << ",\"err\":"; jstr(o, R.err);
+    o << ",\"log\":[";
+    for (size_t i = 0; i < R.log.size(); i++) { if (i) o << ','; jstr(o, R.log[i]); }
+    o << "],\"paths\":[";
+    for (size_t k = 0; k < R.paths.size(); k++) { if (k) o << ','; jarr2(o, R.paths[k]); }
+    o << "],\"trx_paths\":"; jarr2(o, R.trxPaths);
+    o << ",\"path_len\":" << R.pathLen << ",\"cn_sum\":" << R.cnSum << ",\"max_cn\":" << R.maxCN << ",\"n_seg\":" << R.nSeg << ",\"n_junc\":" << R.nJunc;
+    o << ",\"chr\":[";
+    for (size_t c = 0; c < R.chr.size(); c++) {
+        if (c) o << ',';
+        o << '[';
+        for (size_t k = 0; k < R.chr[c].size(); k++) {
+            const ChrStage& s = R.chr[c][k];
+            if (k) o << ',';
+            o << "{\"shortcut\":" << (s.shortcut ? "true" : "false") << ",\"infeasible\":" << (s.infeasible ? "true" : "false")
+              << ",\"num_orders\":" << s.numOrders << ",\"first_valid\":" << s.bfb.firstValidOrder << ",\"first_forward\":" << s.bfb.firstValidOrientationForward
+              << ",\"evaluated\":" << s.bfb.evaluated << ",\"ub\":" << (s.bfb.undefinedBehaviour ? "true" : "false");
+            o << ",\"node2pat\":"; jarr2(o, s.dag.node2pat);
+            o << ",\"node2loop\":"; jarr2(o, s.dag.node2loop);
+            o << ",\"bkp\":"; jarr(o, s.bfb.bkpFirst);
+            o << ",\"path\":"; jarr(o, s.bfb.path);
+            o << ",\"path_indel\":"; jarr(o, s.pathAfterIndel);
+            o << ",\"indel_printed\":" << (s.indelPrinted ? "true" : "false") << "}";
+        }
+        o << ']';
+    }
+    o << "]}";
+    return dup(o.str());
+}
+
+// Joint ILP of chromosome `chr` as main() hands it to BFB_ILP_SC (localhap.cpp:464-515): every graph loaded, the first
+// graph's getIndelBias applied for chromosomes 0..chr.
+char* oracle_ilp_sc_json(const char* lhs, int chr) {
+    std::vector<std::string> files = split(lhs, ',');
+    std::vector<Graph> graphs(files.size());
+    std::ostringstream o;
+    o.precision(17);
+    std::string err;
+    for (size_t k = 0; k < files.size(); k++) {
+        if (!readGraph(files[k], graphs[k], err) || !calculateHapDepth(graphs[k], err)) { o << "{\"ok\":false}"; return dup(o.str()); }
+        calculateCopyNum(graphs[k]);
+    }
+    Graph& g = graphs[0];
+    calculateHapDepth(g, err); calculateCopyNum(g);
+    if (chr < 0 || chr >= (int)g.sinkIds.size()) { o << "{\"ok\":false}"; return dup(o.str()); }
+    for (int c = 0; c <= chr; c++) getIndelBias(g, g.sourceIds[c], g.sinkIds[c]);
+    std::vector<const Graph*> gp; std::vector<std::vector<double>> jcn(graphs.size());
+    for (size_t k = 0; k < graphs.size(); k++) { gp.push_back(&graphs[k]); Inversions inv; getJuncCN(graphs[k], g.sourceIds[chr], g.sinkIds[chr], inv, jcn[k]); }
+    std::vector<std::vector<int>> evolution(graphs.size());
+    for (size_t i = 0; i < graphs.size(); i++) for (size_t j = i + 1; j < graphs.size(); j++) evolution[i].push_back((int)j);
+    IlpModel m;
+    buildBfbIlpSc(gp, g.sourceIds[chr], g.sinkIds[chr], jcn, evolution, m);
+    o << "{\"ok\":true,\"n_cols\":" << m.numCols << ",\"n_int\":" << m.numInt << ",\"row_ptr\":";
+    { std::vector<long long> rp(m.rowPtr.begin(), m.rowPtr.end()); jarr(o, rp); }
+    o << ",\"col\":"; jarr(o, m.colIdx);
+    o << ",\"val\":"; jdarr(o, m.val);
+    o << ",\"row_lo\":"; jdarr(o, m.rowLo); o << ",\"row_up\":"; jdarr(o, m.rowUp);
+    o << ",\"col_lo\":"; jdarr(o, m.colLo); o << ",\"col_up\":"; jdarr(o, m.colUp);
+    o << ",\"obj\":"; jdarr(o, m.obj);
+    o << "}";
+    return dup(o.str());
+}
+
 // Parsed-graph dump (after calculateHapDepth/calculateCopyNum), same JSON shape as oracle/_ref's ref_graph_dump.
 static char* graph_dump_impl(const char* lh, const char* juncs);
 char* oracle_graph_dump(const char* lh) { return graph_dump_impl(lh, nullptr); }

@@ -58,6 +58,24 @@ def run_bfb(lh, sols, juncs="", reversed_=False, all_=False, junc_info=False, ke
     return out
 
 
+def run_sc_bfb(lhs, sols, reversed_=False, all_=False, max_orders=0):
+    """Whole `--op sc_bfb` flow (localhap.cpp:390-679): `lhs` = the .lh files, `sols` = one joint .sol per chromosome that
+    reaches the ILP."""
+    L = lib()
+    L.oracle_run_sc_bfb.restype = ctypes.c_void_p
+    L.oracle_run_sc_bfb.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_longlong]
+    flags = (FLAG_REVERSED if reversed_ else 0) | (FLAG_ALL if all_ else 0)
+    return _take(L.oracle_run_sc_bfb(",".join(lhs).encode(), ",".join(sols).encode(), flags, max_orders))
+
+
+def ilp_sc(lhs, chr_=0):
+    """Joint ILP of `--op sc_bfb` (BFB_ILP_SC, LGM.cpp:4754-5093), literal restatement, as CSR + bounds."""
+    L = lib()
+    L.oracle_ilp_sc_json.restype = ctypes.c_void_p
+    L.oracle_ilp_sc_json.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    return _take(L.oracle_ilp_sc_json(",".join(lhs).encode(), chr_))
+
+
 def graph_dump(lh, juncs=None):
     """Parsed graph (after calculateCopyNum); with `juncs` also after readComponents, plus its components."""
     if juncs is None:
