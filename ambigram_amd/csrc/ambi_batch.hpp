@@ -141,6 +141,8 @@ struct BatchArgs {
     int32_t zero_pending;        // 1: block 0 of the prepare kernel zeroes *n_pending
     int32_t* host_pending;       // device address of a pinned host int32 (nullptr: the host copies n_pending itself)
     int32_t* blocks_done;        // [1] finished workgroups of the lean finish kernel (the last one reports n_pending and resets it)
+    int32_t* refin_list;         // [U] units the lean finish stage hands to the full stage (SVs that chain or edit the path), in any order
+    int32_t* refin_count;        // [1] entries of refin_list; zeroed before the lean kernel, read by the full-stage kernel behind it
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)
     int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)
     // diagnostics hook (ambi_batch_debug_inject_validity): verdicts that REPLACE the outcome of evaluating an order, so that

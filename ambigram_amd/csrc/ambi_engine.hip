@@ -43,7 +43,7 @@ extern __shared__ __align__(16) uint8_t ambi_lds[];
 
 __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
-    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.n_pending = 0;   // nothing counts pending units before the scan
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { *A.n_pending = 0; *A.refin_count = 0; }   // nothing counts pending / handed-over units before the scan
     stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
@@ -436,9 +436,21 @@ __global__ __launch_bounds__(64) void ambi_order_paths_kernel(BatchArgs A, int u
     if (g.tid() == 0) lengths[j] = P;
 }
 
-__global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list) {
+// Full finish stage.  unit_list == nullptr: every unit of the slice (one workgroup each).  With a list: the listed units;
+// list_count == nullptr: one workgroup per entry (host-built list of the slow path), else the list is the one the lean
+// kernel in front of this launch filled on the device (refin_list / refin_count) and the workgroups share it in strides
+// -- no host round trip between the two kernels.
+__global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list, const int32_t* list_count) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
+    if (unit_list && list_count) {
+        const int n = *list_count;
+        for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+            stage_finish(g, A, unit_list[i], ambi_lds);
+            __syncthreads();
+        }
+        return;
+    }
     const int u = unit_list ? unit_list[blockIdx.x] : A.unit_base + (int)blockIdx.x;
     // the scan kernel is complete (stream order): its count of units left for the parallel search goes to the host
     if (A.host_pending && !unit_list && blockIdx.x == 0 && threadIdx.x == 0) *A.host_pending = *A.n_pending;
@@ -607,7 +619,7 @@ class HipBackend : public Backend {
     int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_finish_lean_ = 0, lds_enum_ = 0;
     bool lean_finish_ = true;   // env AMBI_LEAN_FINISH=0: every unit through the full finish stage
     int finish_grid_ = 0;       // workgroups of the lean finish kernel; 0 = sized per run (env AMBI_FINISH_GRID overrides)
-    int32_t* d_blocks_done_ = nullptr;
+    int32_t* d_blocks_done_ = nullptr; int32_t* d_refin_list_ = nullptr; int32_t* d_refin_count_ = nullptr;
     uint32_t* d_anblk_ = nullptr; uint8_t* d_adepth_ = nullptr;
     int finish_path_cells_ = 0;
     std::vector<KernelTime> times_;
@@ -649,14 +661,14 @@ class HipBackend : public Backend {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
-                        d_all_bits_, d_all_off_, d_all_count_, d_all_flags_, d_inject_, d_inject_off_};
+                        d_all_bits_, d_all_off_, d_all_count_, d_all_flags_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
         d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
-        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0;
+        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         h_npending_ = nullptr; h_needed_ = nullptr;
@@ -756,6 +768,9 @@ class HipBackend : public Backend {
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
         if ((rc = dalloc(&d_blocks_done_, 1))) return rc;
+        if ((rc = dalloc(&d_refin_list_, U))) return rc;
+        if ((rc = dalloc(&d_refin_count_, 1))) return rc;
+        HIP_CK(hipMemset(d_refin_count_, 0, sizeof(int32_t)));
         HIP_CK(hipMemset(d_blocks_done_, 0, sizeof(int32_t)));
         enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
@@ -861,7 +876,7 @@ class HipBackend : public Backend {
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
-        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_;
+        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_;
     }
     BatchArgs slice_args(int s) const {
@@ -963,8 +978,12 @@ class HipBackend : public Backend {
         tick("ambi_first_kernel", s, 4, false, sb);
         tick("ambi_finish_kernel", s, 5, true, sb);
         const int fgrid = finish_grid_for(U);
-        if (lean_finish_) hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
-        else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr);
+        if (lean_finish_) {
+            hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
+            // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
+            // device (an empty list costs one launch of workgroups that exit at once)
+            if (hb_.any_sv) hipLaunchKernelGGL(ambi_finish_kernel, dim3(U < 1024 ? U : 1024), dim3(256), lds_finish_, sb, A, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_);
+        } else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr, (const int32_t*)nullptr);
         tick("ambi_finish_kernel", s, 5, false, sb);
         if (overlap_back_) { (void)hipEventRecord(ev_back_, sb); (void)hipStreamWaitEvent(st, ev_back_, 0); }
     }
@@ -977,7 +996,7 @@ class HipBackend : public Backend {
         const int U = A_.n_units;
         // one slice, arena sized: no copy commands around the kernels (see BatchArgs::zero_pending)
         const bool direct = arena_checked_ && n_slices_ == 1 && dh_npending_ && dh_needed_;
-        if (!direct) HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_));
+        if (!direct) { HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_)); HIP_CK(hipMemsetAsync(d_refin_count_, 0, sizeof(int32_t), stream_)); }
         if (!arena_checked_) {
             // first run of this batch: size the arena regions of the slices from what their order tables need
             for (int s = 0; s < n_slices_; s++) launch_front(0, slice_args(s));   // all on the caller's stream
@@ -1080,7 +1099,7 @@ class HipBackend : public Backend {
             HIP_CK(hipGetLastError());
             fwd = !fwd;
         }
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend);
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend, (const int32_t*)nullptr);
         HIP_CK(hipGetLastError());
         HIP_CK(hipStreamSynchronize(stream_));
         (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_slots);

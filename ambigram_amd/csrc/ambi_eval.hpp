@@ -220,7 +220,12 @@ AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forwar
     clk_mark(g, clk, 25);
     bool ok = imperfect_fbi(g, bkp, L, inv);   // LGM.cpp:3656, before the validity test
     *L_out = L;
-    if (!ok) return ST_ERR_REF_UB;
+    // imperfectFBI reading past the end of the breakpoint vector (LGM.cpp:3436-3442 with pos+1 == end) is undefined in the
+    // reference.  On an order that did not place all its elements the outcome is "invalid" whatever that read returns
+    // (validity is i == K, fixed before imperfectFBI runs, and the breakpoints of an invalid order are thrown away,
+    // LGM.cpp:3522), so the order is simply invalid here as well -- what the reference reports whenever it survives the
+    // read.  On a VALID order the printed path would depend on the stray value: that is refused.
+    if (!ok && i == K) return ST_ERR_REF_UB;
     return (i == K) ? 1 : 0;
 }
 

@@ -50,6 +50,7 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
         const bool fbi = !same && std::abs(j_src[j] - j_tgt[j]) <= 2;
         if (normal || fbi) continue;
         n_sv++;
+        any_sv = true;
         if (same) may_dup = true;
     }
     int64_t path_cap = std::min<int64_t>(kPathCapLimit, bound * (may_dup ? 2 : 1) + n_sv + 64);

@@ -796,7 +796,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         const RunPath RP{W.bkp, W.offs, np};
         printed = indel_lookups_only(g, n, W.ends, nsv, RP, P, S);
         if (!printed) {   // chaining or editing SVs: the full stage redoes this unit
-            if (g.tid() == 0) { out->status = ST_REFINISH; atomic_add_i32(A.n_pending, 1); }
+            if (g.tid() == 0) { out->status = ST_REFINISH; A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }
             g.sync();
             return;
         }

@@ -42,6 +42,11 @@ def parse_args():
     ap.add_argument("--juncs", type=int, default=512)
     ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])
     ap.add_argument("--K", type=int, default=19)
+    ap.add_argument("--sv-every", type=int, default=8, help="every N-th sample carries deletions / duplications that make indelBFB EDIT the path "
+                    "(SURVEY.md 8d padding; those units go through the full finish stage inside the timed region); 0: none")
+    ap.add_argument("--mode", default="default", choices=["default", "all"], help="all: the timed step runs --all (every order of every sample "
+                    "evaluated by the fused unrank + evaluate kernel); the headline value stays reconstructions/s")
+    ap.add_argument("--all-steps", type=int, default=2, help="steps of the --all leg reported beside the headline (0 disables it)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
     ap.add_argument("--single-reps", type=int, default=200, help="repetitions of the single-sample latency leg (0 disables it)")
     ap.add_argument("--pipelined", type=int, default=1, help="1: also report the throughput with two resident batches on two streams (N = 1 only)")
@@ -82,7 +87,8 @@ def main():
     batch = api.Batch(lib)
     batch.configure(target_lanes=args.target_lanes)
     for i in range(B):
-        s = synth.make_sample(args.segs, args.juncs, args.tier, args.K, seed=1000 * 2 + rank * B + i)
+        edits = args.sv_every > 0 and i % args.sv_every == args.sv_every - 1
+        s = synth.make_sample(args.segs, args.juncs, args.tier, args.K, seed=1000 * 2 + rank * B + i, n_del=2 if edits else 0, n_dup=1 if edits else 0)
         lh, sols = s.write(tmp, "s%d" % i)
         g = api.Graph(lib, lh)
         graphs.append(g)
@@ -115,8 +121,12 @@ def main():
         px.exchange()
         px.expand(stream)
 
+    run_flags = api.FLAG_ALL if args.mode == "all" else 0
+
     def step():
-        batch.run(0, stream)
+        batch.run(run_flags, stream)
+        if run_flags:
+            batch.wait()                   # --all: the evaluation of every order is issued when the run is waited for
         if gather_mode == 2:
             gather()
 

@@ -537,15 +537,15 @@ void imperfectFBI(const Graph& g, std::vector<int>& bkp, const Inversions& inver
 }
 
 bool evalOrder(const Graph& g, const std::vector<int>& bfb, const Dag& dag, const Inversions& inversions,
-               bool forwardDir, std::vector<int>& bkpPath, bool* ub) {
+               bool forwardDir, std::vector<int>& bkpPath, bool* ub, bool* crash) {
     // body of the per-order loop, LGM.cpp:3519-3658
     const auto& node2pat = dag.node2pat; const auto& node2loop = dag.node2loop;
     bkpPath.clear();
-    if (bfb.empty()) { if (ub) *ub = true; return false; }
+    if (bfb.empty()) { if (crash) *crash = true; return false; }   // bfb[0] on an empty order
     int start, end;
     if (node2pat[bfb[0]].size()) { start = node2pat[bfb[0]][0]; end = node2pat[bfb[0]][1]; }
     else if (node2loop[bfb[0]].size()) { start = node2loop[bfb[0]][0]; end = node2loop[bfb[0]][1]; }
-    else { if (ub) *ub = true; return false; }   // reference indexes an empty vector
+    else { if (crash) *crash = true; return false; }   // node2loop[bfb[0]][0] on an EMPTY vector<int> (never allocated: a null dereference)
     if (forwardDir) {
         if (node2pat[bfb[0]].size()) { bkpPath.push_back(start); bkpPath.push_back(end); }
         else {
@@ -563,7 +563,7 @@ bool evalOrder(const Graph& g, const std::vector<int>& bfb, const Dag& dag, cons
     for (i = 1; i < bfb.size(); i++) {
         if (node2pat[bfb[i]].size()) {
             start = node2pat[bfb[i]][0]; end = node2pat[bfb[i]][1];
-            if (bkpPath.empty()) { if (ub) *ub = true; return false; }
+            if (bkpPath.empty()) { if (crash) *crash = true; return false; }
             if (bkpPath.back() == -start) { bkpPath.push_back(start); bkpPath.push_back(end); }
             else if (bkpPath.back() == end) { bkpPath.push_back(-end); bkpPath.push_back(-start); }
             else break;
@@ -635,10 +635,17 @@ void getBFB(const Graph& g, const std::vector<std::vector<int>>& orders, const D
     bool forwardDir = !isReversed;
     std::vector<int> bkpPath;
     for (long n = 0; n < (long)orders.size(); n++) {
-        bool ub = false;
-        bool valid = evalOrder(g, orders[n], dag, inv, forwardDir, bkpPath, &ub);
+        bool ub = false, crash = false;
+        bool valid = evalOrder(g, orders[n], dag, inv, forwardDir, bkpPath, &ub, &crash);
         res.evaluated++;
-        if (ub) res.undefinedBehaviour = true;
+        if (ub || crash) res.undefinedBehaviour = true;
+        // Two kinds of undefined behaviour in the reference.  (a) a null dereference (empty order, node with both slots
+        // empty at bfb[0]): it crashes there, nothing after this order is ever printed.  (b) imperfectFBI touching the cell
+        // behind the end of the breakpoint vector: on an order that is invalid anyway the outcome is "invalid" whatever
+        // the stray cell holds (validity was fixed before imperfectFBI ran and the breakpoints are discarded), so the scan
+        // goes on; on a VALID order the printed path would depend on the stray cell.  (a) and (b)-on-valid have no
+        // defined result: the scan stops here and the unit counts as refused.
+        if (crash || (ub && valid)) { res.undefinedOnValid = true; break; }
         if (valid) {
             if (res.path.empty()) {
                 expandBkp(bkpPath, res.path);

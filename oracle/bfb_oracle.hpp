@@ -119,7 +119,9 @@ struct BfbResult {
     long firstValidOrder = -1;                     // index in `orders`
     int firstValidOrientationForward = -1;         // 1 forward seed, 0 reversed seed
     long evaluated = 0;                            // number of order evaluations performed (E in SURVEY 8d)
-    bool undefinedBehaviour = false;               // the reference would have read out of bounds
+    bool undefinedBehaviour = false;               // the reference would have read out of bounds on some evaluated order
+    bool undefinedOnValid = false;                 // the run has no defined result: a null dereference on some evaluated order, or a stray read
+                                                   // on an order that placed all its elements (the scan stopped there)
 };
 // LGM.cpp:3431-3512
 void imperfectFBI(const Graph& g, std::vector<int>& bkp, const Inversions& inv, bool* ub);
@@ -127,8 +129,9 @@ void imperfectFBI(const Graph& g, std::vector<int>& bkp, const Inversions& inv, 
 void getBFB(const Graph& g, const std::vector<std::vector<int>>& orders, const Dag& dag, const Inversions& inv,
             bool isReversed, bool printAll, BfbResult& res, std::vector<std::string>& log);
 // evaluate ONE order in one orientation (the body of the loop LGM.cpp:3519-3658); returns validity
+// *ub: imperfectFBI touched the cell behind the end of bkp (stray read / write); *crash: a null dereference
 bool evalOrder(const Graph& g, const std::vector<int>& order, const Dag& dag, const Inversions& inv, bool forwardDir,
-               std::vector<int>& bkp, bool* ub);
+               std::vector<int>& bkp, bool* ub, bool* crash);
 void expandBkp(const std::vector<int>& bkp, std::vector<int>& path);   // LGM.cpp:3661-3670
 
 // LGM.cpp:3746-3837; returns true if the caption+path were printed

@@ -91,7 +91,8 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
         o << ",\"num_orders\":" << s.numOrders;
         o << ",\"orders\":"; jarr2(o, s.orders);
         o << ",\"first_valid\":" << s.bfb.firstValidOrder << ",\"first_forward\":" << s.bfb.firstValidOrientationForward
-          << ",\"evaluated\":" << s.bfb.evaluated << ",\"ub\":" << (s.bfb.undefinedBehaviour ? "true" : "false");
+          << ",\"evaluated\":" << s.bfb.evaluated << ",\"ub\":" << (s.bfb.undefinedBehaviour ? "true" : "false")
+          << ",\"ub_valid\":" << (s.bfb.undefinedOnValid ? "true" : "false");
         o << ",\"bkp\":"; jarr(o, s.bfb.bkpFirst);
         o << ",\"path\":"; jarr(o, s.bfb.path);
         o << ",\"all_paths\":"; jarr2(o, s.bfb.allPaths);

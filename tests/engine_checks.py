@@ -45,9 +45,10 @@ def check_random_decompositions(lib, oracle, workdir, seeds, budget=0):
             b.add_chromosome_sol(g, 0, sols[0])
             b.upload(); b.run(api.FLAG_REVERSED if rev else 0); b.download()
             r = b.unit_result(0)
-            if oc["ub"]:
-                # the reference itself reads out of bounds here; the engine must refuse, not guess
-                assert r["status"] in (-12, 3, 0), (seed, r)
+            if oc["ub_valid"]:
+                # the reference reads out of bounds while rewriting a VALID order: its printed path is not defined by its
+                # source; the engine refuses.  (The same read on an order that is invalid anyway changes nothing.)
+                assert r["status"] == -12, (seed, r)
                 stats["refused"] += 1
                 continue
             assert r["num_orders"] == oc["num_orders"], (seed, rev)
@@ -240,7 +241,7 @@ def check_all_mode(lib, oracle, workdir, seeds=range(40)):
             o = oracle.run_bfb(lh, sols, reversed_=rev, all_=True)
             assert o["ok"], o["err"]
             oc = o["chr"][0]
-            if oc["shortcut"] or oc["ub"]:
+            if oc["shortcut"] or oc["ub_valid"]:
                 continue
             d = parity.compare(lib, oracle, lh, sols, reversed_=rev, all_=True, keep_orders=False)
             if oc["first_valid"] < 0:
@@ -315,8 +316,8 @@ def check_mixed_batch(lib, oracle, workdir, big=False):
                     want = oc["path_indel"] or oc["path"]      # the reference path 1+ .. n+ (no indelBFB on this branch)
                     assert b.unit_path(u, 1).tolist() == want or not want, tag
                     continue
-                if oc["ub"]:
-                    assert r["status"] in (-12, 3, 0), tag
+                if oc["ub_valid"]:
+                    assert r["status"] == -12, tag
                     continue
                 assert r["num_orders"] == oc["num_orders"], tag
                 if oc["orders"]:

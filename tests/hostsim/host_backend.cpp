@@ -27,7 +27,8 @@ class HostSimBackend : public Backend {
     std::vector<uint32_t> ilink_;
     std::vector<int32_t> ilvl_off_, icounter_, ipos_, acbase_, rows_per_lane_, scratch_;
     std::vector<int64_t> blk_off_;
-    int32_t n_pending_ = 0;
+    int32_t n_pending_ = 0, refin_count_ = 0;
+    std::vector<int32_t> refin_list_;
     int64_t orders_needed_ = 0;
     std::vector<KernelTime> times_;
     BatchArgs A_{};
@@ -75,6 +76,8 @@ class HostSimBackend : public Backend {
         A_.blk_off = blk_off_.data(); A_.rows_per_lane = rows_per_lane_.data();
         A_.n_pending = &n_pending_; A_.orders_needed = &orders_needed_;
         A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
+        refin_list_.assign(units_.size() + 1, 0); refin_count_ = 0;
+        A_.refin_list = refin_list_.data(); A_.refin_count = &refin_count_;
         A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
         A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
     }

@@ -38,9 +38,9 @@ for i in range(count // 5):
             # two outcomes are agreement, not difference: the oracle finds no valid order either (e.g. a cyclic DAG: no
             # topological order at all), or the oracle flags that the reference reads out of bounds and the engine refuses
             oc = oracle_py.run_bfb(lh, sols, reversed_=rev)["chr"][0]
-            if d == ["engine failed: no valid BFB order"] and oc["first_valid"] < 0 and not oc["ub"]:
+            if d == ["engine failed: no valid BFB order"] and oc["first_valid"] < 0 and not oc["ub_valid"]:
                 agreed_none += 1
-            elif d == ["engine failed: reference behaviour undefined on this input (out-of-bounds read)"] and oc["ub"]:
+            elif d == ["engine failed: reference behaviour undefined on this input (out-of-bounds read)"] and oc["ub_valid"]:
                 agreed_ub += 1
             else:
                 bad += 1
