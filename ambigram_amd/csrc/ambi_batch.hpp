@@ -31,6 +31,9 @@ struct UnitIn {
     int64_t ideal_off;    // slot offset into the ideal-table pools
     int32_t ideal_cap;    // power of two
     int32_t has_components;   // .juncs components exist for this chromosome (localhap.cpp:158-164)
+    int32_t direct_full;      // the unit has same-strand non-adjacent junctions (deletion / duplication / insertion candidates of indelBFB,
+                              // LGM.cpp:3746-3837): it goes straight to the full finish stage, the lean stage leaves it alone
+    int32_t pad_;
 };
 
 // fixed-size result header of one unit
@@ -142,6 +145,7 @@ struct BatchArgs {
     int32_t* host_pending;       // device address of a pinned host int32 (nullptr: the host copies n_pending itself)
     int32_t* blocks_done;        // [1] finished workgroups of the lean finish kernel (the last one reports n_pending and resets it)
     int32_t* refin_list;         // [U] units the lean finish stage hands to the full stage (SVs that chain or edit the path), in any order
+    int32_t direct_full_on;      // 1: units with UnitIn::direct_full are served by a full-stage launch of their own (the lean stage skips them)
     int32_t* refin_count;        // [1] entries of refin_list; zeroed before the lean kernel, read by the full-stage kernel behind it
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)
     int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
 // workgroups of the CU -- and the separate build kernel only serves the units that several workgroups share.
 // LDS: [block_lds] image (+ automaton copy while building).
 template <int CLS>
-__global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A) {
+__global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_blocks_kernel(BatchArgs A)
     int dfs_block_max = 0;
     BuildTables Bt;
     const uint32_t* dfs_suf = nullptr;
-    uint8_t* wave_state = tmem + A.block_lds - kDfsStateBytes + wave * (kDfsStateBytes / 4);
+    uint8_t* wave_state = tmem + A.block_lds - kDfsStateBytes + wave * kDfsWaveStride;
     for (int64_t b = (int64_t)blockIdx.x; b < total; b += (int64_t)gridDim.x) {
         int lo = 0, hi = A.n_units;
         if (b < A.n_units && A.blk_off[b] == b && A.blk_off[b + 1] == b + 1) lo = (int)b;   // one work block per unit so far: two independent reads
@@ -440,11 +440,11 @@ __global__ __launch_bounds__(64) void ambi_order_paths_kernel(BatchArgs A, int u
 // list_count == nullptr: one workgroup per entry (host-built list of the slow path), else the list is the one the lean
 // kernel in front of this launch filled on the device (refin_list / refin_count) and the workgroups share it in strides
 // -- no host round trip between the two kernels.
-__global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list, const int32_t* list_count) {
+__global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list, const int32_t* list_count, int fixed_count = -1) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
-    if (unit_list && list_count) {
-        const int n = *list_count;
+    if (unit_list && (list_count || fixed_count >= 0)) {
+        const int n = list_count ? *list_count : fixed_count;
         for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
             stage_finish(g, A, unit_list[i], ambi_lds);
             __syncthreads();
@@ -641,7 +641,9 @@ class HipBackend : public Backend {
     // overlap of [first valid order, finish] with the enumerate kernel (one slice, arena sized): own stream + two events
     bool overlap_back_ = false, want_overlap_ = true;
     hipStream_t back_stream_ = nullptr;
-    hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr;
+    hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr, ev_first_ = nullptr, ev_full_ = nullptr;
+    hipStream_t full_stream_ = nullptr;
+    int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     uint8_t* d_first_rows_ = nullptr;
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
     int emit_interleave_ = 1; // env AMBI_EMIT_INTERLEAVE=0: every wave a contiguous quarter of the work block instead of every fourth block
@@ -656,19 +658,20 @@ class HipBackend : public Backend {
     int64_t all_bits_cap_ = 0;
     bool all_done_ = false;
     int enum_grid_ = 2048;
+    int enum_threads_ = 256;  // threads per workgroup of the block-emission kernel (env AMBI_ENUM_THREADS: 256 / 512 / 1024)
 
     void free_all() {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
-                        d_all_bits_, d_all_off_, d_all_count_, d_all_flags_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_};
+                        d_all_bits_, d_all_off_, d_all_count_, d_all_flags_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
         d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
-        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr;
+        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         h_npending_ = nullptr; h_needed_ = nullptr;
@@ -683,6 +686,10 @@ class HipBackend : public Backend {
         for (auto e : ev_stage_) (void)hipEventDestroy(e);
         ev_stage_.clear();
         if (back_stream_) (void)hipStreamDestroy(back_stream_);
+        if (full_stream_) (void)hipStreamDestroy(full_stream_);
+        if (ev_first_) (void)hipEventDestroy(ev_first_);
+        if (ev_full_) (void)hipEventDestroy(ev_full_);
+        full_stream_ = nullptr; ev_first_ = ev_full_ = nullptr; direct_n_ = 0;
         if (ev_prep_) (void)hipEventDestroy(ev_prep_);
         if (ev_back_) (void)hipEventDestroy(ev_back_);
         back_stream_ = nullptr; ev_prep_ = ev_back_ = nullptr;
@@ -824,6 +831,7 @@ class HipBackend : public Backend {
             for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_join_.push_back(e); }
             for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_stage_.push_back(e); }
             { const char* e2 = getenv("AMBI_STAGGER"); stagger_ = e2 ? atoi(e2) != 0 : true; }
+            { const char* e4 = getenv("AMBI_ENUM_THREADS"); enum_threads_ = e4 ? atoi(e4) : 256; if (enum_threads_ != 512 && enum_threads_ != 1024) enum_threads_ = 256; }
             { const char* e3 = getenv("AMBI_ENUM_GRID"); enum_grid_ = e3 ? atoi(e3) : 16384; if (enum_grid_ < 1) enum_grid_ = 1; }   // >= work blocks: one block per workgroup, the rest exit (measured: 2048 -> 16384 workgroups = -8 % kernel time)
         }
         // first orders of every unit, written by the prepare stage (takes the enumerate kernel off the critical path of the scan)
@@ -843,6 +851,22 @@ class HipBackend : public Backend {
               } }
             HIP_CK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
             HIP_CK(hipEventCreateWithFlags(&ev_back_, hipEventDisableTiming));
+            HIP_CK(hipEventCreateWithFlags(&ev_first_, hipEventDisableTiming));
+            HIP_CK(hipEventCreateWithFlags(&ev_full_, hipEventDisableTiming));
+            {   // units that go straight to the full finish stage (env AMBI_DIRECT_FULL=0: none, they pass through the lean stage first)
+                const char* e7 = getenv("AMBI_DIRECT_FULL"); const bool on = e7 ? atoi(e7) != 0 : true;
+                const char* e8 = getenv("AMBI_DIRECT_GRID"); direct_grid_ = e8 ? atoi(e8) : 1024; if (direct_grid_ < 1) direct_grid_ = 1;   // one workgroup per unit up to 1024 (measured: 64 / 128 / 256 / 512 workgroups for 512 units = 1.63 / 1.37 / 1.25 / 1.23 ms per step; without this launch 1.30)
+                std::vector<int32_t> dl;
+                if (on && lean_finish_) for (size_t u2 = 0; u2 < U; u2++) if (hb.units[u2].direct_full) dl.push_back((int32_t)u2);
+                direct_n_ = (int)dl.size();
+                if (direct_n_ > 0) {
+                    if ((rc = dalloc(&d_direct_list_, dl.size()))) return rc;
+                    HIP_CK(hipMemcpy(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    int least = 0, greatest = 0;
+                    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&full_stream_, hipStreamNonBlocking, least)); }
+                    else HIP_CK(hipStreamCreateWithFlags(&full_stream_, hipStreamNonBlocking));
+                }
+            }
             // AMBI_ENUM_LDS_FLOOR (experiments): make the enumerate kernel ask for more LDS than its image needs, i.e. fewer
             // of its workgroups per CU.  Measured (profiles/r01_slices.md): no floor is best -- the scan / finish
             // workgroups slip in as enumerate workgroups retire.
@@ -876,7 +900,7 @@ class HipBackend : public Backend {
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
-        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_;
+        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_;
     }
     BatchArgs slice_args(int s) const {
@@ -962,9 +986,9 @@ class HipBackend : public Backend {
         const int grid = enum_grid_;
         tick("ambi_enumerate_kernel", s, 3, true);
         const int lds_emit = lds_blocks_;
-        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(256), lds_emit, st, A);
-        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(256), lds_emit, st, A);
-        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(256), lds_emit, st, A);
+        if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
+        if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
+        if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
         if ((enum_classes_ & 1) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 2) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 4) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
@@ -976,16 +1000,28 @@ class HipBackend : public Backend {
         tick("ambi_first_kernel", s, 4, true, sb);
         hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, sb, A);
         tick("ambi_first_kernel", s, 4, false, sb);
+        // units with deletion / duplication candidates go straight to the full finish stage, on a stream of their own beside
+        // the lean kernel (both behind the scan, both beside the enumerate kernel); few workgroups, each taking units in turn
+        if (direct_n_ > 0 && overlap_back_ && full_stream_) {
+            (void)hipEventRecord(ev_first_, sb);
+            (void)hipStreamWaitEvent(full_stream_, ev_first_, 0);
+            const int dgrid = direct_n_ < direct_grid_ ? direct_n_ : direct_grid_;
+            hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(256), lds_finish_, full_stream_, A, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
+            (void)hipEventRecord(ev_full_, full_stream_);
+        }
         tick("ambi_finish_kernel", s, 5, true, sb);
         const int fgrid = finish_grid_for(U);
         if (lean_finish_) {
             hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
             // device (an empty list costs one launch of workgroups that exit at once)
-            if (hb_.any_sv) hipLaunchKernelGGL(ambi_finish_kernel, dim3(U < 1024 ? U : 1024), dim3(256), lds_finish_, sb, A, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_);
-        } else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr, (const int32_t*)nullptr);
+            if (hb_.any_sv) hipLaunchKernelGGL(ambi_finish_kernel, dim3(U < 1024 ? U : 1024), dim3(256), lds_finish_, sb, A, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_, -1);
+        } else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr, (const int32_t*)nullptr, -1);
         tick("ambi_finish_kernel", s, 5, false, sb);
-        if (overlap_back_) { (void)hipEventRecord(ev_back_, sb); (void)hipStreamWaitEvent(st, ev_back_, 0); }
+        if (overlap_back_) {
+            (void)hipEventRecord(ev_back_, sb); (void)hipStreamWaitEvent(st, ev_back_, 0);
+            if (direct_n_ > 0 && full_stream_) (void)hipStreamWaitEvent(st, ev_full_, 0);
+        }
     }
 
     int run(uint32_t flags, void* stream) override {
@@ -1028,6 +1064,7 @@ class HipBackend : public Backend {
             arena_checked_ = true;
         }
         overlap_back_ = want_overlap_ && back_stream_ != nullptr && arena_checked_ && n_slices_ == 1;
+        A_.direct_full_on = (overlap_back_ && direct_n_ > 0 && full_stream_ != nullptr) ? 1 : 0;
         if (direct) { A_.zero_pending = 1; A_.host_pending = dh_npending_; A_.host_needed = dh_needed_; }
         // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
         // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
@@ -1099,7 +1136,7 @@ class HipBackend : public Backend {
             HIP_CK(hipGetLastError());
             fwd = !fwd;
         }
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend, (const int32_t*)nullptr, -1);
         HIP_CK(hipGetLastError());
         HIP_CK(hipStreamSynchronize(stream_));
         (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_slots);

@@ -36,16 +36,26 @@ AMBI_HD int find_last_slot(const G& g, const cell_t* bkp, int L, int target, boo
     return g.max_i32(best);
 }
 
-// open a gap of `count` cells at index `at` (cells [at,L) move up); group-cooperative, in place
+// open a gap of `count` cells at index `at` (cells [at,L) move up); group-cooperative, in place.  A round moves
+// kShiftVec * size() cells: every thread reads its cells of the round (top-down, so nothing is overwritten before it was
+// read by a LATER round), all wait, every thread writes -- two barriers per round instead of per size() cells.
+constexpr int kShiftVec = 8;
 template <class G, class T>
 AMBI_HD void shift_up(const G& g, T* a, int L, int at, int count) {
-    int n = L - at;
-    for (int top = n; top > 0; top -= g.size()) {
-        int i = top - 1 - g.tid();
-        T v = 0;
-        if (i >= 0) v = a[at + i];
+    const int n = L - at, step = kShiftVec * g.size();
+    for (int top = n; top > 0; top -= step) {
+        T v[kShiftVec];
+#pragma unroll
+        for (int k = 0; k < kShiftVec; k++) {
+            const int i = top - 1 - g.tid() - k * g.size();
+            v[k] = i >= 0 ? a[at + i] : (T)0;
+        }
         g.sync();
-        if (i >= 0) a[at + i + count] = v;
+#pragma unroll
+        for (int k = 0; k < kShiftVec; k++) {
+            const int i = top - 1 - g.tid() - k * g.size();
+            if (i >= 0) a[at + i + count] = v[k];
+        }
         g.sync();
     }
 }
@@ -53,13 +63,20 @@ AMBI_HD void shift_up(const G& g, T* a, int L, int at, int count) {
 // close the gap [at, at+count): cells [at+count, L) move down
 template <class G, class T>
 AMBI_HD void shift_down(const G& g, T* a, int L, int at, int count) {
-    int n = L - (at + count);
-    for (int base = 0; base < n; base += g.size()) {
-        int i = base + g.tid();
-        T v = 0;
-        if (i < n) v = a[at + count + i];
+    const int n = L - (at + count), step = kShiftVec * g.size();
+    for (int base = 0; base < n; base += step) {
+        T v[kShiftVec];
+#pragma unroll
+        for (int k = 0; k < kShiftVec; k++) {
+            const int i = base + g.tid() + k * g.size();
+            v[k] = i < n ? a[at + count + i] : (T)0;
+        }
         g.sync();
-        if (i < n) a[at + i] = v;
+#pragma unroll
+        for (int k = 0; k < kShiftVec; k++) {
+            const int i = base + g.tid() + k * g.size();
+            if (i < n) a[at + i] = v[k];
+        }
         g.sync();
     }
 }

@@ -59,6 +59,7 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
     U.path_cap = (int32_t)path_cap;
     U.out_cap = (int32_t)(bkp_cap + 64);
     U.ideal_cap = ideal_cap;
+    U.direct_full = may_dup ? 1 : 0;
     units.push_back(U);
     junc_global.emplace_back();
     max_n = std::max(max_n, n_seg); max_m = std::max(max_m, n_junc); max_k = std::max(max_k, n_elem);

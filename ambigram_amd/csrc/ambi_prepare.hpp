@@ -78,42 +78,41 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
         nfb += tot;
     }
     g.sync();
-    // does any slot get two normal junctions?  (f64 accumulation order matters only then)
-    int multi = 0;
-    for (int i = g.tid(); i <= n; i += g.size()) multi |= (slot_cnt[i] > 1);
-    const bool serial_normal = g.any(multi != 0);
-    if (!serial_normal) {
-        // four junctions per thread and round: the copy numbers come from the records in HBM (L2 by now), so the four
-        // loads are issued together instead of one round trip per junction
-        for (int base = 0; base < m; base += 4 * g.size()) {
-            int slot[4];
-            double cn[4];
+    // Normal junctions.  A slot with ONE contribution is 0 + cn, whoever writes it.  A slot with several (an adjacency and a
+    // tandem duplication i -> i-1 share one) is a sum in JUNCTION ORDER (f64 addition is not associative): those few
+    // contributions are added one after the other, lowest junction index first -- the rounds of this loop run in junction
+    // order (base, then q, then thread), and inside a round the pending threads take turns by thread index.
+    // Four junctions per thread and round: the copy numbers come from the records in HBM (L2 by now), so the four
+    // loads are issued together instead of one round trip per junction.
+    for (int base = 0; base < m; base += 4 * g.size()) {
+        int slot[4];
+        double cn[4];
+        bool shared[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int ji = base + q * g.size() + g.tid();
-                slot[q] = -1;
-                cn[q] = 0.0;
-                if (ji < m) {
-                    const JuncEnds E = J.e[ji];
-                    const int s = iabs(E.s), t = iabs(E.t);
-                    if (!(s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0))) {
-                        if (s + 1 == t) slot[q] = s;
-                        else if (s - 1 == t) slot[q] = t;
-                    }
-                    if (slot[q] >= 0) cn[q] = J.full[ji].cn;
+        for (int q = 0; q < 4; q++) {
+            const int ji = base + q * g.size() + g.tid();
+            slot[q] = -1;
+            cn[q] = 0.0;
+            shared[q] = false;
+            if (ji < m) {
+                const JuncEnds E = J.e[ji];
+                const int s = iabs(E.s), t = iabs(E.t);
+                if (!(s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0))) {
+                    if (s + 1 == t) slot[q] = s;
+                    else if (s - 1 == t) slot[q] = t;
                 }
+                if (slot[q] >= 0) { cn[q] = J.full[ji].cn; shared[q] = slot_cnt[slot[q]] != 1; }
             }
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (slot[q] >= 0) junc_cn[2 * slot[q]] = 0.0 + junc_cn_round(cn[q]);
         }
-    } else if (g.tid() == 0) {
-        for (int ji = 0; ji < m; ji++) {
-            const JuncEnds E = J.e[ji];
-            const int s = iabs(E.s), t = iabs(E.t);
-            if (s < 1 || s > n || t < 1 || t > n || (E.s < 0) != (E.t < 0)) continue;
-            if (s + 1 == t) junc_cn[2 * s] += junc_cn_round(J.full[ji].cn);
-            else if (s - 1 == t) junc_cn[2 * t] += junc_cn_round(J.full[ji].cn);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (slot[q] >= 0 && !shared[q]) junc_cn[2 * slot[q]] = 0.0 + junc_cn_round(cn[q]);
+            bool pend = shared[q];
+            while (g.any(pend)) {
+                const int lead = g.first_flag(pend);
+                if (g.tid() == lead) { junc_cn[2 * slot[q]] += junc_cn_round(cn[q]); pend = false; }
+                g.sync();
+            }
         }
     }
     // fold-back claims are first come first served (LGM.cpp:4012-4041): serial over the compacted list.  A slot is

@@ -329,7 +329,8 @@ AMBI_HD void emit_blocks_dfs_dispatch(const BuildTables& B, const uint32_t* suf,
 }
 // group memory of the walk per wave: the ideals of the current path + prefix words with wrap copies
 constexpr int kDfsWaveBytes = 2 * 64 + 4 * (16 + 3) + 4;   // 208
-constexpr int kDfsStateBytes = 4 * ((kDfsWaveBytes + 15) & ~15);   // four waves per workgroup
+constexpr int kDfsWaveStride = (kDfsWaveBytes + 15) & ~15;
+constexpr int kDfsStateBytes = 16 * kDfsWaveStride;   // up to sixteen waves per workgroup
 
 // Row-width classes of the enumerate kernel (one kernel instantiation each, so that the register budget of the wide
 // rows does not throttle the occupancy of the narrow ones): 0: K <= 20, 1: K <= 32, 2: K <= 63.
@@ -759,6 +760,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
     const int base = U.seg_base;
     const int status = out->status;
+    if (U.direct_full && A.direct_full_on) return;   // taken by the full stage from the start (its kernel runs beside this one)
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
         // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
         int P = n <= U.path_cap ? n : U.path_cap;

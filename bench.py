@@ -144,7 +144,7 @@ def main():
         gather()                           # untimed: first use of the exchange (collective setup, lazily loaded kernels)
     batch.wait()
     torch.cuda.synchronize()
-    warm_times = {k: v for k, v in batch.kernel_times().items() if v >= 0}
+    warm_times = {k: v for k, v in batch.kernel_times().items() if v >= 0 and k != "ambi_all_kernel"}
     dom = max(warm_times, key=lambda k: warm_times[k]) if warm_times else "ambi_enumerate_kernel"
     batch.set_timing_only([dom])
     barrier(); torch.cuda.synchronize()
@@ -206,21 +206,25 @@ def main():
     dom_ms = ktimes.get(dom, float("nan"))
     dom_bytes = per_kernel.get(dom, 0) / slices
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    # HBM traffic by the PMC counters (rocprofv3 --pmc passes of this very command, corrected as MI355X_MICROARCH.md
+    # prescribes; profiles/traffic_r02.json, written by profiles/tools/collect.sh + summarize): per launch of the dominant
+    # kernel, and summed over every kernel of a step
+    traffic, step_traffic = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("slices", 1) == slices and tj.get("workload") == "%d/%d/%s/K%d" % (args.segs, args.juncs, args.tier, args.K):
+            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("slices", 1) == slices and tj.get("workload") == "%d/%d/%s/K%d/sv%d" % (args.segs, args.juncs, args.tier, args.K, args.sv_every):
                 traffic = tj.get("hbm_bytes_per_launch")
+                step_traffic = tj.get("hbm_bytes_per_step_all_kernels")
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": dom_ms, "launches_per_step": slices,
                 "all_kernels_ms": ktimes, "all_kernels_note": "%s: HIP events over the timed steps; the other kernels: over the warm-up steps" % dom,
-                "pipeline_bytes_per_step": formula,
-                "pipeline_GBps": formula / (dt / args.steps) / 1e9}
+                "step_hbm_bytes_pmc": step_traffic,
+                "step_hbm_GBps_pmc": (step_traffic / (dt / args.steps) / 1e9) if step_traffic else None}
 
     # ---- CPU baseline: the oracle (a single-thread port of the reference path) on this box's host cores ----
     cpu = None
@@ -238,10 +242,32 @@ def main():
             spent = time.perf_counter() - t_start
             if spent > args.cpu_seconds:
                 break
+        model = ""
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        # the same port at -O0, the optimisation level of the reference's shipped build (CMakeLists.txt:7-8), on a few of the
+        # same samples
+        o0 = None
+        try:
+            n0, recon0 = 0, 0.0
+            t_start = time.perf_counter()
+            for (lh, sols) in files[:max(1, min(cnt, 64))]:
+                r0 = oracle_py.run_bfb(lh, sols, O0=True)
+                recon0 += r0["recon_seconds"]; n0 += 1
+                if time.perf_counter() - t_start > max(3.0, args.cpu_seconds / 3):
+                    break
+            o0 = {"value": n0 / recon0 if recon0 > 0 else None, "samples": n0, "slowdown_vs_O3": (recon0 / n0) / (recon / cnt) if recon > 0 and n0 else None}
+        except Exception as e:      # the -O0 build is optional
+            o0 = {"error": str(e)}
         cpu = {"value": cnt / recon if recon > 0 else None, "unit": "reconstructions/s", "cores": 1, "kind": "port",
                "sample": "%d of the %d benchmarked samples, stages #7,#8,#11-#16,#20 only (%.2f s); whole oracle run incl. .lh "
                          "parse and the variableIdx map: %.1f /s" % (cnt, B, recon, cnt / whole if whole > 0 else 0),
-               "host_cores_available": os.cpu_count()}
+               "cpu_model": model, "host_cores_available": os.cpu_count(), "compiled": "-O3", "port_at_O0": o0}
 
     # ---- two resident batches on two streams (double buffering): the latency-bound prepare / plan kernels of one batch
     # run under the HBM-bound enumerate kernel of the other.  Reported beside the headline value, which stays the plain
@@ -304,15 +330,69 @@ def main():
             single["speedup"] = best * 1e3 / gpu_ms
             single["cpu_kind"] = "port (oracle, 1 core, best of 5)"
 
+    # ---- the step WITH the ILP assembly ("reported twice").  BFB_ILP (LGM.cpp:4397-4752) is where the
+    # reference spends its non-solver time (O(n * numPat^2) coefficient loop, 313 s at 256 segments);
+    # here the same rows come from the closed form: on the host (O(nnz), one core) or written by ambi_ilp_fill_kernel.
+    ilp = None
+    if world == 1:
+        try:
+            prep = batch.unit_prepare(0, args.segs)
+            g0 = graphs[0]
+            max_cn = float(sum(prep["seg_cn"][1:]))
+            t1 = time.perf_counter()
+            mh = api.IlpModel(lib, g0, 0, prep["seg_cn"], prep["junc_cn"], res[0]["bias"], max_cn)
+            host_ms = (time.perf_counter() - t1) * 1e3
+            md = api.IlpModel(lib, g0, 0, prep["seg_cn"], prep["junc_cn"], res[0]["bias"], max_cn, device=True)
+            nnz, rows = mh.nnz, mh.n_rows
+            fill_ms = md.kernel_ms
+            mh.close(); md.close()
+            ilp_bytes = 12 * nnz + 16 * rows            # int32 column + f64 coefficient per entry, two f64 bounds per row
+            ilp = {"sample": "sample 0 (%d segments): %d rows, %d non-zeros" % (args.segs, rows, nnz),
+                   "host_generator_ms_per_sample": host_ms, "device_fill_kernel_ms_per_sample": fill_ms,
+                   "device_fill_GBps": (12 * nnz / (fill_ms * 1e-3) / 1e9) if fill_ms else None, "algorithmic_bytes_per_sample": ilp_bytes,
+                   "reconstructions_per_s_without_assembly": value,
+                   "reconstructions_per_s_with_host_assembly_1core": units_total / (dt / args.steps + units_total * host_ms * 1e-3),
+                   "reconstructions_per_s_with_device_fill": (units_total / (dt / args.steps + units_total * fill_ms * 1e-3)) if fill_ms else None,
+                   "note": "assembly of ONE model timed, charged once per sample; the reference's own assembly loop takes 313 s per sample at this size (SURVEY.md section 6)"}
+        except Exception as e:
+            ilp = {"error": str(e)}
+
+    # ---- --all (LGM.cpp:3672-3695): every order of every sample evaluated -- the mode in which the enumeration is consumed.
+    # Fused unrank + evaluate kernel over all (sample, 64-order chunk) work items, one launch per orientation pass.
+    all_mode = None
+    if args.all_steps > 0 and world == 1:
+        batch.set_timing(True)
+        batch.run(api.FLAG_ALL, stream); batch.wait()          # untimed: bitmap allocation
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.all_steps):
+            batch.run(api.FLAG_ALL, stream); batch.wait()
+        torch.cuda.synchronize()
+        dta = (time.perf_counter() - t1) / args.all_steps
+        batch.download()
+        ev = sum(batch.unit_result(u)["evaluated"] for u in range(B))
+        kms = batch.kernel_times().get("ambi_all_kernel")
+        batch.set_timing(False)
+        nvalid = sum(len(batch.all_orders(u, 0)) for u in range(0, B, max(1, B // 8)))
+        rows_bytes = sum(r["num_orders"] * r["n_nodes"] for r in res)
+        all_mode = {"orders_evaluated_per_step": ev, "ms_per_step": dta * 1e3, "orders_evaluated_per_s": ev / dta,
+                    "reconstructions_per_s": B / dta, "all_kernel_ms_both_passes": kms,
+                    "orders_evaluated_per_s_kernel_only": (ev / (kms * 1e-3)) if kms else None,
+                    "hbm_algorithmic_bytes": {"validity_bitmap": ev // 8, "order_table_not_read": 0, "note": "orders are unranked from the automaton in L2/LDS, breakpoint cells live in LDS: the kernel is bound by LDS latency / issue, not by HBM"},
+                    "equivalent_table_read_GBps": (rows_bytes / (kms * 1e-3) / 1e9) if kms else None,
+                    "valid_orders_in_sampled_units": nvalid, "steps": args.all_steps}
+
     out = {
         "metric": "BFB reconstructions/sec (synthetic .lh, 256 seg) at 1/2/4/8 MI355X",
         "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/int16 (order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
-        "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, default CLI mode; %d samples per GPU resident in HBM"
-                               % (args.segs, args.juncs, args.tier, args.K, B),
+        "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, %s; every %s sample carries 2 deletions + 1 duplication that edit the path (full finish stage); %d samples per GPU resident in HBM"
+                               % (args.segs, args.juncs, args.tier, args.K, "--all mode" if args.mode == "all" else "default CLI mode",
+                                  ("%d-th" % args.sv_every) if args.sv_every > 0 else "no", B),
                    "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths (run-length form, expanded on rank 0) at the end of the timed steps", 2: "; one RCCL gather of the paths (run-length form) to rank 0 at the end of every step"}[gather_mode])},
         "roofline": roofline, "cpu_baseline": cpu, "single_sample": single, "pipelined": pipelined,
+        "ilp_assembly": ilp, "all_mode": all_mode,
     }
     print(json.dumps(out))
     if world > 1:

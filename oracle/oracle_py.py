@@ -46,13 +46,32 @@ def _take(ptr):
     return json.loads(s)
 
 
-def run_bfb(lh, sols, juncs="", reversed_=False, all_=False, junc_info=False, keep_orders=False, max_orders=0):
+_LIB_O0 = None
+
+
+def lib_O0():
+    """The oracle compiled at -O0, the optimisation level of the reference's shipped build (CMakeLists.txt:7-8)."""
+    global _LIB_O0
+    if _LIB_O0 is None:
+        path = os.path.join(_HERE, "liboracle_O0.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "O0"])
+        L = ctypes.CDLL(path)
+        L.oracle_run_bfb.restype = ctypes.c_void_p
+        L.oracle_run_bfb.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int,
+                                     ctypes.c_longlong, ctypes.POINTER(ctypes.c_double)]
+        L.oracle_free.argtypes = [ctypes.c_void_p]
+        _LIB_O0 = L
+    return _LIB_O0
+
+
+def run_bfb(lh, sols, juncs="", reversed_=False, all_=False, junc_info=False, keep_orders=False, max_orders=0, O0=False):
     """Whole `--op bfb` flow on the CPU oracle. `sols`: list of .sol paths, one per chromosome reaching the ILP."""
     flags = (FLAG_REVERSED if reversed_ else 0) | (FLAG_ALL if all_ else 0) | \
             (FLAG_JUNC_INFO if junc_info else 0) | (FLAG_KEEP_ORDERS if keep_orders else 0)
     sec = ctypes.c_double(0)
-    p = lib().oracle_run_bfb(lh.encode(), juncs.encode(), ",".join(sols).encode(), flags, max_orders,
-                             ctypes.byref(sec))
+    p = (lib_O0() if O0 else lib()).oracle_run_bfb(lh.encode(), juncs.encode(), ",".join(sols).encode(), flags, max_orders,
+                                                     ctypes.byref(sec))
     out = _take(p)
     out["seconds"] = sec.value
     return out
