@@ -72,6 +72,7 @@ def _declare(L):
         "ambi_batch_upload": (C.c_int, [vp]),
         "ambi_batch_run": (C.c_int, [vp, u32, vp]),
         "ambi_batch_wait": (C.c_int, [vp]),
+        "ambi_batch_wait_results": (C.c_int, [vp]),
         "ambi_batch_download": (C.c_int, [vp]),
         "ambi_batch_device_results": (C.c_int, [vp, _P(vp), pi64]),
         "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
@@ -346,6 +347,10 @@ class Batch:
 
     def wait(self):
         self._ck(self.lib.ambi_batch_wait(self.h), "wait")
+
+    def wait_results(self):
+        """Reconstruction results complete (small batches: before the order tables behind them are written)."""
+        self._ck(self.lib.ambi_batch_wait_results(self.h), "wait_results")
 
     def download(self):
         self._ck(self.lib.ambi_batch_download(self.h), "download")

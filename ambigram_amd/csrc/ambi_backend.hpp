@@ -31,6 +31,7 @@ class Backend {
     virtual int upload(const HostBatch& hb, const EngineConfig& cfg) = 0;
     virtual int run(uint32_t flags, void* stream) = 0;
     virtual int wait() = 0;
+    virtual int wait_results() { return wait(); }   // results complete; order tables may still be in flight (express path)
     virtual int download(std::vector<uint8_t>& blob) = 0;
     virtual int device_results(void** ptr, int64_t* bytes) = 0;
     virtual int pack_runs(int which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start, int32_t* dev_run_len,

@@ -145,6 +145,9 @@ struct BatchArgs {
     int32_t* host_pending;       // device address of a pinned host int32 (nullptr: the host copies n_pending itself)
     int32_t* blocks_done;        // [1] finished workgroups of the lean finish kernel (the last one reports n_pending and resets it)
     int32_t* refin_list;         // [U] units the lean finish stage hands to the full stage (SVs that chain or edit the path), in any order
+    int32_t* express_seq;        // pinned host int: the express kernel's last workgroup stores run_seq here (the host spins on it)
+    int32_t run_seq;
+    int32_t* express_left;       // pinned host int: set to 1 by the express kernel when a unit is left to the ordinary scan / finish kernels
     int32_t direct_full_on;      // 1: units with UnitIn::direct_full are served by a full-stage launch of their own (the lean stage skips them)
     int32_t* refin_count;        // [1] entries of refin_list; zeroed before the lean kernel, read by the full-stage kernel behind it
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)

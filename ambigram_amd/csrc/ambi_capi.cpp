@@ -236,6 +236,7 @@ int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream) {
     return b->be->run(flags, hip_stream);
 }
 int ambi_batch_wait(ambi_batch_t* b) { return b ? b->be->wait() : AMBI_ERR_ARG; }
+int ambi_batch_wait_results(ambi_batch_t* b) { return b ? b->be->wait_results() : AMBI_ERR_ARG; }
 int ambi_batch_download(ambi_batch_t* b) {
     if (!b) return AMBI_ERR_ARG;
     if (!b->uploaded) return AMBI_ERR_STATE;

@@ -47,6 +47,33 @@ __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
     stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
+// Small batches: the whole reconstruction of a unit whose first order assembles, one workgroup per unit (ambi_stages.hpp:
+// stage_express) -- junction side and DAG side on two wavefronts at once, then imperfectFBI, then the finish stage on the
+// workgroup.  The lattice / order table follow in the kernels behind (ambi_lattice_kernel, plan, enumerate).
+__global__ __launch_bounds__(256) void ambi_express_kernel(BatchArgs A) {
+    __shared__ int scratch[40];
+    BlockGroup gb(scratch);
+    WaveGroup gw;
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.n_pending = 0;
+    const int wave = threadIdx.x >> 6, u = A.unit_base + (int)blockIdx.x;
+    stage_express(gw, gb, wave < 2 ? wave : 2, A, u, ambi_lds);
+    __syncthreads();
+    if (threadIdx.x == 0 && A.express_left) {
+        if (!unit_out(A.results, u)->reserved) *A.express_left = 1;
+        __threadfence_system();
+        if (atomicAdd(A.blocks_done, 1) == (int)gridDim.x - 1) {   // last workgroup: tell the host (it spins on this word)
+            *A.blocks_done = 0;
+            __threadfence_system();
+            *(volatile int32_t*)A.express_seq = A.run_seq;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void ambi_lattice_kernel(BatchArgs A) {
+    WaveGroup g;
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.refin_count = 0;   // the lean finish kernel behind fills the list
+    stage_lattice(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
+}
+
 __device__ inline int64_t wave_incl_scan_i64(int64_t v) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -446,7 +473,7 @@ __global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int
     if (unit_list && (list_count || fixed_count >= 0)) {
         const int n = list_count ? *list_count : fixed_count;
         for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-            stage_finish(g, A, unit_list[i], ambi_lds);
+            if (!unit_out(A.results, unit_list[i])->reserved) stage_finish(g, A, unit_list[i], ambi_lds);   // (reserved: done by the express kernel)
             __syncthreads();
         }
         return;
@@ -644,6 +671,12 @@ class HipBackend : public Backend {
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr, ev_first_ = nullptr, ev_full_ = nullptr;
     hipStream_t full_stream_ = nullptr;
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
+    // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
+    int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0;
+    bool express_ = false;
+    hipEvent_t ev_express_ = nullptr;
+    int32_t* h_express_left_ = nullptr; int32_t* dh_express_left_ = nullptr;   // [0] left flag, [1] sequence word
+    int32_t run_seq_ = 0;
     uint8_t* d_first_rows_ = nullptr;
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
     int emit_interleave_ = 1; // env AMBI_EMIT_INTERLEAVE=0: every wave a contiguous quarter of the work block instead of every fourth block
@@ -674,6 +707,10 @@ class HipBackend : public Backend {
         d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
+        if (h_express_left_) (void)hipHostFree(h_express_left_);
+        h_express_left_ = nullptr; dh_express_left_ = nullptr;
+        if (ev_express_) (void)hipEventDestroy(ev_express_);
+        ev_express_ = nullptr;
         h_npending_ = nullptr; h_needed_ = nullptr;
         for (auto& e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         evs_.clear();
@@ -716,6 +753,7 @@ class HipBackend : public Backend {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
         if (uploaded_) { free_all(); uploaded_ = false; ran_ = false; general_path_ = -1; timed_runs_ = 0; }
+        express_ = false;
         shared_units_ = -1;   // a second upload replaces the first
         hb_ = hb; cfg_ = cfg;
         const size_t U = hb.units.size();
@@ -881,6 +919,20 @@ class HipBackend : public Backend {
             HIP_CK(hipMemcpy(d_inject_, hb.inject.data(), hb.inject.size(), hipMemcpyHostToDevice));
             HIP_CK(hipMemcpy(d_inject_off_, hb.inject_off.data(), 2 * U * sizeof(int64_t), hipMemcpyHostToDevice));
         }
+        {   // express path: small batches only, and only if a unit's whole working set fits one workgroup's group memory
+            const char* e9 = getenv("AMBI_EXPRESS_UNITS"); express_units_ = e9 ? atoi(e9) : 32;
+            lds_express_ = (int)express_work_bytes(hb.max_n, hb.max_m, hb.max_k, hb.max_bkp, finish_path_cells_, hb.max_out) + 64;
+            lds_lattice_ = (int)(64 * 8 + kPrepLatticeBytes + 64);
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_express_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+            if (!ev_express_) HIP_CK(hipEventCreateWithFlags(&ev_express_, hipEventDisableTiming));
+            if (!h_express_left_) {
+                HIP_CK(hipHostMalloc((void**)&h_express_left_, 2 * sizeof(int32_t)));
+                h_express_left_[0] = 1; h_express_left_[1] = 0;
+                if (hipHostGetDevicePointer((void**)&dh_express_left_, h_express_left_, 0) != hipSuccess) dh_express_left_ = nullptr;
+                (void)hipGetLastError();
+            }
+        }
         uploaded_ = true; arena_checked_ = false;
         return 0;
     }
@@ -945,10 +997,27 @@ class HipBackend : public Backend {
 
     void launch_front(int s, const BatchArgs& A) {   // prepare + plan of one slice
         hipStream_t st = slice_stream(s);
-        tick("ambi_prepare_kernel", s, 0, true);
-        hipLaunchKernelGGL(ambi_prepare_kernel, dim3(A.n_units), dim3(64), lds_prepare_, st, A);
-        tick("ambi_prepare_kernel", s, 0, false);
-        tick("ambi_plan_kernel", s, 1, true);
+        if (express_) {
+            // express kernel (whole reconstruction of the units whose first order assembles; results complete at ev_express_),
+            // then the lattice stage of every unit; the express kernel hands units over by status, not through the list
+            BatchArgs Ax = A;
+            Ax.refin_list = nullptr;
+            Ax.express_left = dh_express_left_;
+            Ax.express_seq = dh_express_left_ + 1;
+            Ax.run_seq = ++run_seq_;
+            h_express_left_[0] = 0;
+            tick("ambi_express_kernel", s, 0, true);
+            hipLaunchKernelGGL(ambi_express_kernel, dim3(A.n_units), dim3(256), lds_express_, st, Ax);
+            tick("ambi_express_kernel", s, 0, false);
+            (void)hipEventRecord(ev_express_, st);
+            tick("ambi_plan_kernel", s, 1, true);
+            hipLaunchKernelGGL(ambi_lattice_kernel, dim3(A.n_units), dim3(64), lds_lattice_, st, A);
+        } else {
+            tick("ambi_prepare_kernel", s, 0, true);
+            hipLaunchKernelGGL(ambi_prepare_kernel, dim3(A.n_units), dim3(64), lds_prepare_, st, A);
+            tick("ambi_prepare_kernel", s, 0, false);
+            tick("ambi_plan_kernel", s, 1, true);
+        }
         hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
         tick("ambi_plan_kernel", s, 1, false);
         // The scan for the first valid order starts BEHIND the plan kernel: the plan kernel reads UnitOut::status (and may
@@ -1065,6 +1134,7 @@ class HipBackend : public Backend {
         }
         overlap_back_ = want_overlap_ && back_stream_ != nullptr && arena_checked_ && n_slices_ == 1;
         A_.direct_full_on = (overlap_back_ && direct_n_ > 0 && full_stream_ != nullptr) ? 1 : 0;
+        express_ = arena_checked_ && n_slices_ == 1 && U <= express_units_ && lds_express_ <= kLdsMaxDynamic && dh_express_left_ != nullptr && direct;
         if (direct) { A_.zero_pending = 1; A_.host_pending = dh_npending_; A_.host_needed = dh_needed_; }
         // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
         // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
@@ -1199,6 +1269,22 @@ class HipBackend : public Backend {
             times_.push_back({"ambi_all_kernel", all_kernel_ms_});
         }
         return 0;
+    }
+    // Results complete (paths, breakpoints, output junctions of every unit) -- which, for a small batch on the express path,
+    // is before the order tables behind them are written: returns once the express kernel is done and it left no unit to
+    // the ordinary kernels; otherwise the same as wait().
+    int wait_results() override {
+        if (!ran_) return 0;
+        if (express_ && !(A_.flags & FLAG_ALL) && ev_express_) {
+            // the kernel's last workgroup stores the run's sequence number into pinned host memory: a short spin on it
+            // returns microseconds before an event wait would; the event wait is the fallback
+            volatile int32_t* seq = h_express_left_ + 1;
+            bool seen = false;
+            for (int spin = 0; spin < 400000 && !(seen = (*seq == run_seq_)); spin++) __builtin_ia32_pause();
+            if (!seen) HIP_CK(hipEventSynchronize(ev_express_));
+            if (*(volatile int32_t*)h_express_left_ == 0) return 0;
+        }
+        return wait();
     }
     int download(std::vector<uint8_t>& blob) override {
         int rc = wait();

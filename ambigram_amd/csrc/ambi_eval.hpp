@@ -159,10 +159,24 @@ AMBI_HD bool imperfect_fbi(const G& g, cell_t* bkp, int L, const InvMap& inv) {
     return true;
 }
 
-// Evaluate one order.  Returns 1 valid / 0 invalid / negative Status on error.  *L_out = bkp length.
+// Second part of the evaluation: imperfectFBI (LGM.cpp:3656, always before the validity test) and the verdict.
+// `placed` = what eval_place returned (>= 0).
 template <class G>
-AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forward, const InvMap& inv,
-                       cell_t* bkp, int cap, int* L_out, int64_t* clk = nullptr) {
+AMBI_HD int eval_finish(const G& g, int placed, int K, cell_t* bkp, int L, const InvMap& inv) {
+    const bool ok = imperfect_fbi(g, bkp, L, inv);
+    // imperfectFBI reading past the end of the breakpoint vector (LGM.cpp:3436-3442 with pos+1 == end) is undefined in the
+    // reference.  On an order that did not place all its elements the outcome is "invalid" whatever that read returns
+    // (validity is i == K, fixed before imperfectFBI runs, and the breakpoints of an invalid order are thrown away,
+    // LGM.cpp:3522), so the order is simply invalid here as well -- what the reference reports whenever it survives the
+    // read.  On a VALID order the printed path would depend on the stray value: that is refused.
+    if (!ok && placed == K) return ST_ERR_REF_UB;
+    return (placed == K) ? 1 : 0;
+}
+
+// Placement part of the evaluation of one order (LGM.cpp:3519-3646): seeds and places the elements; needs the DAG only.
+// Returns the number of elements placed (== K: all) or a negative Status; *L_out = bkp length.
+template <class G>
+AMBI_HD int eval_place(const G& g, const Dag& D, const uint8_t* ord, bool forward, cell_t* bkp, int cap, int* L_out) {
     const int K = D.K;
     int L = 0;
     int x = ord[0];
@@ -234,17 +248,23 @@ AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forwar
         }
         // both slots empty (possible after the library sort for K > 16): nothing is placed, the loop goes on
     }
-    clk_mark(g, clk, 25);
-    bool ok = imperfect_fbi(g, bkp, L, inv);   // LGM.cpp:3656, before the validity test
     *L_out = L;
-    // imperfectFBI reading past the end of the breakpoint vector (LGM.cpp:3436-3442 with pos+1 == end) is undefined in the
-    // reference.  On an order that did not place all its elements the outcome is "invalid" whatever that read returns
-    // (validity is i == K, fixed before imperfectFBI runs, and the breakpoints of an invalid order are thrown away,
-    // LGM.cpp:3522), so the order is simply invalid here as well -- what the reference reports whenever it survives the
-    // read.  On a VALID order the printed path would depend on the stray value: that is refused.
-    if (!ok && i == K) return ST_ERR_REF_UB;
-    return (i == K) ? 1 : 0;
+    return i;
 }
+
+// Evaluate one order.  Returns 1 valid / 0 invalid / negative Status on error.  *L_out = bkp length.
+template <class G>
+AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forward, const InvMap& inv,
+                       cell_t* bkp, int cap, int* L_out, int64_t* clk = nullptr) {
+    const int K = D.K;
+    int L = 0;
+    const int i = eval_place(g, D, ord, forward, bkp, cap, &L);
+    *L_out = L;
+    if (i < 0) return i;
+    clk_mark(g, clk, 25);
+    return eval_finish(g, i, K, bkp, L, inv);
+}
+
 
 // LGM.cpp:3661-3670: breakpoint pairs -> per-segment path (int16 local signed ids).  `offs` = scratch of
 // L/2+1 ints.  Returns P or a negative Status.

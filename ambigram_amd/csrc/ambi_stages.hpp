@@ -131,54 +131,58 @@ AMBI_HD LatticeWork unit_lattice_work(const BatchArgs& A, int u, const IdealTabl
     return W;
 }
 
+// The prepare stage in pieces (stage_prepare runs them one after the other on one group; the express kernel runs the
+// junction piece and the DAG piece on two wavefronts at the same time):
+//   prep_junctions   junction ends + segment CNs staged, getJuncCN, bias, getIndelBias, the no-fold-back test
+//   prep_dag         solution elements staged, targetCN, constructDAG
+//   prep_copy_out    target CN, fold-back map, DAG -> result blob / HBM
+//   prep_lattice     order-ideal lattice, R, the frozen automaton, the first orders
+//   prep_header      the unit's result header
 template <class G>
-AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work) {
-    const UnitIn U = A.units[u];
-    const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
-    PrepareWork W = carve_prepare(work, n, m, K);
+AMBI_HD void prep_junctions(const G& g, const BatchArgs& A, int u, const UnitIn& U, const PrepareWork& W, int* bias, bool* no_fbi, double* inv_sum) {
+    const int n = U.n_seg, m = U.n_junc;
     uint8_t* res = A.results + U.res_off;
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
-    UnitOut* out = unit_out(A.results, u);
-    int64_t* clk = A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr;
-    AMBI_MARK(A, g, u, 0);
-
-    // staging: junction ends (4 of the 24 bytes of a record) and the solution elements into group memory; the segment
-    // CNs go straight into their slot of the result blob (getIndelBias edits them there)
+    // staging: junction ends (4 of the 24 bytes of a record) into group memory; the segment CNs go straight into their
+    // slot of the result blob (getIndelBias edits them there)
     const JuncView J{W.ends, A.juncs + U.junc_off};
     double* junc_cn = reinterpret_cast<double*>(res + Lay.junc_cn);
     double* seg_cn = reinterpret_cast<double*>(res + Lay.seg_cn);
-    int32_t* target_cn = W.slot_cnt;
     for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(J.full[j]);
     copy_words(g, reinterpret_cast<uint32_t*>(seg_cn), reinterpret_cast<const uint32_t*>(A.seg_cn + U.seg_off), 2ll * (n + 1));
-    copy_words(g, reinterpret_cast<uint32_t*>(W.elems), reinterpret_cast<const uint32_t*>(A.elems + U.elem_off),
-               int64_t(sizeof(Element) / 4) * K);
     g.sync();
     AMBI_MARK(A, g, u, 1);
-
-    int status = ST_OK;
-    double inv_sum = 0;
     get_junc_cn_g(g, n, J, m, junc_cn, W.inv_junc, W.slot_cnt, W.list);                    // localhap.cpp:136-139
     AMBI_MARK(A, g, u, 2);
-    const int bias = compute_bias_g(g, n, J, junc_cn, W.inv_junc);                        // :141-146
+    *bias = compute_bias_g(g, n, J, junc_cn, W.inv_junc);                                 // :141-146
     AMBI_MARK(A, g, u, 3);
     get_indel_bias_g(g, n, J, m, seg_cn, W.list, W.taken, A.scratch_i32 + A.scratch_off[u]);   // :147
     AMBI_MARK(A, g, u, 4);
-    const bool no_fbi = no_foldback_g(g, n, junc_cn, &inv_sum);                           // :150-153
-    bool have_target = false;
-    if (no_fbi && !U.has_components) status = ST_SHORTCUT;                                // :164
-    else if (U.infeasible) status = ST_INFEASIBLE;                                        // :213
-    else if (K <= 0) status = ST_ERR_NO_ELEMENTS;
-    else {
-        target_cn_g(g, W.elems, K, n, target_cn, W.slot_cnt);                             // :222-232 (in place)
-        have_target = true;
-        AMBI_MARK(A, g, u, 5);
-        DagScratch DS{W.idx, W.loops};
-        status = construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS, clk);                 // :236
-    }
+    *no_fbi = no_foldback_g(g, n, junc_cn, inv_sum);                                      // :150-153
+}
+// target_cn: [n+2] ints of group memory that nothing else uses while this runs
+template <class G>
+AMBI_HD int prep_dag(const G& g, const BatchArgs& A, int u, const UnitIn& U, const PrepareWork& W, int32_t* target_cn) {
+    const int K = U.n_elem;
+    copy_words(g, reinterpret_cast<uint32_t*>(W.elems), reinterpret_cast<const uint32_t*>(A.elems + U.elem_off), int64_t(sizeof(Element) / 4) * K);
     g.sync();
-    AMBI_MARK(A, g, u, 6);
-
-    // results that still sit in group memory: target_cn, fold-back map -- before the lattice search takes the bytes
+    if (K <= 0) return ST_ERR_NO_ELEMENTS;
+    if (target_cn) target_cn_g(g, W.elems, K, U.n_seg, target_cn, target_cn);            // :222-232 (in place)
+    AMBI_MARK(A, g, u, 5);
+    DagScratch DS{W.idx, W.loops};
+    return construct_dag_g(g, W.elems, K, U.seg_base, *W.dag, DS, A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);   // :236
+}
+// the unit's status from the pieces, in the order localhap.cpp decides it (:164 shortcut, :213 infeasible, then the DAG)
+AMBI_HD int prep_status(const UnitIn& U, bool no_fbi, int dag_status) {
+    if (no_fbi && !U.has_components) return ST_SHORTCUT;
+    if (U.infeasible) return ST_INFEASIBLE;
+    return dag_status;
+}
+template <class G>
+AMBI_HD void prep_copy_out(const G& g, const BatchArgs& A, int u, const UnitIn& U, const PrepareWork& W, const int32_t* target_cn, bool have_target, int status) {
+    const int n = U.n_seg;
+    uint8_t* res = A.results + U.res_off;
+    const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
     {
         int32_t* gt = reinterpret_cast<int32_t*>(res + Lay.target_cn);
         for (int i = g.tid(); i <= n; i += g.size()) gt[i] = have_target ? target_cn[i] : 0;
@@ -195,33 +199,81 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     }
     if (status == ST_OK)
         copy_words(g, reinterpret_cast<uint32_t*>(A.dags + u), reinterpret_cast<const uint32_t*>(W.dag), int64_t(sizeof(Dag) / 4));
+}
+// lattice of the unit's DAG (`pred`: 64 masks in group memory or HBM); lattice_mem: kPrepLatticeBytes of group memory.
+// Returns the status (ST_OK, IDEALS / ORDERS capacity); *R_out = number of orders.
+template <class G>
+AMBI_HD int prep_lattice(const G& g, const BatchArgs& A, int u, const uint64_t* pred, int K, uint8_t* lattice_mem, uint64_t* R_out) {
+    const IdealTable T = unit_ideal_table(A, u);
+    int64_t* clk = A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr;
+    // fast path: search state in group memory (the frozen automaton itself always goes to HBM)
+    uint8_t* first_rows = A.first_rows ? A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride : nullptr;
+    int st = ideal_build_and_count(g, pred, K, carve_prepare_lattice(lattice_mem), T, R_out, first_rows, A.first_budget, clk, A.block_max);
+    if (st == ST_ERR_IDEALS_CAPACITY)   // large lattice
+        st = ideal_build_and_count(g, pred, K, unit_lattice_work(A, u, T), T, R_out, first_rows, A.first_budget, nullptr, A.block_max);
+    if (st != ST_OK) return st;
+    if (*R_out >= kCountSat) return ST_ERR_ORDERS_CAPACITY;   // no table of 2^62 rows: decided here, not by the plan kernel
+    return ST_OK;
+}
+AMBI_HD void prep_header(UnitOut* out, int status, int bias, int K, uint64_t R, double inv_sum) {
+    out->status = status;
+    out->bias = bias;
+    out->K = K;
+    out->bkp_len = 0; out->path_len = 0; out->path_indel_len = 0; out->indel_printed = 0; out->n_out_junc = 0;
+    out->first_forward = -1; out->evaluated = 0; out->path_ind_stored = 0; out->reserved = 0;
+    out->num_orders = (int64_t)R;
+    out->first_valid = -1;
+    out->order_off = -1;
+    out->inv_cn_sum = inv_sum;
+}
+
+template <class G>
+AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
+    PrepareWork W = carve_prepare(work, n, m, K);
+    UnitOut* out = unit_out(A.results, u);
+    AMBI_MARK(A, g, u, 0);
+    int bias = 1;
+    bool no_fbi = false;
+    double inv_sum = 0;
+    prep_junctions(g, A, u, U, W, &bias, &no_fbi, &inv_sum);
+    int status = prep_status(U, no_fbi, ST_OK);
+    bool have_target = false;
+    if (status == ST_OK) {   // target CN and the DAG only for units that reach the reconstruction (the slot counters are free by now)
+        status = prep_dag(g, A, u, U, W, W.slot_cnt);
+        have_target = status != ST_ERR_NO_ELEMENTS;
+    }
+    g.sync();
+    AMBI_MARK(A, g, u, 6);
+    // results that still sit in group memory: target_cn, fold-back map -- before the lattice search takes the bytes
+    prep_copy_out(g, A, u, U, W, W.slot_cnt, have_target, status);
     g.sync();
     AMBI_MARK(A, g, u, 7);
-
     uint64_t R = 0;
-    if (status == ST_OK) {
-        const IdealTable T = unit_ideal_table(A, u);
-        // fast path: search state in group memory (the frozen automaton itself always goes to HBM)
-        uint8_t* first_rows = A.first_rows ? A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride : nullptr;
-        int st = ideal_build_and_count(g, W.dag->pred, K, carve_prepare_lattice(W.lattice_mem), T, &R, first_rows, A.first_budget, clk, A.block_max);
-        if (st == ST_ERR_IDEALS_CAPACITY)   // large lattice
-            st = ideal_build_and_count(g, W.dag->pred, K, unit_lattice_work(A, u, T), T, &R, first_rows, A.first_budget, nullptr, A.block_max);
-        if (st != ST_OK) status = st;
-        else if (R >= kCountSat) status = ST_ERR_ORDERS_CAPACITY;   // no table of 2^62 rows: decided here, not by the plan kernel
-    }
-    if (g.tid() == 0) {
-        out->status = status;
-        out->bias = bias;
-        out->K = K;
-        out->bkp_len = 0; out->path_len = 0; out->path_indel_len = 0; out->indel_printed = 0; out->n_out_junc = 0;
-        out->first_forward = -1; out->evaluated = 0; out->path_ind_stored = 0; out->reserved = 0;
-        out->num_orders = (int64_t)R;
-        out->first_valid = -1;
-        out->order_off = -1;
-        out->inv_cn_sum = inv_sum;
-    }
+    if (status == ST_OK) status = prep_lattice(g, A, u, W.dag->pred, K, W.lattice_mem, &R);
+    if (g.tid() == 0) prep_header(out, status, bias, K, R, inv_sum);
     g.sync();
     AMBI_MARK(A, g, u, 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lattice stage alone: units whose front (junctions, DAG, header) was done by the express stage below
+// ---------------------------------------------------------------------------------------------
+template <class G>
+AMBI_HD void stage_lattice(const G& g, const BatchArgs& A, int u, uint8_t* work /* pad8(64 * 8) + kPrepLatticeBytes */) {
+    UnitOut* out = unit_out(A.results, u);
+    if (out->status != ST_OK) return;
+    uint64_t* pred = reinterpret_cast<uint64_t*>(work);
+    for (int i = g.tid(); i < 64; i += g.size()) pred[i] = A.dags[u].pred[i];
+    g.sync();
+    uint64_t R = 0;
+    const int st = prep_lattice(g, A, u, pred, out->K, work + 64 * 8, &R);
+    if (g.tid() == 0) {
+        out->num_orders = (int64_t)R;
+        if (st != ST_OK) out->status = st;   // as the one-piece prepare stage reports it (a path the express stage may have written is void then)
+    }
+    g.sync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -413,7 +465,7 @@ AMBI_HD int injected_verdict(const BatchArgs& A, int u, int64_t R, int64_t nidx,
 template <class G>
 AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     UnitOut* out = unit_out(A.results, u);
-    if (out->status != ST_OK) return;
+    if (out->status != ST_OK || out->reserved) return;   // (reserved: reconstructed by the express stage already)
     const UnitIn U = A.units[u];
     FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
     AMBI_MARK(A, g, u, 9);
@@ -760,6 +812,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
     const int base = U.seg_base;
     const int status = out->status;
+    if (out->reserved) return;                        // reconstructed by the express stage already
     if (U.direct_full && A.direct_full_on) return;   // taken by the full stage from the start (its kernel runs beside this one)
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
         // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
@@ -798,7 +851,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         const RunPath RP{W.bkp, W.offs, np};
         printed = indel_lookups_only(g, n, W.ends, nsv, RP, P, S);
         if (!printed) {   // chaining or editing SVs: the full stage redoes this unit
-            if (g.tid() == 0) { out->status = ST_REFINISH; A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }
+            if (g.tid() == 0) { out->status = ST_REFINISH; if (A.refin_list) A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }   // (no list: the caller looks at the status itself)
             g.sync();
             return;
         }
@@ -813,6 +866,158 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     }
     g.sync();
     AMBI_MARK(A, g, u, 21);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage_express: the whole reconstruction of a unit whose FIRST order is valid, in one workgroup -- for small batches,
+// where the latency of the kernel chain (prepare -> plan -> scan -> finish, each a single wavefront working through
+// order-dependent steps) is what a caller waits for.  allTopologicalOrders emits the orders in lexicographic order
+// (LGM.cpp:3380-3409), so order 0 is "always the lowest-numbered node whose predecessors are placed" -- K steps over the
+// DAG, no lattice.  Two wavefronts work at the same time: one on the junction side (getJuncCN, bias, getIndelBias), one
+// on the DAG side (targetCN, constructDAG, order 0, placement of its elements); then imperfectFBI (needs both), then the
+// finish stage on the whole workgroup.  If order 0 does not assemble, the unit is left to the ordinary scan kernel; the
+// lattice / order table are built behind this kernel either way (stage_lattice).
+// W0 / W1: the junction-side and DAG-side wavefront groups (the same 1-thread group in the host simulation, which runs
+// the two sides one after the other); gb: the workgroup; role: 0 / 1 = this thread belongs to W0 / W1, 2 = neither,
+// -1 = every role in turn (host).
+// ---------------------------------------------------------------------------------------------
+struct ExpressWork {
+    PrepareWork P;
+    int32_t* target;      // [n+2]   target CN (the DAG side's own array: the slot counters belong to the junction side)
+    FirstWork F;
+    int32_t* flags;       // [8]     cross-wave scalars
+    uint8_t* finish;      // finish-stage work area
+};
+AMBI_HD int64_t express_finish_bytes(int n, int m, int bkp_cap, int path_cells, int out_cap) {
+    const int64_t a = finish_work_bytes(n, m, bkp_cap, path_cells, out_cap), b = finish_lean_work_bytes(n, m, bkp_cap);
+    return a > b ? a : b;
+}
+AMBI_HD int64_t express_work_bytes(int n, int m, int K, int bkp_cap, int path_cells, int out_cap) {
+    return pad8(prepare_work_bytes(n, m, K)) + pad8(4ll * (n + 2)) + pad8(first_work_bytes(n, bkp_cap)) + 64 + express_finish_bytes(n, m, bkp_cap, path_cells, out_cap);
+}
+AMBI_HD ExpressWork carve_express(uint8_t* base, int n, int m, int K, int bkp_cap) {
+    ExpressWork W;
+    int64_t o = 0;
+    W.P = carve_prepare(base, n, m, K); o += pad8(prepare_work_bytes(n, m, K));
+    W.target = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (n + 2));
+    W.F = carve_first(base + o, n, bkp_cap); o += pad8(first_work_bytes(n, bkp_cap));
+    W.flags = reinterpret_cast<int32_t*>(base + o); o += 64;
+    W.finish = base + o;
+    return W;
+}
+// order 0: repeatedly the lowest-numbered node all of whose predecessors are placed
+template <class G>
+AMBI_HD bool first_order(const G& g, const Dag& D, uint8_t* ord) {
+    const int K = D.K;
+    if (g.size() >= 64) {
+        // node j in thread j: "all my predecessors are placed and I am not" is one ballot per step
+        const int j = g.tid();
+        const uint64_t mine = j < K ? D.pred[j & 63] : ~0ull;
+        uint64_t placed = 0;
+        bool ok = K > 0;
+        for (int d = 0; d < K; d++) {
+            const uint64_t av = g.ballot_u64(j < K && !((placed >> j) & 1ull) && (mine & ~placed) == 0);
+            if (!av) { ok = false; break; }
+            const int v = ctz64(av);
+            if (j == 0) ord[d] = (uint8_t)v;
+            placed |= 1ull << v;
+        }
+        if (!ok && j == 0) ord[0] = 0xFF;
+        g.sync();
+        return ok;
+    }
+    if (g.tid() == 0) {
+        uint64_t placed = 0;
+        for (int d = 0; d < K; d++) {
+            const uint64_t av = avail_mask(D.pred, K, placed);
+            if (!av) { ord[0] = 0xFF; break; }   // cyclic relation: no order at all
+            const int v = ctz64(av);
+            ord[d] = (uint8_t)v;
+            placed |= 1ull << v;
+        }
+    }
+    g.sync();
+    return K > 0 && ord[0] != 0xFF;
+}
+
+template <class GW, class GB>
+AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs& A, int u, uint8_t* work) {
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
+    ExpressWork W = carve_express(work, n, m, K, U.bkp_cap);
+    UnitOut* out = unit_out(A.results, u);
+    int32_t* fl = W.flags;   // [0] bias, [1] no_fbi, [2] dag status, [3] elements placed by order 0 (or negative status), [4] L, [5] verdict
+    double* inv_sum_slot = reinterpret_cast<double*>(fl + 6);
+    const bool forward = !(A.flags & FLAG_REVERSED);
+    AMBI_MARK(A, gb, u, 9);   // (diagnostics: marks 9-12 are the scan stage's; that stage leaves an express unit alone)
+    if (role == 0 || role < 0) {
+        int bias = 1; bool no_fbi = false; double inv_sum = 0;
+        prep_junctions(gw, A, u, U, W.P, &bias, &no_fbi, &inv_sum);
+        if (gw.tid() == 0) { fl[0] = bias; fl[1] = no_fbi ? 1 : 0; *inv_sum_slot = inv_sum; }
+    }
+    if (role == 1 || role < 0) {
+        int dst = prep_dag(gw, A, u, U, W.P, role < 0 ? W.target : nullptr);   // (a third wavefront fills the target CN, below)
+        int placed = -1, L = 0;
+        if (dst == ST_OK) {
+            gw.sync();
+            if (first_order(gw, *W.P.dag, W.F.ord)) placed = eval_place(gw, *W.P.dag, W.F.ord, forward, W.F.bkp, U.bkp_cap, &L);
+            else placed = 0;   // no order: nothing assembles here; the lattice stage reports R = 0
+        }
+        if (gw.tid() == 0) { fl[2] = dst; fl[3] = placed; fl[4] = L; }
+    }
+    if (role == 2 && K > 0 && gw.tid() < 64 && (gb.tid() >> 6) == 2) {
+        // targetCN (localhap.cpp:222-232) straight from the elements in HBM, beside the other two sides
+        target_cn_g(gw, A.elems + U.elem_off, K, n, W.target, W.target);
+    }
+    gb.sync();
+    AMBI_MARK(A, gb, u, 10);
+    const int bias = fl[0], dag_status = fl[2];
+    const bool no_fbi = fl[1] != 0;
+    const int status = prep_status(U, no_fbi, dag_status);
+    const bool have_target = !(no_fbi && !U.has_components) && !U.infeasible && dag_status != ST_ERR_NO_ELEMENTS;
+    prep_copy_out(gb, A, u, U, W.P, W.target, have_target, status);
+    // the fold-back map in the form the evaluation reads (as load_first_work would fetch it from the blob)
+    for (int i = gb.tid(); i <= n; i += gb.size()) {
+        const int ji = W.P.inv_junc[i];
+        W.F.inv_src[i] = (int16_t)(ji >= 0 ? iabs(W.P.ends[ji].s) : 0);
+        W.F.inv_tgt[i] = (int16_t)(ji >= 0 ? iabs(W.P.ends[ji].t) : 0);
+    }
+    if (gb.tid() == 0) prep_header(out, status, bias, K, 0, *inv_sum_slot);   // R comes from the lattice stage
+    gb.sync();
+    // finish: the lean stage (runs of the breakpoint path; any path length), the full stage when the lean one hands the
+    // unit over or would leave it to the direct full-stage launch
+    auto finish = [&]() {
+        bool need_full = U.direct_full && A.direct_full_on;
+        if (!need_full) {
+            stage_finish_lean(gb, A, u, W.finish);
+            gb.sync();
+            need_full = out->status == ST_REFINISH;
+        }
+        if (need_full) stage_finish(gb, A, u, W.finish);
+        gb.sync();
+        if (gb.tid() == 0) out->reserved = 1;   // done: the scan / finish kernels behind leave the unit alone
+        gb.sync();
+    };
+    if (status == ST_SHORTCUT || status == ST_INFEASIBLE) { finish(); return; }   // the reference path: the finish stage writes it
+    if (status != ST_OK) return;
+    const int placed = fl[3], L = fl[4];
+    if (role == 1 || role < 0) {
+        int v = placed < 0 ? placed : eval_finish(gw, placed, K, W.F.bkp, L, InvMap{W.F.inv_src, W.F.inv_tgt});
+        if (A.inject_valid && A.inject_off[2 * (int64_t)u] >= 0) v = 0;   // injected verdicts (diagnostics) are indexed with R: the scan kernel applies them
+        if (gw.tid() == 0) fl[5] = v;
+    }
+    gb.sync();
+    AMBI_MARK(A, gb, u, 11);
+    if (fl[5] != 1) return;   // order 0 does not assemble (or ends in an error): the ordinary scan takes the unit, from order 0
+    {
+        const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
+        cell_t* dst = reinterpret_cast<cell_t*>(A.results + U.res_off + Lay.bkp);
+        for (int i = gb.tid(); i < L; i += gb.size()) dst[i] = W.F.bkp[i];
+        if (gb.tid() == 0) { out->first_valid = 0; out->first_forward = forward ? 1 : 0; out->bkp_len = L; out->evaluated = 1; }
+    }
+    gb.sync();
+    finish();
+    AMBI_MARK(A, gb, u, 12);
 }
 
 }  // namespace ambi

@@ -139,6 +139,12 @@ int ambi_batch_upload(ambi_batch_t* b);
  * Asynchronous unless the order arena has to grow. */
 int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream);
 int ambi_batch_wait(ambi_batch_t* b);
+/* Returns as soon as the RECONSTRUCTION results of the enqueued run are complete in HBM (paths, breakpoints, output
+ * junctions, headers): for small batches the engine reconstructs every unit whose first order assembles in one kernel and
+ * builds the order tables (LocalGenomicMap::allTopologicalOrders' by-product) behind it, still in flight when this call
+ * returns.  ambi_batch_wait / ambi_batch_download / the next ambi_batch_run wait for everything.  Same as ambi_batch_wait
+ * whenever the fast path does not apply. */
+int ambi_batch_wait_results(ambi_batch_t* b);
 /* Copies the result blob to the host (implies wait).  After this the getters below are valid. */
 int ambi_batch_download(ambi_batch_t* b);
 

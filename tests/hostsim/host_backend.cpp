@@ -184,8 +184,24 @@ class HostSimBackend : public Backend {
         bind(flags);
         n_pending_ = 0;
         const int Un = (int)units_.size();
+        // small batches: the express stage (whole reconstruction of units whose first order assembles) in front, the lattice
+        // stage behind it, as the HIP backend launches them (env AMBI_EXPRESS_UNITS, default 32; 0 = never)
+        const char* ex = getenv("AMBI_EXPRESS_UNITS");
+        const int express_units = ex ? atoi(ex) : 32;
+        const bool express = Un <= express_units;
+        if (express)
+            for (int u = 0; u < Un; u++) {
+                const UnitIn& U = units_[u];
+                std::vector<uint8_t> work((size_t)express_work_bytes(U.n_seg, U.n_junc, U.n_elem, U.bkp_cap, lds_path_cap(A_, U.path_cap), U.out_cap) + 64);
+                stage_express(g, g, -1, A_, u, work.data());
+            }
         for (int attempt = 0; attempt < 2; attempt++) {
             for (int u = 0; u < Un; u++) {
+                if (express) {
+                    std::vector<uint8_t> work((size_t)(64 * 8 + kPrepLatticeBytes + 64));
+                    stage_lattice(g, A_, u, work.data());
+                    continue;
+                }
                 std::vector<uint8_t> work((size_t)prepare_work_bytes(units_[u].n_seg, units_[u].n_junc, units_[u].n_elem));
                 stage_prepare(g, A_, u, work.data());
             }
@@ -193,6 +209,11 @@ class HostSimBackend : public Backend {
             if (orders_needed_ <= (int64_t)arena_.size()) break;
             arena_.assign((size_t)orders_needed_, 0);   // grow the arena and redo (first run only)
             bind(flags);
+            if (express)   // the lattice stage does not rewrite the header: take back what the plan pass decided against the small arena
+                for (int u = 0; u < Un; u++) {
+                    UnitOut* o = unit_out(A_.results, u);
+                    if (o->status == ST_ERR_ORDERS_CAPACITY && o->num_orders < (int64_t)kCountSat) { o->status = ST_OK; o->order_off = -1; }
+                }
         }
         enumerate_all();
         for (int u = 0; u < Un; u++) {
@@ -210,6 +231,7 @@ class HostSimBackend : public Backend {
         }
         for (int u = 0; u < Un; u++) {
             const UnitIn& U = units_[u];
+            if (unit_out(A_.results, u)->reserved) continue;   // done by the express stage
             if (lean && unit_out(A_.results, u)->status != ST_REFINISH) continue;
             std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, lds_path_cap(A_, U.path_cap), U.out_cap));
             stage_finish(g, A_, u, work.data());

@@ -288,3 +288,43 @@ def test_two_batches_of_different_sizes_alive(hip_lib, oracle, workdir):
         b.close()
     for g in graphs:
         g.close()
+
+
+def test_express_path_equals_kernel_chain(hip_lib, oracle, workdir, monkeypatch):
+    """Small batches take the express path (one kernel reconstructs every unit whose first order assembles, the lattice /
+    order table follow behind; ambi_batch_wait_results returns before they are done).  Same results, same order tables as
+    the ordinary kernel chain (AMBI_EXPRESS_UNITS=0), on every kind of unit."""
+    import cases
+    items = [(lh, sols[0]) for _, lh, sols in cases.synthetic_cases(workdir, small_only=True) if len(sols) == 1][:14]
+    for seed in (3, 5, 8, 13):
+        lh, sols = cases.random_decomposition(workdir, 1700 + seed)
+        items.append((lh, sols[0]))
+
+    def run(express, flags):
+        monkeypatch.setenv("AMBI_EXPRESS_UNITS", "64" if express else "0")
+        graphs, b = [], api.Batch(hip_lib)
+        for lh, sol in items:
+            g = api.Graph(hip_lib, lh); graphs.append(g)
+            b.add_chromosome_sol(g, 0, sol)
+        b.upload()
+        b.run(flags); b.wait()                  # first run sizes the arena (ordinary chain)
+        b.run(flags); b.wait_results(); b.wait(); b.download()
+        out = []
+        for u in range(len(items)):
+            r = b.unit_result(u)
+            rec = dict(r)
+            if r["status"] == 0:
+                rec["path"] = b.unit_path(u, 0).tolist(); rec["path_indel"] = b.unit_path(u, 1).tolist(); rec["bkp"] = b.unit_bkp(u).tolist()
+                rec["out"] = b.unit_out_juncs(u)
+                rec["orders"] = b.unit_orders(u, 0, min(r["num_orders"], 3000), r["n_nodes"]).tolist()
+            out.append(rec)
+        b.close()
+        for g in graphs:
+            g.close()
+        return out
+
+    for flags in (0, api.FLAG_REVERSED):
+        a, c = run(True, flags), run(False, flags)
+        for u, (x, y) in enumerate(zip(a, c)):
+            x.pop("reserved", None); y.pop("reserved", None)
+            assert x == y, (flags, u, items[u][0])
