@@ -329,6 +329,11 @@ __global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A
                 nB = H.nB;
                 image = reinterpret_cast<const uint32_t*>(tmem + scr);
                 if (!fits && threadIdx.x == 0) A.unit_fallback[u] = 1;   // the general enumerate kernel takes the unit
+                if (threadIdx.x == 0) {   // what this unit's workgroup really needs of its group memory (the host sizes later launches by it)
+                    int32_t* hdr = A.block_hdr + 8 * (int64_t)u;
+                    hdr[0] = fits ? (dfs ? 2 : 1) : 0;
+                    hdr[3] = (int32_t)(scr + (fits ? H.image_bytes : 0) + (dfs ? kDfsStateBytes : 0));
+                }
             } else {
                 const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
                 fits = hdr->fits != 0;
@@ -691,6 +696,8 @@ class HipBackend : public Backend {
     int64_t all_bits_cap_ = 0;
     bool all_done_ = false;
     int enum_grid_ = 2048;
+    bool emit_lds_auto_ = true;
+    double avg_path_ = 0;
     int enum_threads_ = 256;  // threads per workgroup of the block-emission kernel (env AMBI_ENUM_THREADS: 256 / 512 / 1024)
 
     void free_all() {
@@ -823,6 +830,7 @@ class HipBackend : public Backend {
         { const char* env = getenv("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
         lds_blocks_ = block_lds_;
         const int kLdsLimit = 160 * 1024 - 1024;
+        emit_lds_auto_ = !getenv("AMBI_BLOCK_LDS");
         { const char* env = getenv("AMBI_BLOCK_SCRATCH_LDS"); block_scratch_lds_ = ((env ? atoi(env) : cfg.block_scratch_lds) + 15) & ~15; }
         if (block_scratch_lds_ > kLdsLimit) block_scratch_lds_ = kLdsLimit & ~15;
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
@@ -849,6 +857,9 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         enum_classes_ = 0;
         for (const UnitIn& un : hb.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
+        avg_path_ = 0;
+        for (const UnitIn& un : hb.units) avg_path_ += un.path_cap;
+        avg_path_ /= (double)(U > 0 ? U : 1);
         // slices: env AMBI_SLICES or the configuration; 0 = automatic (4 when the batch is large enough to fill the
         // chip four times over, else 1)
         {
@@ -1042,8 +1053,10 @@ class HipBackend : public Backend {
         if (finish_grid_ > 0) return U < finish_grid_ ? U : finish_grid_;          // env AMBI_FINISH_GRID
         if (!overlap_back_) return U;
         const double enum_us = (double)last_needed_ / 5.2e6;                        // order-table bytes of the previous run at an optimistic 5.2 TB/s
-        const double unit_us = 4.0 + hb_.max_path / 900.0 + hb_.max_m / 64.0;       // one unit through the lean finish stage
+        const double unit_us = 4.0 + avg_path_ / 900.0 + hb_.max_m / 64.0;          // one unit through the lean finish stage (mean path capacity of the batch)
         if (enum_us < 8.0 * unit_us) return U;
+        // (measured with the SV-carrying bench batch, 40 KB images: 160 / 192 / 256 / 320 workgroups = 1.24 / 1.17 / 1.20 / 1.24 ms
+        // per step, profiles/r02_notes.md; the rule lands on 192 there)
         int64_t grid = (int64_t)((double)U * unit_us / enum_us) + 1;
         grid = (grid + 31) & ~int64_t(31);
         if (grid < 32) grid = 32;
@@ -1080,6 +1093,7 @@ class HipBackend : public Backend {
         }
         tick("ambi_finish_kernel", s, 5, true, sb);
         const int fgrid = finish_grid_for(U);
+        if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d\n", fgrid, block_lds_);
         if (lean_finish_) {
             hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
@@ -1229,6 +1243,28 @@ class HipBackend : public Backend {
                 HIP_CK(hipMemcpy(bo.data(), d_blk_off_, bo.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
                 shared_units_ = 0;
                 for (size_t u2 = 0; u2 + 1 < bo.size(); u2++) shared_units_ += (bo[u2 + 1] - bo[u2] > 1) ? 1 : 0;
+                // Group memory per enumerate workgroup for the runs to come.  k workgroups share a CU's 160 KB and its store
+                // bandwidth, so W work blocks take about ceil(W / (CUs * k)) * k "slot rounds": pick the k in 3..5 with the
+                // fewest, among those whose budget 160 KB / k still holds every image of this batch (measured on the bench
+                // batch, 4096 work blocks on 256 CUs: k = 3 (48 KB) 0.92-0.95 ms, k = 4 (40 KB) 0.86-0.87 ms).
+                if (emit_lds_auto_ && general_path_ == 0 && bo.back() > 0) {
+                    std::vector<int32_t> hd(hb_.units.size() * 8);
+                    HIP_CK(hipMemcpy(hd.data(), d_blk_hdr_, hd.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                    int need = 0;
+                    for (size_t u2 = 0; u2 < hb_.units.size(); u2++) if (hd[8 * u2] > 0 && hd[8 * u2 + 3] > need) need = hd[8 * u2 + 3];
+                    int ncu = 256;
+                    { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+                    const int64_t W = bo.back();
+                    int best_k = 0; int64_t best = 0;
+                    for (int k = 3; k <= 5; k++) {
+                        const int budget = ((160 * 1024) / k) & ~15;
+                        if (need <= 0 || need > budget) continue;
+                        const int64_t rounds = ((W + (int64_t)ncu * k - 1) / ((int64_t)ncu * k)) * k;
+                        if (!best_k || rounds < best) { best_k = k; best = rounds; }
+                    }
+                    if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: image need %d bytes, %lld work blocks on %d CUs -> %d workgroups per CU\n", need, (long long)W, ncu, best_k);
+                    if (best_k) { block_lds_ = ((160 * 1024) / best_k) & ~15; lds_blocks_ = block_lds_; }
+                }
             }
         }
         for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s];

@@ -72,12 +72,14 @@ class RunExchange:
     stream -- `stream` (a raw hipStream_t) if given, else torch's current stream -- by making it torch's current stream
     for the duration of the call, so the steps are ordered without host synchronisation."""
 
-    def __init__(self, lib, n_units, local_runs, local_cells, device, world=None, rank=None):
+    def __init__(self, lib, n_units, local_runs, local_cells, device, world=None, rank=None, force_collectives=False):
+        """force_collectives: issue the collectives even in a one-rank group (lets a 1-GPU box exercise the RCCL calls)."""
         self.lib = lib
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
         cap = torch.tensor([max(int(local_runs), 1), max(int(local_cells), 1), max(int(n_units), 1)], dtype=torch.int64, device=device)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(cap, op=dist.ReduceOp.MAX)
         self.run_cap, self.cell_cap, self.unit_cap = int(cap[0].item()), int(cap[1].item()), int(cap[2].item())
         self.n_units = n_units
@@ -85,7 +87,7 @@ class RunExchange:
         self.counts = torch.zeros(2 * U, dtype=torch.int32, device=device)            # [cells per unit | runs per unit]
         self.runs = torch.zeros(2 * self.run_cap, dtype=torch.int32, device=device)   # [start values | lengths]
         self.totals = torch.zeros(2, dtype=torch.int64, device=device)                # {runs, cells} of this rank
-        multi = self.world > 1
+        multi = self.collective
         self.counts_all = torch.zeros(2 * U * self.world, dtype=torch.int32, device=device) if multi else self.counts
         self.gather_list = [torch.zeros_like(self.runs) for _ in range(self.world)] if (multi and self.rank == 0) else None
         # rank 0: the expanded paths of every rank, and the run offsets the expansion reads (kept alive until the next call)
@@ -136,7 +138,7 @@ class RunExchange:
                             self.runs[self.run_cap:].data_ptr(), self.run_cap, self.totals.data_ptr(), RunExchange._raw(self.counts, stream))
 
     def exchange(self, stream=None):
-        if self.world > 1:
+        if self.collective:
             with RunExchange._on(self.counts, stream):
                 dist.all_gather_into_tensor(self.counts_all, self.counts)
                 dist.gather(self.runs, self.gather_list, dst=0)
@@ -149,7 +151,7 @@ class RunExchange:
         with RunExchange._on(self.runs, stream):
             raw = RunExchange._raw(self.runs, stream)
             for r in range(self.world):
-                runs = self.gather_list[r] if self.world > 1 else self.runs
+                runs = self.gather_list[r] if self.collective else self.runs
                 lens = runs[self.run_cap:]
                 self.offs[r] = torch.cumsum(lens, 0, dtype=torch.int64) - lens      # kept: the kernel reads it asynchronously
                 rc = self.lib.ambi_expand_runs(C.c_void_p(runs.data_ptr()), C.c_void_p(lens.data_ptr()), C.c_void_p(self.offs[r].data_ptr()), self.run_cap,

@@ -72,7 +72,10 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # AMBI_FORCE_DIST=1 (diagnostics): initialise RCCL and issue the end-of-batch collectives even with one rank, so that a
+    # 1-GPU box exercises the very calls the N > 1 job makes (launch under torch.distributed.run --nproc-per-node 1)
+    force_dist = os.environ.get("AMBI_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.slices > 0:
@@ -107,9 +110,9 @@ def main():
     total_cells = sum(r["path_indel_len"] for r in res)
     n_runs, n_cells = RunExchange.probe(batch, B, "cuda", 1, stream)
     assert n_cells == total_cells
-    px = RunExchange(lib, B, n_runs, n_cells, "cuda", world=world, rank=rank)
+    px = RunExchange(lib, B, n_runs, n_cells, "cuda", world=world, rank=rank, force_collectives=force_dist)
 
-    gather_mode = (1 if world > 1 else 0) if args.gather < 0 else args.gather
+    gather_mode = (1 if (world > 1 or force_dist) else 0) if args.gather < 0 else args.gather
 
     def gather():
         # the single end-of-batch exchange of the north star: the final paths in run-length form (a few dozen runs of
@@ -118,7 +121,7 @@ def main():
         # reconstruction itself has no exchange step (samples are independent), so at N = 1 there is nothing to send and
         # the step is the pipeline alone.
         px.pack(batch, 1, stream)
-        px.exchange()
+        px.exchange(stream)
         px.expand(stream)
 
     run_flags = api.FLAG_ALL if args.mode == "all" else 0
@@ -131,7 +134,7 @@ def main():
             gather()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     # Warm-up with HIP events around EVERY kernel (on the streams the kernels run on): per-kernel times of the step and
@@ -156,7 +159,7 @@ def main():
     batch.wait()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -178,7 +181,7 @@ def main():
         assert mine.shape == want.shape and bool((mine == want).all()), "expanded runs differ from the downloaded paths"
 
     if rank != 0:
-        if world > 1:
+        if world > 1 or force_dist:
             dist.destroy_process_group()
         return
 
@@ -406,7 +409,7 @@ def main():
         "ilp_assembly": ilp, "all_mode": all_mode,
     }
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -74,7 +74,23 @@ def main():
         rd_kib = mean_counter(a.paths[1], a.kernel, "FETCH_SIZE")
         wr = wr_kib * 1024.0
         rd = rd_kib * 1024.0 * 2.0      # gfx950 correction: FETCH_SIZE tallies 128-byte requests at 64 bytes
+        # every kernel of a step: sum over ALL dispatches of the run / number of steps (= dispatches of the prepare kernel)
+        def total(db, counter):
+            c = sqlite3.connect(db)
+            tot = c.execute("select sum(value) from counters_collection where counter_name=? and kernel_name like '%ambi_%'", (counter,)).fetchone()[0] or 0.0
+            steps = c.execute("select count(*) from counters_collection where counter_name=? and kernel_name like '%ambi_prepare_kernel%'", (counter,)).fetchone()[0] or 1
+            per_kernel = {r[0].split("(")[0].replace("void ", "").replace("ambi::", ""): r[1] * 1024.0 / steps for r in c.execute(
+                "select kernel_name, sum(value) from counters_collection where counter_name=? and kernel_name like '%ambi_%' group by kernel_name", (counter,))}
+            return tot * 1024.0 / steps, per_kernel
+        wr_all, wr_k = total(a.paths[0], "WRITE_SIZE")
+        rd_all, rd_k = total(a.paths[1], "FETCH_SIZE")
+        step_kernels = ("ambi_prepare_kernel", "ambi_plan_kernel", "ambi_blocks_build_kernel", "ambi_enumerate_blocks_kernel", "ambi_enumerate_kernel",
+                        "ambi_first_kernel", "ambi_finish_lean_kernel", "ambi_finish_kernel", "ambi_express_kernel", "ambi_lattice_kernel")
+        per_kernel = {k: {"write": wr_k.get(k, 0.0), "fetch_corrected": 2.0 * rd_k.get(k, 0.0)} for k in sorted(set(wr_k) | set(rd_k))
+                      if k.split("<")[0] in step_kernels}
+        step_bytes = sum(v["write"] + v["fetch_corrected"] for v in per_kernel.values())
         j = {"kernel": a.bench_name, "device_kernel": a.kernel, "batch": a.batch, "workload": a.workload,
+             "hbm_bytes_per_step_all_kernels": step_bytes, "per_kernel_bytes_per_step": per_kernel,
              "write_bytes_per_launch": wr, "fetch_bytes_per_launch_corrected": rd,
              "fetch_size_raw_kib": rd_kib, "write_size_raw_kib": wr_kib,
              "hbm_bytes_per_launch": wr + rd,

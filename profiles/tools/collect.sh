@@ -5,13 +5,13 @@
 # databases go to gpurun_out/prof_<tag>/, the summaries (CSV / JSON) to gpurun_out/profiles_<tag>/ for copying into
 # profiles/.
 set -eo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --steps 10 --warmup 3"   # batch leg only: the single-sample and two-batch legs would mix other launches into the per-kernel means
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --all-steps 0 --steps 10 --warmup 3"   # batch leg only: the single-sample and two-batch legs would mix other launches into the per-kernel means
 
 pass() {   # name, rocprofv3 flags ...
     local name=$1; shift
@@ -28,8 +28,15 @@ wr=$(pass pmc_write --kernel-trace --pmc WRITE_SIZE)
 python3 profiles/summarize_rocpd.py pmc "$wr" "$SUM/${TAG}_bench_b4096_pmc_write.csv" > /dev/null
 rd=$(pass pmc_fetch --kernel-trace --pmc FETCH_SIZE)
 python3 profiles/summarize_rocpd.py pmc "$rd" "$SUM/${TAG}_bench_b4096_pmc_fetch.csv" > /dev/null
-python3 profiles/summarize_rocpd.py traffic "$wr" "$rd" "$SUM/traffic_${TAG}.json" --batch 4096
+python3 profiles/summarize_rocpd.py traffic "$wr" "$rd" "$SUM/traffic_${TAG}.json" --batch 4096 --workload "256/512/wide/K19/sv8"
 db=$(pass pmc_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS)
 python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_bench_b4096_pmc_sq.csv" > /dev/null
+# the --all leg (fused unrank + evaluate kernel) and the ILP fill kernel: their own kernel-trace passes
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --all-steps 2 --steps 2 --warmup 1 --batch 1024"
+db=$(pass all_mode --kernel-trace --stats)
+python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_bench_b1024_allmode_kernel_stats.csv"
+BENCH="python3 $ROOT/profiles/tools/express_latency.py"
+db=$(pass express --kernel-trace --stats)
+python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_single_sample_express_kernel_stats.csv"
 tail -2 "$OUT/stats.log"
 ls -la "$SUM"
