@@ -428,7 +428,56 @@ __global__ __launch_bounds__(64) void ambi_resolve_kernel(BatchArgs A, SearchArg
 // lanes, never read from the table.  Output: one 64-bit word of the unit's validity bitmap per wave-chunk.
 // Work item c of the launch = word c of the concatenated pass-0 maps (all_off is also the chunk prefix, up to the
 // factor 2 for the two passes).  LDS per wave: first-work area + 64 unranked rows.
-__global__ __launch_bounds__(256) void ambi_all_kernel(BatchArgs A, int pass, int wave_lds, int64_t total_chunks) {
+// One thread per order (stage_all_chunk_lanes) for units whose breakpoint path has at most lane_cap cells -- the rule on
+// real inputs (a path of ~100 cells at 256 segments); ambi_all_kernel below keeps the longer ones.
+// LDS per wave: DAG + fold-back map | 64 x 64 bytes of transposed orders | lane_cap x 64 cells.
+__global__ __launch_bounds__(256) void ambi_all_lanes_kernel(BatchArgs A, int pass, int wave_lds, int64_t total_chunks, int lane_cap, int head_bytes,
+                                                            int lane_cells, int auto_bytes, int rows_bytes) {
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint8_t* work = ambi_lds + (size_t)wave * wave_lds;
+    WaveGroup g;
+    int loaded = -1;
+    bool staged_ok = false;
+    AutoView SV{};
+    for (int64_t c = (int64_t)blockIdx.x * wpb + wave; c < total_chunks; c += (int64_t)gridDim.x * wpb) {
+        int lo = 0, hi = A.n_units;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.all_off[mid] <= 2 * c) lo = mid; else hi = mid; }
+        const int u = lo;
+        const UnitIn& U = A.units[u];
+        if (U.bkp_cap > lane_cap) continue;
+        const int64_t R = unit_out(A.results, u)->num_orders;
+        if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;
+        FirstWork W = carve_first(work, U.n_seg, 8);   // (the wavefront form's breakpoint area is not used here)
+        uint8_t* rows_t = work + head_bytes;
+        cell_t* cells = reinterpret_cast<cell_t*>(rows_t + rows_bytes);
+        // the unit's automaton behind the cells: every lane unranks its own order (K dependent steps), from group memory
+        // instead of 64 scattered walks through L2
+        uint8_t* amem = reinterpret_cast<uint8_t*>(cells) + (size_t)lane_cells * 64 * sizeof(cell_t);
+        if (u != loaded) {
+            g.sync();
+            load_first_work(g, A, u, W);
+            const IdealTable T = unit_ideal_table(A, u);
+            const int nI = T.counter[0], nC = T.counter[1];
+            const int64_t need = 16ll * nI + 4ll * (nI + 1) + 2ll * nC + 16;
+            staged_ok = need <= auto_bytes;
+            if (staged_ok) {
+                uint64_t* av = reinterpret_cast<uint64_t*>(amem);
+                uint64_t* cn = av + nI;
+                int32_t* cb = reinterpret_cast<int32_t*>(cn + nI);
+                uint16_t* ch = reinterpret_cast<uint16_t*>(cb + nI + 1);
+                for (int i = threadIdx.x & 63; i < nI; i += 64) { av[i] = T.a_avail[i]; cn[i] = T.a_cnt[i]; }
+                for (int i = threadIdx.x & 63; i <= nI; i += 64) cb[i] = T.a_cbase[i];
+                for (int i = threadIdx.x & 63; i < nC; i += 64) ch[i] = T.a_child[i];
+                SV = AutoView{av, cn, cb, ch, nI};
+            }
+            loaded = u;
+            g.sync();
+        }
+        stage_all_chunk_lanes(g, A, u, W, rows_t, cells, c - A.all_off[u] / 2, pass, staged_ok ? &SV : nullptr);
+        g.sync();
+    }
+}
+__global__ __launch_bounds__(256) void ambi_all_kernel(BatchArgs A, int pass, int wave_lds, int64_t total_chunks, int lane_cap) {
     const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     uint8_t* work = ambi_lds + (size_t)wave * wave_lds;
     WaveGroup g;
@@ -440,6 +489,7 @@ __global__ __launch_bounds__(256) void ambi_all_kernel(BatchArgs A, int pass, in
         const int64_t R = unit_out(A.results, u)->num_orders;
         if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;   // no orientation flip for this unit (LGM.cpp:3691-3695)
         const UnitIn& U = A.units[u];
+        if (U.bkp_cap <= lane_cap) continue;                         // taken by ambi_all_lanes_kernel
         FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
         uint8_t* rows = work + first_work_bytes(U.n_seg, U.bkp_cap);
         g.sync();
@@ -1433,8 +1483,29 @@ class HipBackend : public Backend {
             if (nblk > (1 << 20)) nblk = 1 << 20;   // grid-stride beyond
             hipEvent_t ea = nullptr, eb = nullptr;
             if (timing_) { HIP_CK(hipEventCreate(&ea)); HIP_CK(hipEventCreate(&eb)); HIP_CK(hipEventRecord(ea, stream_)); }
-            for (int pass = 0; pass < 2; pass++)
-                hipLaunchKernelGGL(ambi_all_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * wave_lds, stream_, A_, pass, wave_lds, chunks);
+            // units with a short breakpoint path (the rule): one thread per order; the others: one wavefront per order
+            int lane_cap = 0, lanes_units = 0, wave_units = 0;
+            { const char* e = getenv("AMBI_ALL_LANES"); lane_cap = (e && atoi(e) == 0) ? 0 : kAllLaneMaxCells; }
+            for (int u = 0; u < U; u++) if (all_off_[u + 1] > all_off_[u]) { if (hb_.units[u].bkp_cap <= lane_cap) lanes_units++; else wave_units++; }
+            int max_lane_cells = 8;
+            for (int u = 0; u < U; u++) if (hb_.units[u].bkp_cap <= lane_cap && hb_.units[u].bkp_cap > max_lane_cells) max_lane_cells = hb_.units[u].bkp_cap;
+            const int head_bytes = (int)((first_work_bytes(hb_.max_n, 8) + 15) & ~15);
+            // group memory for a staged copy of the unit's automaton (env AMBI_ALL_AUTO_LDS): 0 = the lanes unrank through L2.
+            // Measured (4096 bench units): 0 / 4096 / 8192 bytes = 561 / 489 / 390 M orders/s -- the kernel lives on the number
+            // of resident wavefronts (group-memory latency), and every KB of group memory costs some.
+            int auto_bytes = 0;
+            { const char* e = getenv("AMBI_ALL_AUTO_LDS"); if (e) auto_bytes = atoi(e) & ~15; if (auto_bytes < 0) auto_bytes = 0; }
+            const int rows_bytes = 64 * ((hb_.max_k + 3) & ~3);   // transposed orders: one 64-lane row per position
+            const int lane_wave_lds = (head_bytes + rows_bytes + max_lane_cells * 64 * (int)sizeof(cell_t) + auto_bytes + 15) & ~15;
+            int lane_waves = 1;   // wavefronts per workgroup (measured 1 / 2 / 4 = 563 / 553 / 379 M orders/s: group-memory allocation granularity)
+            { const char* e = getenv("AMBI_ALL_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 4) lane_waves = atoi(e); }
+            HIP_CK(hipFuncSetAttribute((const void*)ambi_all_lanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+            int64_t lblk = (chunks + lane_waves - 1) / lane_waves;
+            if (lblk > (1 << 20)) lblk = 1 << 20;
+            for (int pass = 0; pass < 2; pass++) {
+                if (lanes_units) hipLaunchKernelGGL(ambi_all_lanes_kernel, dim3((unsigned)lblk), dim3(64 * lane_waves), lane_waves * lane_wave_lds, stream_, A_, pass, lane_wave_lds, chunks, lane_cap, head_bytes, max_lane_cells, auto_bytes, rows_bytes);
+                if (wave_units) hipLaunchKernelGGL(ambi_all_kernel, dim3((unsigned)nblk), dim3(64 * waves), waves * wave_lds, stream_, A_, pass, wave_lds, chunks, lane_cap);
+            }
             if (timing_) HIP_CK(hipEventRecord(eb, stream_));
             hipLaunchKernelGGL(ambi_all_finalize_kernel, dim3((U + 255) / 256), dim3(256), 0, stream_, A_);
             HIP_CK(hipGetLastError());

@@ -13,6 +13,7 @@
 #include "ambi_batch.hpp"
 #include "ambi_enum_blocks.hpp"
 #include "ambi_eval.hpp"
+#include "ambi_eval_lane.hpp"
 #include "ambi_finish.hpp"
 #include "ambi_orders.hpp"
 #include "ambi_prepare.hpp"
@@ -646,6 +647,43 @@ AMBI_HD void stage_all_chunk(const G& g, const BatchArgs& A, int u, const FirstW
         A.all_bits[A.all_off[u] + (int64_t)pass * all_words(R) + c] = word;
         if (word) atomic_add_i32(A.all_count + 2 * (int64_t)u + pass, popc64(word));
         if (undefined) atomic_add_i32(A.all_flags + u, 1);
+    }
+}
+// The same chunk with ONE THREAD PER ORDER (ambi_eval_lane.hpp): every thread unranks its order and walks it through the
+// scalar algorithm; the cells of the 64 orders are interleaved in group memory.  rows_t: [64 positions][64 lanes] bytes,
+// cells: [bkp_cap][64 lanes] cells.  Units whose breakpoint path is too long for that take stage_all_chunk.
+constexpr int kAllLaneMaxCells = 192;   // breakpoint cells per order the lane form holds (64 lanes x 192 cells x 2 bytes = 24 KB per wavefront)
+template <class G>
+AMBI_HD void stage_all_chunk_lanes(const G& g, const BatchArgs& A, int u, const FirstWork& W, uint8_t* rows_t, cell_t* cells, int64_t c, int pass,
+                                   const AutoView* staged = nullptr /* the unit's automaton in group memory, if the caller staged it */) {
+    const UnitOut* out = unit_out(A.results, u);
+    const UnitIn& U = A.units[u];
+    const int K = out->K;
+    const int64_t R = out->num_orders;
+    const bool fwd0 = !(A.flags & FLAG_REVERSED), forward = pass == 0 ? fwd0 : !fwd0;
+    const AutoView V = staged ? *staged : auto_view(unit_ideal_table(A, u));
+    const int64_t first = c * 64;
+    const int cnt = (int)(R - first < 64 ? R - first : 64);
+    const InvMap inv{W.inv_src, W.inv_tgt};
+    uint64_t mine = 0;
+    int undefined = 0;
+    for (int i = g.tid(); i < 64; i += g.size()) {
+        int v = 0;
+        if (i < cnt) {
+            (void)order_unrank(V, K, (uint64_t)(first + i), rows_t + i, 64);
+            int L = 0;
+            v = eval_order_lane(*W.dag, rows_t + i, 64, forward, inv, LaneCells{cells + i, 64}, U.bkp_cap, &L);
+            v = injected_verdict(A, u, R, first + i, forward, v);
+        }
+        if (v == 1) mine |= 1ull << i;
+        else if (v < 0) undefined = 1;
+    }
+    const uint64_t word = g.size() >= 64 ? g.ballot_u64(mine != 0) : mine;
+    const bool any_undefined = g.any(undefined != 0);
+    if (g.tid() == 0) {
+        A.all_bits[A.all_off[u] + (int64_t)pass * all_words(R) + c] = word;
+        if (word) atomic_add_i32(A.all_count + 2 * (int64_t)u + pass, popc64(word));
+        if (any_undefined) atomic_add_i32(A.all_flags + u, 1);
     }
 }
 // header of a unit after both passes: all orders of the executed passes were evaluated; undefined orders refuse the unit

@@ -457,3 +457,47 @@ def check_injected_validity(lib, oracle, workdir):
     g, b, r = run(fwd, [1] * R, flags=api.FLAG_ALL, budget=64)
     assert r["status"] == E, r
     b.close(); g.close()
+
+
+def check_all_two_forms(lib, workdir, seeds=range(300, 420)):
+    """--all evaluates an order with one THREAD (ambi_eval_lane.hpp, units with a short breakpoint path) or with one
+    WAVEFRONT (ambi_eval.hpp): the same valid-order lists, counts, flip decisions and statuses from both, on random
+    decompositions (most orders invalid, both orientations) and on wide synthetic samples (every order valid)."""
+    import os
+    from ambigram_amd import synth
+    items = []
+    for seed in seeds:
+        lh, sols = cases.random_decomposition(workdir, seed)
+        items.append((lh, sols[0]))
+    for i, (tier, K) in enumerate([("wide", 9), ("mixed", 9), ("wide", 13), ("chain", 7), ("mixed", 17), ("mixed", 19)]):
+        s = synth.make_sample(64, 128, tier, K, seed=8800 + i, imperfect=i % 2)
+        lh, sols = s.write(workdir, "tf%d" % i)
+        items.append((lh, sols[0]))
+    saved = os.environ.get("AMBI_ALL_LANES")
+    got = {}
+    try:
+        for form in ("1", "0"):
+            os.environ["AMBI_ALL_LANES"] = form
+            for rev in (0, api.FLAG_REVERSED):
+                graphs, b = [], api.Batch(lib)
+                for lh, sol in items:
+                    g = api.Graph(lib, lh); graphs.append(g)
+                    b.add_chromosome_sol(g, 0, sol)
+                b.upload(); b.run(api.FLAG_ALL | rev); b.download()
+                rec = []
+                for u in range(len(items)):
+                    r = b.unit_result(u)
+                    rec.append((r["status"], r["evaluated"], b.all_orders(u, 0).tolist(), b.all_orders(u, 1).tolist()))
+                got[(form, rev)] = rec
+                b.close()
+                for g in graphs:
+                    g.close()
+    finally:
+        os.environ.pop("AMBI_ALL_LANES", None)
+        if saved is not None:
+            os.environ["AMBI_ALL_LANES"] = saved
+    for rev in (0, api.FLAG_REVERSED):
+        a, c = got[("1", rev)], got[("0", rev)]
+        for u, (x, y) in enumerate(zip(a, c)):
+            assert x == y, (rev, u, items[u][0], x[:2], y[:2])
+    assert sum(1 for x in got[("1", 0)] if x[0] == 0 and len(x[2]) > 1) > 3

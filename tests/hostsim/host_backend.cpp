@@ -264,7 +264,14 @@ class HostSimBackend : public Backend {
                 std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap)), rows(64 * kFirstRowStride);
                 FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
                 load_first_work(g, A_, u, W);
-                for (int64_t c = 0; c < all_words(R); c++) stage_all_chunk(g, A_, u, W, rows.data(), c, pass);
+                // as the HIP backend: one thread per order for units with a short breakpoint path, the wavefront form otherwise
+                const char* el = getenv("AMBI_ALL_LANES");
+                const bool lanes = !(el && atoi(el) == 0) && U.bkp_cap <= kAllLaneMaxCells;
+                std::vector<cell_t> cells(lanes ? (size_t)U.bkp_cap * 64 : 1);
+                for (int64_t c = 0; c < all_words(R); c++) {
+                    if (lanes) stage_all_chunk_lanes(g, A_, u, W, rows.data(), cells.data(), c, pass);
+                    else stage_all_chunk(g, A_, u, W, rows.data(), c, pass);
+                }
             }
         }
         for (int u = 0; u < Un; u++) {

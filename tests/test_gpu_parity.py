@@ -170,6 +170,10 @@ def test_all_mode(hip_lib, oracle, workdir):
     assert st["multi"] > 0, st
 
 
+def test_all_mode_two_forms(hip_lib, workdir):
+    ec.check_all_two_forms(hip_lib, workdir)
+
+
 def test_mixed_batch(hip_lib, oracle, workdir):
     ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)
 

@@ -55,6 +55,10 @@ def test_injected_validity(hostsim_lib, oracle, workdir, monkeypatch, search_ord
     ec.check_injected_validity(hostsim_lib, oracle, workdir)
 
 
+def test_all_mode_two_forms(hostsim_lib, workdir):
+    ec.check_all_two_forms(hostsim_lib, workdir)
+
+
 def test_mixed_batch(hostsim_lib, oracle, workdir):
     ec.check_mixed_batch(hostsim_lib, oracle, workdir)
 
