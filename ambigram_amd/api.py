@@ -93,6 +93,9 @@ def _declare(L):
         "ambi_batch_all_count": (C.c_int, [vp, i32, i32, _P(C.c_int64)]),
         "ambi_batch_all_orders": (C.c_int, [vp, i32, i32, i64, i64, _P(C.c_int64)]),
         "ambi_batch_all_paths": (C.c_int, [vp, i32, i32, i64, i64, _P(C.c_int32), _P(C.c_int32), i64]),
+        "ambi_batch_all_set_shard": (C.c_int, [vp, i32, i32]),
+        "ambi_batch_all_device": (C.c_int, [vp, _P(vp), pi64]),
+        "ambi_batch_all_finish": (C.c_int, [vp]),
         "ambi_batch_traffic": (C.c_int, [vp, pi64, pi64, pi64]),
         "ambi_format_path": (i64, [vp, pi32, i32, C.c_char_p, i64]),
         "ambi_translocation_bfb": (C.c_int, [vp, pi32, pi64, i32, pi32, i32]),
@@ -433,6 +436,19 @@ class Batch:
         if n.value:
             self._ck(self.lib.ambi_batch_all_orders(self.h, u, pass_, 0, n.value, out.ctypes.data_as(_P(C.c_int64))), "all_orders")
         return out[:n.value]
+
+    def all_set_shard(self, rank, world):
+        """--all with the 64-order chunks dealt over `world` ranks (include/ambigram_hip.h)."""
+        self._ck(self.lib.ambi_batch_all_set_shard(self.h, rank, world), "all_set_shard")
+
+    def all_device(self):
+        """(address, bytes) of the pool the ranks merge after a sharded --all run: bitmaps + undefined-order flags."""
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.ambi_batch_all_device(self.h, C.byref(p), C.byref(n)), "all_device")
+        return p.value or 0, n.value
+
+    def all_finish(self):
+        self._ck(self.lib.ambi_batch_all_finish(self.h), "all_finish")
 
     def all_paths(self, u, pass_, first, count, stride):
         """--all: the paths of valid orders [first, first+count) of the pass (list of int32 arrays)."""

@@ -49,6 +49,11 @@ class Backend {
     // empty unless the last order of pass 0 is invalid), and the paths of a range of them (cells: count x stride int32)
     virtual int all_count(int unit, int pass, int64_t* count) = 0;
     virtual int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) = 0;
+    // --all with the orders of a unit dealt over `world` ranks (see BatchArgs::all_rank): set before run; after wait() every
+    // rank merges the pool all_device() names (bitmaps + flags, bytes: MAX over the ranks) and calls all_finish()
+    virtual int set_shard(int rank, int world) = 0;
+    virtual int all_device(void** ptr, int64_t* bytes) = 0;
+    virtual int all_finish() = 0;
     virtual int all_paths(int unit, int pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells, int64_t stride) = 0;
 };
 

@@ -161,7 +161,9 @@ struct BatchArgs {
     uint64_t* all_bits;          // pool of 64-order words
     const int64_t* all_off;      // [U+1] first word of every unit's pass-0 map; its pass-1 map follows (ceil(R/64) words each)
     int32_t* all_count;          // [U][2] valid orders per pass
-    int32_t* all_flags;          // [U]    bit 0: an order on which the reference's behaviour is undefined was met
+    int32_t* all_flags;          // [U]    != 0: an order on which the reference's behaviour is undefined was met (behind the bitmaps in the same pool)
+    int32_t all_rank, all_world; // --all over several ranks (one wide sample): a rank evaluates the chunks c with c % world == rank,
+                                 // plus the LAST chunk of every unit (every rank must know whether the orientation flips)
 };
 
 // stage-level timing marks (diagnostics only; one predictable branch per mark when off)

@@ -365,6 +365,9 @@ int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t fi
     if (!b || !b->uploaded || !lengths || !cells) return AMBI_ERR_ARG;
     return b->be->all_paths(unit, pass, first, count, lengths, cells, stride);
 }
+int ambi_batch_all_set_shard(ambi_batch_t* b, int32_t rank, int32_t world) { return b ? b->be->set_shard(rank, world) : AMBI_ERR_ARG; }
+int ambi_batch_all_device(ambi_batch_t* b, void** ptr, int64_t* bytes) { return (b && b->uploaded) ? b->be->all_device(ptr, bytes) : AMBI_ERR_ARG; }
+int ambi_batch_all_finish(ambi_batch_t* b) { return (b && b->uploaded) ? b->be->all_finish() : AMBI_ERR_ARG; }
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on) { if (!b) return AMBI_ERR_ARG; b->be->set_timing(on != 0); return 0; }
 int ambi_batch_set_timing_mask(ambi_batch_t* b, uint32_t mask) { if (!b) return AMBI_ERR_ARG; b->be->set_timing_mask(mask); return 0; }
 int ambi_batch_slices(const ambi_batch_t* b) { return b ? b->be->slice_count() : AMBI_ERR_ARG; }

@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void ambi_all_lanes_kernel(BatchArgs A, int pa
         const UnitIn& U = A.units[u];
         if (U.bkp_cap > lane_cap) continue;
         const int64_t R = unit_out(A.results, u)->num_orders;
+        if (!all_chunk_is_mine(A, c, c - A.all_off[u] / 2, R)) continue;   // another rank's chunk
         if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;
         FirstWork W = carve_first(work, U.n_seg, 8);   // (the wavefront form's breakpoint area is not used here)
         uint8_t* rows_t = work + head_bytes;
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void ambi_all_kernel(BatchArgs A, int pass, in
         if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;   // no orientation flip for this unit (LGM.cpp:3691-3695)
         const UnitIn& U = A.units[u];
         if (U.bkp_cap <= lane_cap) continue;                         // taken by ambi_all_lanes_kernel
+        if (!all_chunk_is_mine(A, c, c - A.all_off[u] / 2, R)) continue;   // another rank's chunk
         FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
         uint8_t* rows = work + first_work_bytes(U.n_seg, U.bkp_cap);
         g.sync();
@@ -743,7 +745,8 @@ class HipBackend : public Backend {
     uint64_t* d_all_bits_ = nullptr; int64_t* d_all_off_ = nullptr; int32_t* d_all_count_ = nullptr; int32_t* d_all_flags_ = nullptr;
     int8_t* d_inject_ = nullptr; int64_t* d_inject_off_ = nullptr;
     float all_kernel_ms_ = -1.f;
-    int64_t all_bits_cap_ = 0;
+    int64_t all_bits_cap_ = 0, all_pool_bytes_ = 0;
+    int all_rank_ = 0, all_world_ = 1;
     bool all_done_ = false;
     int enum_grid_ = 2048;
     bool emit_lds_auto_ = true;
@@ -754,7 +757,7 @@ class HipBackend : public Backend {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
-                        d_all_bits_, d_all_off_, d_all_count_, d_all_flags_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_};
+                        d_all_bits_, d_all_off_, d_all_count_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
@@ -1014,7 +1017,7 @@ class HipBackend : public Backend {
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0;
-        A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_;
+        A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_;
     }
     BatchArgs slice_args(int s) const {
         BatchArgs A = A_;
@@ -1466,13 +1469,17 @@ class HipBackend : public Backend {
         all_idx_[0].assign(U, {}); all_idx_[1].assign(U, {});
         all_counts_.assign(2 * (size_t)U, 0);
         const int64_t words = all_off_[U], chunks = words / 2;
-        if (d_all_bits_ && all_bits_cap_ < words) { (void)hipFree(d_all_bits_); d_all_bits_ = nullptr; }
-        if (!d_all_off_) { if (int rc = dalloc(&d_all_off_, (size_t)U + 1)) return rc; if (int rc = dalloc(&d_all_count_, 2 * (size_t)U)) return rc; if (int rc = dalloc(&d_all_flags_, (size_t)U)) return rc; }
-        if (!d_all_bits_) { HIP_CK(hipMalloc((void**)&d_all_bits_, (size_t)(words > 0 ? words : 1) * sizeof(uint64_t))); all_bits_cap_ = words; }
+        // one pool: [bitmaps: words x 8 bytes][flags: U x 4 bytes] -- what ranks merge with ONE reduction when a wide sample's
+        // orders are dealt over them (ambi_batch_all_device)
+        const int64_t pool_words = words + ((int64_t)U + 1) / 2 + 1;
+        if (d_all_bits_ && all_bits_cap_ < pool_words) { (void)hipFree(d_all_bits_); d_all_bits_ = nullptr; }
+        if (!d_all_off_) { if (int rc = dalloc(&d_all_off_, (size_t)U + 1)) return rc; if (int rc = dalloc(&d_all_count_, 2 * (size_t)U)) return rc; }
+        if (!d_all_bits_) { HIP_CK(hipMalloc((void**)&d_all_bits_, (size_t)pool_words * sizeof(uint64_t))); all_bits_cap_ = pool_words; }
+        d_all_flags_ = reinterpret_cast<int32_t*>(d_all_bits_ + words);
+        all_pool_bytes_ = (words + ((int64_t)U + 1) / 2) * (int64_t)sizeof(uint64_t);
         HIP_CK(hipMemcpyAsync(d_all_off_, all_off_.data(), (U + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-        HIP_CK(hipMemsetAsync(d_all_bits_, 0, (size_t)(words > 0 ? words : 1) * sizeof(uint64_t), stream_));
+        HIP_CK(hipMemsetAsync(d_all_bits_, 0, (size_t)pool_words * sizeof(uint64_t), stream_));
         HIP_CK(hipMemsetAsync(d_all_count_, 0, 2 * (size_t)U * sizeof(int32_t), stream_));
-        HIP_CK(hipMemsetAsync(d_all_flags_, 0, (size_t)U * sizeof(int32_t), stream_));
         bind(A_.flags);
         all_kernel_ms_ = -1.f;
         if (chunks > 0) {
@@ -1513,6 +1520,28 @@ class HipBackend : public Backend {
             HIP_CK(hipStreamSynchronize(stream_));
             if (timing_) { (void)hipEventElapsedTime(&all_kernel_ms_, ea, eb); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); }
         }
+        return 0;
+    }
+    // --all over several ranks: which chunks this rank evaluates; the pool the ranks merge; counts / headers after the merge
+    int set_shard(int rank, int world) override {
+        if (world < 1 || rank < 0 || rank >= world) return ST_ERR_BAD_INPUT;
+        all_rank_ = rank; all_world_ = world;
+        return 0;
+    }
+    int all_device(void** ptr, int64_t* bytes) override {
+        if (ptr) *ptr = d_all_bits_;
+        if (bytes) *bytes = d_all_bits_ ? all_pool_bytes_ : 0;
+        return 0;
+    }
+    int all_finish() override {
+        if (!d_all_bits_) return 0;
+        const int U = (int)hb_.units.size();
+        hipLaunchKernelGGL(ambi_all_finalize_kernel, dim3((U + 255) / 256), dim3(256), 0, stream_, A_);
+        HIP_CK(hipGetLastError());
+        HIP_CK(hipMemcpyAsync(all_counts_.data(), d_all_count_, 2 * (size_t)U * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CK(hipStreamSynchronize(stream_));
+        all_cache_.assign(U, {});
+        all_idx_[0].assign(U, {}); all_idx_[1].assign(U, {});
         return 0;
     }
     // valid order indices of one pass of a unit, from its bitmap (fetched once per unit)

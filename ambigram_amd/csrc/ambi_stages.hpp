@@ -645,7 +645,6 @@ AMBI_HD void stage_all_chunk(const G& g, const BatchArgs& A, int u, const FirstW
     }
     if (g.tid() == 0) {
         A.all_bits[A.all_off[u] + (int64_t)pass * all_words(R) + c] = word;
-        if (word) atomic_add_i32(A.all_count + 2 * (int64_t)u + pass, popc64(word));
         if (undefined) atomic_add_i32(A.all_flags + u, 1);
     }
 }
@@ -682,15 +681,26 @@ AMBI_HD void stage_all_chunk_lanes(const G& g, const BatchArgs& A, int u, const 
     const bool any_undefined = g.any(undefined != 0);
     if (g.tid() == 0) {
         A.all_bits[A.all_off[u] + (int64_t)pass * all_words(R) + c] = word;
-        if (word) atomic_add_i32(A.all_count + 2 * (int64_t)u + pass, popc64(word));
         if (any_undefined) atomic_add_i32(A.all_flags + u, 1);
     }
 }
 // header of a unit after both passes: all orders of the executed passes were evaluated; undefined orders refuse the unit
+// does this rank evaluate chunk `cl` (index inside the unit) = global chunk `c` ?
+AMBI_HD bool all_chunk_is_mine(const BatchArgs& A, int64_t c, int64_t cl, int64_t R) {
+    if (A.all_world <= 1) return true;
+    return (c % A.all_world) == A.all_rank || cl == all_words(R) - 1;
+}
 AMBI_HD void all_finalize_unit(const BatchArgs& A, int u) {
     UnitOut* out = unit_out(A.results, u);
     if (A.all_off[u + 1] == A.all_off[u]) return;   // unit without a map (not reconstructed)
     const int64_t R = out->num_orders;
+    // counts from the bitmaps (complete once the ranks' maps are merged; a single rank's are complete at once)
+    const int64_t nw = all_words(R);
+    for (int ps = 0; ps < 2; ps++) {
+        int cnt = 0;
+        for (int64_t w = 0; w < nw; w++) cnt += popc64(A.all_bits[A.all_off[u] + ps * nw + w]);
+        A.all_count[2 * (int64_t)u + ps] = cnt;
+    }
     out->evaluated = (int32_t)(all_pass0_last_valid(A, u, R) ? R : 2 * R);
     if (A.all_flags[u]) out->status = ST_ERR_REF_UB;
 }

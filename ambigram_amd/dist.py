@@ -175,3 +175,34 @@ class RunExchange:
                 off += n
             out.append(paths)
         return out
+
+
+class _DevBytes:
+    """a device address as a CUDA-array-interface object (so that torch can wrap the engine's own allocation)"""
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def all_mode_merge(batch, device, stream=None, force=False):
+    """`--all` with the orders of the batch's units dealt over the ranks (Batch.all_set_shard before run): merges the ranks'
+    validity bitmaps and undefined-order flags with ONE all-reduce (bytes, MAX: the contributions are disjoint and zero
+    elsewhere) and lets the engine recount.  Every rank ends with the complete lists."""
+    import ctypes as C
+    ptr, nbytes = batch.all_device()
+    if nbytes > 0 and dist.is_initialized() and (dist.get_world_size() > 1 or force):   # force: one-rank group (exercises the RCCL call)
+        if str(device).startswith("cuda"):
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if stream else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                t = torch.as_tensor(_DevBytes(ptr, nbytes), device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                torch.cuda.current_stream().synchronize()
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+        else:
+            buf = (C.c_uint8 * nbytes).from_address(ptr)
+            t = torch.frombuffer(buf, dtype=torch.uint8)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    batch.all_finish()

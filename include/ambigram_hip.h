@@ -207,6 +207,16 @@ int ambi_batch_all_count(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t* c
 int ambi_batch_all_orders(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int64_t* order_idx);
 int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells,
                          int64_t stride);
+/* --all for ONE wide sample on several GPUs (orders of a chromosome block-partitioned over ranks).  Every
+ * rank holds the same batch; ambi_batch_all_set_shard(rank, world) before ambi_batch_run(AMBI_FLAG_ALL) makes a rank evaluate
+ * the 64-order chunks c with c % world == rank (plus the last chunk of every unit, so that every rank knows by itself
+ * whether the orientation flips, LocalGenomicMap.cpp:3691-3695).  After ambi_batch_wait the ranks merge the pool that
+ * ambi_batch_all_device names -- validity bitmaps and undefined-order flags, as BYTES with MAX (disjoint contributions,
+ * zero elsewhere): one all-reduce over RCCL -- and call ambi_batch_all_finish, which recounts and finalises the headers;
+ * ambi_batch_all_count / _orders / _paths then answer on every rank as after a single-GPU run. */
+int ambi_batch_all_set_shard(ambi_batch_t* b, int32_t rank, int32_t world);
+int ambi_batch_all_device(ambi_batch_t* b, void** ptr, int64_t* bytes);
+int ambi_batch_all_finish(ambi_batch_t* b);
 /* Copies rows [first,first+count) of the unit's order table (count x K uint8) from the device. */
 int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out);
 

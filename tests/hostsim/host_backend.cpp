@@ -242,7 +242,11 @@ class HostSimBackend : public Backend {
     // --all: the engine's fused unrank + evaluate stage (stage_all_chunk), one 64-order chunk after the other; bitmaps,
     // counts and flags as the HIP backend keeps them
     std::vector<std::vector<int64_t>> all_idx_[2];
-    std::vector<uint64_t> all_bits_; std::vector<int64_t> all_off_; std::vector<int32_t> all_count_, all_flags_;
+    std::vector<uint64_t> all_bits_; std::vector<int64_t> all_off_; std::vector<int32_t> all_count_;
+    int64_t all_pool_bytes_ = 0; int all_rank_ = 0, all_world_ = 1;
+    int set_shard(int rank, int world) override { if (world < 1 || rank < 0 || rank >= world) return ST_ERR_BAD_INPUT; all_rank_ = rank; all_world_ = world; return 0; }
+    int all_device(void** ptr, int64_t* bytes) override { if (ptr) *ptr = all_bits_.empty() ? nullptr : all_bits_.data(); if (bytes) *bytes = all_bits_.empty() ? 0 : all_pool_bytes_; return 0; }
+    int all_finish() override { if (!all_bits_.empty()) finalize_all(); return 0; }
     void compute_all() {
         HostGroup g;
         const int Un = (int)units_.size();
@@ -253,8 +257,13 @@ class HostSimBackend : public Backend {
             const bool live = out->status == ST_OK && out->num_orders > 0 && out->num_orders < (int64_t)kCountSat;
             all_off_[u + 1] = all_off_[u] + (live ? 2 * all_words(out->num_orders) : 0);
         }
-        all_bits_.assign((size_t)all_off_[Un] + 1, 0); all_count_.assign(2 * (size_t)Un, 0); all_flags_.assign((size_t)Un, 0);
-        A_.all_bits = all_bits_.data(); A_.all_off = all_off_.data(); A_.all_count = all_count_.data(); A_.all_flags = all_flags_.data();
+        // one pool as in the HIP backend: [bitmaps][flags]
+        const int64_t words = all_off_[Un];
+        all_bits_.assign((size_t)(words + (Un + 1) / 2 + 1), 0); all_count_.assign(2 * (size_t)Un, 0);
+        all_pool_bytes_ = (words + (Un + 1) / 2) * 8;
+        A_.all_bits = all_bits_.data(); A_.all_off = all_off_.data(); A_.all_count = all_count_.data();
+        A_.all_flags = reinterpret_cast<int32_t*>(all_bits_.data() + words);
+        A_.all_rank = all_rank_; A_.all_world = all_world_;
         for (int pass = 0; pass < 2; pass++) {
             for (int u = 0; u < Un; u++) {
                 if (all_off_[u + 1] == all_off_[u]) continue;
@@ -269,11 +278,17 @@ class HostSimBackend : public Backend {
                 const bool lanes = !(el && atoi(el) == 0) && U.bkp_cap <= kAllLaneMaxCells;
                 std::vector<cell_t> cells(lanes ? (size_t)U.bkp_cap * 64 : 1);
                 for (int64_t c = 0; c < all_words(R); c++) {
+                    if (!all_chunk_is_mine(A_, all_off_[u] / 2 + c, c, R)) continue;   // another rank's chunk
                     if (lanes) stage_all_chunk_lanes(g, A_, u, W, rows.data(), cells.data(), c, pass);
                     else stage_all_chunk(g, A_, u, W, rows.data(), c, pass);
                 }
             }
         }
+        finalize_all();
+    }
+    void finalize_all() {
+        const int Un = (int)units_.size();
+        all_idx_[0].assign(Un, {}); all_idx_[1].assign(Un, {});
         for (int u = 0; u < Un; u++) {
             all_finalize_unit(A_, u);
             if (all_off_[u + 1] == all_off_[u]) continue;

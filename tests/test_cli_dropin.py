@@ -57,6 +57,22 @@ def check_readme(exe, cwd, oracle):
     assert row[1:7] == ["6", "4", "0", "32", "32", "8"]
     sv = open(os.path.join(cwd, "simulation_sv.txt")).read().strip().splitlines()
     assert sum(l.endswith("input") for l in sv) == 4 and sum(l.endswith("output") for l in sv) >= 1
+    # simulation_sv.txt, derived by hand from localhap.cpp:326-337 + :267-289 + Vertex.cpp:27-29: every row is
+    # lh \t juncs \t chrom(u) \t u.getEnd() \t dir(u) \t chrom(v) \t v.getStart() \t dir(v) \t CN \t input|output with u -> v edge A of
+    # the junction; getEnd() of a '-' vertex is the segment's START, getStart() of a '-' vertex its END.  Input rows = the four
+    # JUNC lines; output rows = the non-adjacent steps of README.md:122 in order of first appearance, counted: 6+|6- twice,
+    # 2-|2+ twice, 4+|4- twice, 3-|3+ once.
+    row = lambda cu, pu, du, cv, pv, dv, cn, kind: "\t".join([lh, "", cu, str(pu), du, cv, str(pv), dv, cn, kind])
+    assert sv[:8] == [
+        row("chr7", 55282001, "-", "chr7", 55282001, "+", "2", "input"),
+        row("chr7", 55283001, "-", "chr7", 55283001, "+", "1", "input"),
+        row("chr7", 55285000, "+", "chr7", 55285000, "-", "2", "input"),
+        row("chr7", 55286001, "-", "chr7", 55286001, "+", "2", "input"),
+        row("chr7", 55287000, "+", "chr7", 55287000, "-", "2", "output"),
+        row("chr7", 55282001, "-", "chr7", 55282001, "+", "2", "output"),
+        row("chr7", 55285000, "+", "chr7", 55285000, "-", "2", "output"),
+        row("chr7", 55283001, "-", "chr7", 55283001, "+", "1", "output"),
+    ]
     # reversed
     fake_cbc(bindir, [os.path.join(DATA, "readme6.sol")])
     r = run_cli(exe, cwd, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", "readme", "--reversed", "true")

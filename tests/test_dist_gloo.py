@@ -87,3 +87,71 @@ def test_gather_matches_oracle(oracle, hostsim_lib, workdir, world):
             lh, sols = s.write(tmp, "o%d" % i)
             want = oracle.run_bfb(lh, sols)["chr"][0]["path_indel"]
             assert got[r][k] == want, (r, i)
+
+
+ALL_WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import torch
+    import torch.distributed as dist
+    import cases
+    from ambigram_amd import api, synth
+    from ambigram_amd.dist import all_mode_merge
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    lib = api.load(%(lib)r)
+    tmp = os.path.join(%(tmp)r, "r%%d" %% rank)
+    # EVERY rank holds the same units: wide samples (all orders valid) and random decompositions (few or none valid, flips)
+    items = []
+    for i, (tier, K) in enumerate([("wide", 11), ("wide", 13), ("mixed", 9)]):
+        s = synth.make_sample(64, 128, tier, K, seed=6100 + i)
+        lh, sols = s.write(tmp, "w%%d" %% i)
+        items.append((lh, sols[0]))
+    for seed in range(40):
+        lh, sols = cases.random_decomposition(tmp, 2600 + seed)
+        items.append((lh, sols[0]))
+
+    def run(shard):
+        graphs, b = [], api.Batch(lib)
+        for lh, sol in items:
+            g = api.Graph(lib, lh); graphs.append(g)
+            b.add_chromosome_sol(g, 0, sol)
+        if shard:
+            b.all_set_shard(rank, world)
+        b.upload(); b.run(api.FLAG_ALL); b.wait()
+        if shard:
+            all_mode_merge(b, "cpu")
+        b.download()
+        out = []
+        for u in range(len(items)):
+            r = b.unit_result(u)
+            out.append([r["status"], r["evaluated"], b.all_orders(u, 0).tolist(), b.all_orders(u, 1).tolist()])
+        b.close()
+        return out
+
+    sharded, alone = run(True), run(False)
+    assert sharded == alone, [i for i, (x, y) in enumerate(zip(sharded, alone)) if x != y]
+    assert sum(1 for x in alone if x[0] == 0 and len(x[2]) > 64) >= 2       # really several chunks per unit
+    if rank == 0:
+        json.dump(dict(units=len(items), valid=[len(x[2]) + len(x[3]) for x in alone]), open(os.path.join(%(tmp)r, "all.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_mode_orders_dealt_over_ranks(hostsim_lib, workdir, world):
+    """--all for wide samples with the 64-order chunks of every unit dealt over the ranks (SURVEY.md 8e, order-level
+    sharding): one all-reduce of the bitmaps, then every rank holds the same lists a single rank computes."""
+    tmp = os.path.join(workdir, "distall%d" % world)
+    os.makedirs(tmp, exist_ok=True)
+    lib_path = os.path.join(ROOT, "tests", "hostsim", "libambigram_hostsim.so")
+    script = os.path.join(tmp, "worker.py")
+    with open(script, "w") as f:
+        f.write(ALL_WORKER % dict(root=ROOT, lib=lib_path, tmp=tmp))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29563 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
