@@ -162,6 +162,7 @@ struct BatchArgs {
     const int64_t* all_off;      // [U+1] first word of every unit's pass-0 map; its pass-1 map follows (ceil(R/64) words each)
     int32_t* all_count;          // [U][2] valid orders per pass
     int32_t* all_flags;          // [U]    != 0: an order on which the reference's behaviour is undefined was met (behind the bitmaps in the same pool)
+    int32_t all_rows_from_table; // experiment (env AMBI_ALL_TABLE=1): the lane kernel reads its orders from the order table instead of unranking them
     int32_t all_rank, all_world; // --all over several ranks (one wide sample): a rank evaluates the chunks c with c % world == rank,
                                  // plus the LAST chunk of every unit (every rank must know whether the orientation flips)
 };

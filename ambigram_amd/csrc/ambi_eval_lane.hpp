@@ -28,7 +28,15 @@ AMBI_HD bool imperfect_fbi_lane(const LaneCells& b, int L, const InvMap& inv) {
         if (pos + 1 >= L) return false;
         const int c0 = b.get(pos), c1 = b.get(pos + 1);
         int r = L;
-        for (int q = pos + 3; q < L; q++) if (b.get(q) == -c0) { r = q; break; }
+        // first later cell holding -c0: four cells per round (independent loads: one latency, not four)
+        for (int q = pos + 3; q < L && r == L; q += 4) {
+            const int last = L - 1;
+            const int v0 = b.get(q), v1 = b.get(q + 1 < last ? q + 1 : last), v2 = b.get(q + 2 < last ? q + 2 : last), v3 = b.get(q + 3 < last ? q + 3 : last);
+            if (v0 == -c0) r = q;
+            else if (q + 1 < L && v1 == -c0) r = q + 1;
+            else if (q + 2 < L && v2 == -c0) r = q + 2;
+            else if (q + 3 < L && v3 == -c0) r = q + 3;
+        }
         const int l = r - 1;
         if (r == L || b.get(l) != -c1) {
             int n0 = c0, n1 = c1;
@@ -111,20 +119,29 @@ AMBI_HD int eval_order_lane(const Dag& D, const uint8_t* ord, int ord_stride, bo
             const int s = D.loop[x][0], e = D.loop[x][1], cn = D.loop[x][2];
             // reverse search: the last odd slot holding -s that passes its nesting test, else the last one holding e
             int f1 = -1, f2 = -1;
-            for (int q = (L - 1) | 1; q >= 1; q -= 2) {
-                if (q >= L) continue;
-                const int c = b.get(q);
-                if (c != -s && c != e) continue;
-                if (c == -s && f1 >= 0) continue;
-                if (c == e && (f2 >= 0 || f1 >= 0)) continue;
+            // one candidate slot: true when the search is over (a -s slot outranks every e slot)
+            auto examine = [&](int q, int c) -> bool {
+                if (c != -s && c != e) return false;
+                if (c == e && f2 >= 0) return false;
                 bool skip = false;
                 if (q < L - 2) {
                     const int xa = iabs(b.get(q - 1)), ya = iabs(b.get(q + 2));
                     skip = (c == -s) ? (xa < ya) : (xa > ya);
                 }
-                if (skip) continue;
-                if (c == -s) { f1 = q; break; }   // a -s slot outranks every e slot
+                if (skip) return false;
+                if (c == -s) { f1 = q; return true; }
                 f2 = q;
+                return false;
+            };
+            {   // odd slots from the top, four per round (independent loads)
+                int q = (L - 1) | 1;
+                if (q >= L) q -= 2;
+                bool done = false;
+                for (; !done && q - 6 >= 1; q -= 8) {
+                    const int c0 = b.get(q), c1 = b.get(q - 2), c2 = b.get(q - 4), c3 = b.get(q - 6);
+                    done = examine(q, c0) || examine(q - 2, c1) || examine(q - 4, c2) || examine(q - 6, c3);
+                }
+                for (; !done && q >= 1; q -= 2) done = examine(q, b.get(q));
             }
             const bool viaV1 = f1 >= 0;
             const int f = viaV1 ? f1 : f2;
@@ -132,7 +149,14 @@ AMBI_HD int eval_order_lane(const Dag& D, const uint8_t* ord, int ord_stride, bo
             const int cnt = 4 * cn;
             if (L + cnt > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
             const bool hasNext = (f + 1 != L);
-            for (int q = L - 1; q >= f + 1; q--) b.set(q + cnt, b.get(q));
+            {   // cells [f+1, L) move up by cnt >= 4: four loads, then four stores (the stores of a round land above its loads)
+                int q = L - 1;
+                for (; q - 3 >= f + 1; q -= 4) {
+                    const int v0 = b.get(q), v1 = b.get(q - 1), v2 = b.get(q - 2), v3 = b.get(q - 3);
+                    b.set(q + cnt, v0); b.set(q - 1 + cnt, v1); b.set(q - 2 + cnt, v2); b.set(q - 3 + cnt, v3);
+                }
+                for (; q >= f + 1; q--) b.set(q + cnt, b.get(q));
+            }
             int qq[4], fix0, fix1;
             if (viaV1) { qq[0] = s; qq[1] = e; qq[2] = -e; qq[3] = -s; fix0 = -s; fix1 = s; }
             else { qq[0] = -e; qq[1] = -s; qq[2] = s; qq[3] = e; fix0 = e; fix1 = -e; }

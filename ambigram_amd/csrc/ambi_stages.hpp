@@ -669,7 +669,11 @@ AMBI_HD void stage_all_chunk_lanes(const G& g, const BatchArgs& A, int u, const 
     for (int i = g.tid(); i < 64; i += g.size()) {
         int v = 0;
         if (i < cnt) {
-            (void)order_unrank(V, K, (uint64_t)(first + i), rows_t + i, 64);
+            if (A.all_rows_from_table && out->order_off >= 0) {   // experiment switch: the orders from the table the enumerate kernel wrote
+                const uint8_t* row = A.order_arena + out->order_off + (first + i) * row_stride(K);
+                for (int d = 0; d < K; d++) rows_t[d * 64 + i] = row[d];
+            } else
+                (void)order_unrank(V, K, (uint64_t)(first + i), rows_t + i, 64);
             int L = 0;
             v = eval_order_lane(*W.dag, rows_t + i, 64, forward, inv, LaneCells{cells + i, 64}, U.bkp_cap, &L);
             v = injected_verdict(A, u, R, first + i, forward, v);

@@ -306,7 +306,11 @@ int main(int argc, char** argv) {
         double max_cn = 0;
         for (double v : cn_all) max_cn += v;
         ambi_ilp_t* ilp = nullptr;
-        if ((rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp)) != 0) return die(ambi_error_string(rc));
+        // BFB_ILP (LGM.cpp:4397-4752): the rows are listed on the host, the non-zeros (56.5 M at 256 segments) written by
+        // ambi_ilp_fill_kernel on the device; small chromosomes are not worth the launch and take the host generator
+        if (n >= 32) rc = ambi_ilp_build_device(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, nullptr, &ilp);
+        else rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp);
+        if (rc != 0) return die(ambi_error_string(rc));
         head[c] = "Declare done\nILP formula done\nVariable constrains done\n";
         ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());   // LGM.cpp:4749-4750: both side files
         ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());

@@ -263,7 +263,7 @@ class HostSimBackend : public Backend {
         all_pool_bytes_ = (words + (Un + 1) / 2) * 8;
         A_.all_bits = all_bits_.data(); A_.all_off = all_off_.data(); A_.all_count = all_count_.data();
         A_.all_flags = reinterpret_cast<int32_t*>(all_bits_.data() + words);
-        A_.all_rank = all_rank_; A_.all_world = all_world_;
+        A_.all_rank = all_rank_; A_.all_world = all_world_; A_.all_rows_from_table = 0;
         for (int pass = 0; pass < 2; pass++) {
             for (int u = 0; u < Un; u++) {
                 if (all_off_[u + 1] == all_off_[u]) continue;
