@@ -65,8 +65,9 @@ def synthetic_cases(workdir, small_only=True):
 
 
 def random_decomposition(workdir, seed, n=14):
-    """A .lh with fold-backs everywhere + a RANDOM element set as .sol: most orders are invalid, so the first valid
-    order sits deep in the table (or does not exist) -- exercises the search path and the orientation flip."""
+    """A .lh with fold-backs everywhere + a RANDOM element set as .sol: for most element sets NO order assembles in the
+    first orientation (often in neither) -- exercises the scan budget, the parallel search over whole passes and the
+    orientation flip.  (All orders of a unit share their validity on every input known: tests/tools/search_mixed_validity.py.)"""
     rng = random.Random(seed)
     L = ["SAMPLE_NAME rnd%d" % seed, "AVG_CHR_SEG_DP 30", "AVG_WHOLE_HOST_DP 30", "AVG_JUNC_DP 30", "PURITY 1",
          "AVG_TUMOR_PLOIDY 2", "PLOIDY 2m1", "VIRUS_START %d" % (n + 1), "SOURCE 1", "SINK %d" % n]

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Long randomized parity run, not collected by pytest (minutes):  python3 tests/soak.py [hip|hostsim] [first_seed] [count]
-Random decompositions (both orientations, tiny scan budget so that deep first-valid orders take the parallel search)
+Random decompositions (both orientations, scan budget 2: units without a valid order in the first orientation go through
+the parallel search of both passes; NOTE no known input has a first valid order other than order 0 of a pass -- `deep` in
+the statistics stays 0 -- the search for a deeper one is tested with injected verdicts, engine_checks.check_injected_validity)
 and synthetic samples of every tier with imperfect fold-backs and path-editing SVs, engine against the oracle."""
 import os, sys, tempfile, time
 HERE = os.path.dirname(os.path.abspath(__file__))
