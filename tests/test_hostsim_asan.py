@@ -24,6 +24,9 @@ with tempfile.TemporaryDirectory() as d:
     ec.check_edge_cases(lib, oracle_py, d)
     ec.check_enumerate_variants(lib, oracle_py, d)
     ec.check_all_mode(lib, oracle_py, d, seeds=range(10))
+    ec.check_injected_validity(lib, oracle_py, d)                 # parallel search stages, --all bitmaps with mixed verdicts
+    ec.check_all_two_forms(lib, d, seeds=range(300, 330))         # one thread per order vs one wavefront per order
+    ec.check_mixed_batch(lib, oracle_py, d)                       # > 32 units: ordinary chain; the runs above: express path
 print("SANITIZED RUN CLEAN")
 """
 
