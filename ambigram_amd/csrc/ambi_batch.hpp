@@ -105,6 +105,7 @@ struct BatchArgs {
     int32_t build_in_emit;       // 1: units with one work block get their image built in LDS by the enumerate workgroup
     int32_t emit_interleave;     // 1: the blocks of a work block are dealt round-robin to the workgroup's waves (one compact store window)
     int32_t finish_path_cells;   // path cells the full finish stage can hold in group memory (<= kPathLdsCells; 0: that limit)
+    int32_t order_align;         // every unit's table starts at a multiple of this many bytes of the arena (power of two >= 16)
     int32_t block_dfs;           // 1: units whose directory does not fit get the directory-free image (block walk at emission)
     int32_t* unit_fallback;      // [U] set by ambi_blocks_build_kernel when a unit's image does not fit block_lds
     uint8_t* block_img;          // [U][block_lds] images (built once per unit, copied to LDS by the emitting workgroups)

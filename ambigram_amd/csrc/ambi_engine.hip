@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     int64_t my_rows = 0;
     for (int i = threadIdx.x; i < A.n_units; i += blockDim.x) {
         const UnitOut* o = unit_out(A.results, A.unit_base + i);
-        if (o->status == ST_OK && o->num_orders < (int64_t)kCountSat) my_rows += o->num_orders;
+        if (o->order_off == kOrderOffWanted && o->num_orders < (int64_t)kCountSat) my_rows += o->num_orders;
     }
     int64_t total_rows;
     (void)block_exscan_i64(my_rows, &total_rows, sh);
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
         UnitOut* out = nullptr;
         if (i < A.n_units) {
             out = unit_out(A.results, u);
-            if (out->status == ST_OK) {
+            if (out->order_off == kOrderOffWanted) {   // (not the status: the scan for the first valid order may be rewriting it)
                 const int K = out->K;
                 const int64_t R = out->num_orders;
                 if (R >= (int64_t)kCountSat) toobig = true;
                 else {
                     live = true;
-                    bytes = order_bytes(R, K);
+                    bytes = order_bytes(R, K, A.order_align);
                     blocks = (R + 256ll * T - 1) / (256ll * T);   // one work block = one workgroup = 4 waves x 64*T rows
                 }
             }
@@ -138,11 +138,8 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
         if (i < A.n_units) {
             A.blk_off[i] = blk;
             A.rows_per_lane[u] = T;
-            if (toobig) out->status = ST_ERR_ORDERS_CAPACITY;
-            else if (live) {
-                if (fits) out->order_off = A.arena_base + off;
-                else out->status = ST_ERR_ORDERS_CAPACITY;
-            }
+            if (toobig) out->order_off = kOrderOffNoRoom;
+            else if (live) out->order_off = fits ? A.arena_base + off : kOrderOffNoRoom;   // (no room: the finish stage turns the status into ORDERS_CAPACITY)
         }
         off_carry += tot_b;
         blk_carry += tot_k;
@@ -367,7 +364,18 @@ __global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A
         const int64_t wlo = blo + (int64_t)wave * per;
         int64_t whi = wlo + per;
         if (whi > bhi) whi = bhi;
-        if (!dfs && A.emit_interleave) {   // the blocks of the whole work block dealt round-robin to the waves
+        if (!dfs && A.emit_interleave == 2) {   // TIMING EXPERIMENT (wrong bytes): flat 1 KB pieces, no block logic
+            const int64_t nvec = (R * row_stride(K)) >> 4;
+            uint4* o4 = reinterpret_cast<uint4*>(A.order_arena + out->order_off);
+            for (int64_t p = wave; p * 64 < nvec; p += nwave) {
+                const int64_t idx = p * 64 + lane;
+                if (idx < nvec) {
+                    const uint32_t rel = (uint32_t)(idx * 4) & 2047u, k = rel % 5u;
+                    uint4 v; v.x = image[rel] | image[k]; v.y = image[rel + 1] | image[k + 1]; v.z = image[rel + 2] | image[k + 2]; v.w = image[rel + 3] | image[k + 3];
+                    o4[idx] = v;
+                }
+            }
+        } else if (!dfs && A.emit_interleave) {   // the blocks of the whole work block dealt round-robin to the waves
             if (blo < bhi)
                 emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)blo, (uint32_t)bhi, A.order_arena + out->order_off, lane, lane + 1, wave, nwave);
         } else if (wlo < whi) {
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(64) void ambi_order_paths_kernel(BatchArgs A, int u
 // list_count == nullptr: one workgroup per entry (host-built list of the slow path), else the list is the one the lean
 // kernel in front of this launch filled on the device (refin_list / refin_count) and the workgroups share it in strides
 // -- no host round trip between the two kernels.
-__global__ __launch_bounds__(256) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list, const int32_t* list_count, int fixed_count = -1) {
+__global__ __launch_bounds__(1024) void ambi_finish_kernel(BatchArgs A, const int32_t* unit_list, const int32_t* list_count, int fixed_count = -1) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     if (unit_list && (list_count || fixed_count >= 0)) {
@@ -727,6 +735,9 @@ class HipBackend : public Backend {
     hipStream_t back_stream_ = nullptr;
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr, ev_first_ = nullptr, ev_full_ = nullptr;
     hipStream_t full_stream_ = nullptr;
+    bool first_launched_ = false; hipEvent_t ev_plan_ = nullptr;
+    int full_threads_ = 1024;  // env AMBI_FULL_THREADS: threads per workgroup of the direct full-finish launch (256 / 512 / 1024)
+    hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
     int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0;
@@ -736,6 +747,8 @@ class HipBackend : public Backend {
     int32_t run_seq_ = 0;
     uint8_t* d_first_rows_ = nullptr;
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
+    int order_align_ = 4096;  // env AMBI_ORDER_ALIGN: every unit's table starts on a 4 KB boundary of the arena (a store stream whose 1 KB pieces are
+                              // line-aligned: 5.4 -> 5.7 TB/s on a pure store stream of this shape, profiles/tools/hbm_write_pat5.hip)
     int emit_interleave_ = 1; // env AMBI_EMIT_INTERLEAVE=0: every wave a contiguous quarter of the work block instead of every fourth block
     int block_dfs_ = 1;       // env AMBI_BLOCK_DFS=0: no directory-free images (units whose directory does not fit take the general path)
     std::vector<std::vector<int64_t>> all_idx_[2];   // --all: valid order indices per pass and unit (filled when asked for)
@@ -750,6 +763,7 @@ class HipBackend : public Backend {
     bool all_done_ = false;
     int enum_grid_ = 2048;
     bool emit_lds_auto_ = true;
+    bool emit_lds_tight_ = true;   // env AMBI_EMIT_LDS_TIGHT=0: the whole 160 KB / k share
     double avg_path_ = 0;
     int enum_threads_ = 256;  // threads per workgroup of the block-emission kernel (env AMBI_ENUM_THREADS: 256 / 512 / 1024)
 
@@ -784,9 +798,13 @@ class HipBackend : public Backend {
         ev_stage_.clear();
         if (back_stream_) (void)hipStreamDestroy(back_stream_);
         if (full_stream_) (void)hipStreamDestroy(full_stream_);
+        if (first_stream_) (void)hipStreamDestroy(first_stream_);
+        first_stream_ = nullptr;
         if (ev_first_) (void)hipEventDestroy(ev_first_);
         if (ev_full_) (void)hipEventDestroy(ev_full_);
         full_stream_ = nullptr; ev_first_ = ev_full_ = nullptr; direct_n_ = 0;
+        if (ev_plan_) (void)hipEventDestroy(ev_plan_);
+        ev_plan_ = nullptr;
         if (ev_prep_) (void)hipEventDestroy(ev_prep_);
         if (ev_back_) (void)hipEventDestroy(ev_back_);
         back_stream_ = nullptr; ev_prep_ = ev_back_ = nullptr;
@@ -852,6 +870,7 @@ class HipBackend : public Backend {
         if (hipHostGetDevicePointer((void**)&dh_npending_, h_npending_, 0) != hipSuccess) dh_npending_ = nullptr;
         if (hipHostGetDevicePointer((void**)&dh_needed_, h_needed_, 0) != hipSuccess) dh_needed_ = nullptr;
         (void)hipGetLastError();
+        { const char* e9 = getenv("AMBI_ORDER_ALIGN"); order_align_ = e9 ? atoi(e9) : 4096; if (order_align_ < 16 || (order_align_ & (order_align_ - 1))) order_align_ = 4096; }
         arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
         HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
         HIP_CK(hipMemcpy(d_units_, hb.units.data(), U * sizeof(UnitIn), hipMemcpyHostToDevice));
@@ -884,6 +903,7 @@ class HipBackend : public Backend {
         lds_blocks_ = block_lds_;
         const int kLdsLimit = 160 * 1024 - 1024;
         emit_lds_auto_ = !getenv("AMBI_BLOCK_LDS");
+        { const char* e = getenv("AMBI_EMIT_LDS_TIGHT"); emit_lds_tight_ = e ? atoi(e) != 0 : true; }
         { const char* env = getenv("AMBI_BLOCK_SCRATCH_LDS"); block_scratch_lds_ = ((env ? atoi(env) : cfg.block_scratch_lds) + 15) & ~15; }
         if (block_scratch_lds_ > kLdsLimit) block_scratch_lds_ = kLdsLimit & ~15;
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
@@ -927,7 +947,7 @@ class HipBackend : public Backend {
             slice_lo_.assign(n_slices_ + 1, 0);
             for (int s = 0; s <= n_slices_; s++) slice_lo_[s] = (int)((int64_t)U * s / n_slices_);
             slice_base_.assign(n_slices_, 0); slice_bytes_.assign(n_slices_, 0);
-            for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(15); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(15); }
+            for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(order_align_ - 1); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(order_align_ - 1); }
             for (int s = 1; s < n_slices_; s++) { hipStream_t st; HIP_CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); side_.push_back(st); }
             HIP_CK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
             for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_join_.push_back(e); }
@@ -940,7 +960,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
         { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e9 = getenv("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
-        { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
+        { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? atoi(e9) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
             // the scan / finish kernels fill the gaps the enumerate kernel leaves: lowest dispatch priority (AMBI_BACK_PRIORITY=0: default)
@@ -951,6 +971,13 @@ class HipBackend : public Backend {
               } else {
                   HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
               } }
+            { const char* e = getenv("AMBI_FIRST_AHEAD"); first_ahead_ = e ? atoi(e) : 3; }
+            { const char* e = getenv("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : 1024; if (full_threads_ != 256 && full_threads_ != 512) full_threads_ = 1024; }
+            if (first_ahead_ >= 2) {
+                int least = 0, greatest = 0;
+                if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&first_stream_, hipStreamNonBlocking, greatest)); }
+            }
+            HIP_CK(hipEventCreateWithFlags(&ev_plan_, hipEventDisableTiming));
             HIP_CK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
             HIP_CK(hipEventCreateWithFlags(&ev_back_, hipEventDisableTiming));
             HIP_CK(hipEventCreateWithFlags(&ev_first_, hipEventDisableTiming));
@@ -1006,7 +1033,7 @@ class HipBackend : public Backend {
         A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
-        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.emit_interleave = emit_interleave_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
+        A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.emit_interleave = emit_interleave_; A_.order_align = order_align_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
         A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
@@ -1061,6 +1088,7 @@ class HipBackend : public Backend {
 
     void launch_front(int s, const BatchArgs& A) {   // prepare + plan of one slice
         hipStream_t st = slice_stream(s);
+        first_launched_ = false;
         if (express_) {
             // express kernel (whole reconstruction of the units whose first order assembles; results complete at ev_express_),
             // then the lattice stage of every unit; the express kernel hands units over by status, not through the list
@@ -1080,14 +1108,28 @@ class HipBackend : public Backend {
             tick("ambi_prepare_kernel", s, 0, true);
             hipLaunchKernelGGL(ambi_prepare_kernel, dim3(A.n_units), dim3(64), lds_prepare_, st, A);
             tick("ambi_prepare_kernel", s, 0, false);
+            // The scan for the first valid order reads what the prepare stage left (first rows, DAG) and rewrites the status;
+            // the plan stage reads and writes UnitOut::order_off only.  With first_ahead_ == 3 the scan therefore starts HERE,
+            // beside the plan kernel (one workgroup, 25 us during which the chip is otherwise idle) and the ramp of the
+            // enumerate kernel, instead of queueing behind 4096 enumerate workgroups for group memory.
+            first_launched_ = false;
+            if (overlap_back_ && first_ahead_ == 3) {
+                (void)hipEventRecord(ev_prep_, st);
+                hipStream_t sf = first_stream_ ? first_stream_ : back_stream_;
+                (void)hipStreamWaitEvent(sf, ev_prep_, 0);
+                tick("ambi_first_kernel", s, 4, true, sf);
+                hipLaunchKernelGGL(ambi_first_kernel, dim3(A.n_units), dim3(64), lds_first_, sf, A);
+                tick("ambi_first_kernel", s, 4, false, sf);
+                (void)hipEventRecord(ev_first_, sf);
+                first_launched_ = true;
+            }
             tick("ambi_plan_kernel", s, 1, true);
         }
         hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
         tick("ambi_plan_kernel", s, 1, false);
-        // The scan for the first valid order starts BEHIND the plan kernel: the plan kernel reads UnitOut::status (and may
-        // turn it into ORDERS_CAPACITY), the scan overwrites it (PENDING / NO_VALID_ORDER / errors) -- the two must not
-        // overlap.  Everything that runs beside the scan (image build, enumerate) reads order_off / blk_off only.
-        if (overlap_back_) (void)hipEventRecord(ev_prep_, st);
+        // (express chain: the lattice kernel reads the status, so the scan of the units the express kernel left stays behind
+        // the plan kernel there)
+        if (overlap_back_) (void)hipEventRecord(first_launched_ ? ev_plan_ : ev_prep_, st);
     }
     void launch_build(int s, const BatchArgs& A) {   // block-emission images
         hipStream_t st = slice_stream(s);
@@ -1119,6 +1161,26 @@ class HipBackend : public Backend {
         hipStream_t st = slice_stream(s);
         const int U = A.n_units;
         const int grid = enum_grid_;
+        // The scan for the first valid order (reads the first rows the prepare stage left, not the table).  Beside a long
+        // enumerate kernel it is launched AHEAD of it (first_ahead_): behind the enumerate kernel in launch order its 4096
+        // one-wave workgroups only get group memory as enumerate workgroups retire (0.06 ms alone, 0.5-0.6 ms beside), and
+        // the finish kernels behind it then start half-way through the table and end after it.
+        hipStream_t sb = overlap_back_ ? back_stream_ : st;
+        auto launch_first = [&]() {
+            if (first_launched_) {   // started beside the plan kernel (launch_front): the finish kernels wait for both
+                (void)hipStreamWaitEvent(sb, ev_first_, 0); (void)hipStreamWaitEvent(sb, ev_plan_, 0);
+                if (full_stream_) (void)hipStreamWaitEvent(full_stream_, ev_plan_, 0);
+                return;
+            }
+            hipStream_t sf = (first_ahead_ == 2 && overlap_back_ && first_stream_) ? first_stream_ : sb;
+            if (overlap_back_) (void)hipStreamWaitEvent(sf, ev_prep_, 0);
+            tick("ambi_first_kernel", s, 4, true, sf);
+            hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, sf, A);
+            tick("ambi_first_kernel", s, 4, false, sf);
+            if (overlap_back_) { (void)hipEventRecord(ev_first_, sf); if (sf != sb) (void)hipStreamWaitEvent(sb, ev_first_, 0); }
+        };
+        const bool ahead = (first_ahead_ > 0 && overlap_back_) || first_launched_;
+        if (ahead) { launch_first(); if (first_ahead_ == 1) (void)hipStreamWaitEvent(st, ev_first_, 0); }
         tick("ambi_enumerate_kernel", s, 3, true);
         const int lds_emit = lds_blocks_;
         if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
@@ -1128,20 +1190,13 @@ class HipBackend : public Backend {
         if ((enum_classes_ & 2) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 4) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
         tick("ambi_enumerate_kernel", s, 3, false);
-        // first valid order + finish: beside the enumerate kernel on their own stream when the first orders come from the
-        // prepare stage (they do not read the table then), else behind it
-        hipStream_t sb = st;
-        if (overlap_back_) { sb = back_stream_; (void)hipStreamWaitEvent(sb, ev_prep_, 0); }
-        tick("ambi_first_kernel", s, 4, true, sb);
-        hipLaunchKernelGGL(ambi_first_kernel, dim3(U), dim3(64), lds_first_, sb, A);
-        tick("ambi_first_kernel", s, 4, false, sb);
+        if (!ahead) launch_first();
         // units with deletion / duplication candidates go straight to the full finish stage, on a stream of their own beside
         // the lean kernel (both behind the scan, both beside the enumerate kernel); few workgroups, each taking units in turn
         if (direct_n_ > 0 && overlap_back_ && full_stream_) {
-            (void)hipEventRecord(ev_first_, sb);
             (void)hipStreamWaitEvent(full_stream_, ev_first_, 0);
             const int dgrid = direct_n_ < direct_grid_ ? direct_n_ : direct_grid_;
-            hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(256), lds_finish_, full_stream_, A, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
+            hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(full_threads_), lds_finish_, full_stream_, A, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
             (void)hipEventRecord(ev_full_, full_stream_);
         }
         tick("ambi_finish_kernel", s, 5, true, sb);
@@ -1178,7 +1233,7 @@ class HipBackend : public Backend {
             int64_t total = 0;
             for (int s = 0; s < n_slices_; s++) {
                 slice_base_[s] = total;
-                slice_bytes_[s] = (h_needed_[s] + (h_needed_[s] >> 4) + 4096 + 15) & ~int64_t(15);
+                slice_bytes_[s] = (h_needed_[s] + (h_needed_[s] >> 4) + 4096 + order_align_ - 1) & ~int64_t(order_align_ - 1);
                 total += slice_bytes_[s];
             }
             if (total > arena_bytes_) {
@@ -1193,7 +1248,7 @@ class HipBackend : public Backend {
                     (void)hipGetLastError();
                     fprintf(stderr, "ambigram_hip: order-table arena of %lld bytes not available; keeping %lld bytes (units beyond it report ORDERS_CAPACITY)\n",
                             (long long)total, (long long)arena_bytes_);
-                    for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(15); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(15); }
+                    for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(order_align_ - 1); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(order_align_ - 1); }
                 }
                 bind(flags);
             }
@@ -1316,7 +1371,14 @@ class HipBackend : public Backend {
                         if (!best_k || rounds < best) { best_k = k; best = rounds; }
                     }
                     if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: image need %d bytes, %lld work blocks on %d CUs -> %d workgroups per CU\n", need, (long long)W, ncu, best_k);
-                    if (best_k) { block_lds_ = ((160 * 1024) / best_k) & ~15; lds_blocks_ = block_lds_; }
+                    // ... and ask for no more than the images need (512-byte granules): what the k enumerate workgroups leave of
+                    // the CU's group memory is where the scan / finish workgroups run WITHOUT pushing an enumerate workgroup out
+                    if (best_k) {
+                        block_lds_ = ((160 * 1024) / best_k) & ~15;
+                        const int tight = (need + 511) & ~511;
+                        if (emit_lds_tight_ && tight < block_lds_) block_lds_ = tight;
+                        lds_blocks_ = block_lds_;
+                    }
                 }
             }
         }

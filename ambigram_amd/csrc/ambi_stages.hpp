@@ -216,6 +216,11 @@ AMBI_HD int prep_lattice(const G& g, const BatchArgs& A, int u, const uint64_t* 
     if (*R_out >= kCountSat) return ST_ERR_ORDERS_CAPACITY;   // no table of 2^62 rows: decided here, not by the plan kernel
     return ST_OK;
 }
+// UnitOut::order_off before the plan stage has given the unit rows: the prepare stage says whether the unit WANTS a table
+// (its status is ST_OK when the stage ends), the plan stage answers with an offset or with "no room".  The plan stage reads
+// and writes this word only -- not the status, which the scan for the first valid order rewrites -- so that the scan can
+// run beside it (the plan kernel is one workgroup: the chip is otherwise idle for its 25 us).
+constexpr int64_t kOrderOffWanted = -1, kOrderOffNoRoom = -2, kOrderOffNone = -3;
 AMBI_HD void prep_header(UnitOut* out, int status, int bias, int K, uint64_t R, double inv_sum) {
     out->status = status;
     out->bias = bias;
@@ -224,7 +229,7 @@ AMBI_HD void prep_header(UnitOut* out, int status, int bias, int K, uint64_t R, 
     out->first_forward = -1; out->evaluated = 0; out->path_ind_stored = 0; out->reserved = 0;
     out->num_orders = (int64_t)R;
     out->first_valid = -1;
-    out->order_off = -1;
+    out->order_off = status == ST_OK ? kOrderOffWanted : kOrderOffNone;
     out->inv_cn_sum = inv_sum;
 }
 
@@ -272,7 +277,7 @@ AMBI_HD void stage_lattice(const G& g, const BatchArgs& A, int u, uint8_t* work 
     const int st = prep_lattice(g, A, u, pred, out->K, work + 64 * 8, &R);
     if (g.tid() == 0) {
         out->num_orders = (int64_t)R;
-        if (st != ST_OK) out->status = st;   // as the one-piece prepare stage reports it (a path the express stage may have written is void then)
+        if (st != ST_OK) { out->status = st; out->order_off = kOrderOffNone; }   // as the one-piece prepare stage reports it (a path the express stage may have written is void then)
     }
     g.sync();
 }
@@ -289,14 +294,15 @@ AMBI_HD int rows_per_lane_for(int64_t total_rows, int target_lanes) {
     if (t > 1024) t = 1024;
     return (int)t;
 }
-AMBI_HD int64_t order_bytes(int64_t R, int K) { return (R * row_stride(K) + 15) & ~int64_t(15); }
+// bytes a unit's table takes of the arena: its rows, rounded up to `align` (a power of two >= 16) so that the next table starts aligned
+AMBI_HD int64_t order_bytes(int64_t R, int K, int64_t align = 16) { return (R * row_stride(K) + align - 1) & ~(align - 1); }
 
 // serial reference form of the plan kernel (host simulation)
 AMBI_HD void plan_serial(const BatchArgs& A) {
     int64_t total_rows = 0;
     for (int i = 0; i < A.n_units; i++) {
         const UnitOut* out = unit_out(A.results, A.unit_base + i);
-        if (out->status == ST_OK && out->num_orders < (int64_t)kCountSat) total_rows += out->num_orders;
+        if (out->order_off == kOrderOffWanted && out->num_orders < (int64_t)kCountSat) total_rows += out->num_orders;
     }
     const int T = rows_per_lane_for(total_rows, A.target_lanes);
     int64_t off = 0, blk = 0;   // off: relative to the slice's arena region
@@ -305,13 +311,13 @@ AMBI_HD void plan_serial(const BatchArgs& A) {
         UnitOut* out = unit_out(A.results, u);
         A.blk_off[i] = blk;
         A.rows_per_lane[u] = T;
-        if (out->status != ST_OK) continue;
+        if (out->order_off != kOrderOffWanted) continue;
         const int K = out->K;
         const int64_t R = out->num_orders;
-        if (R >= (int64_t)kCountSat) { out->status = ST_ERR_ORDERS_CAPACITY; continue; }
-        const int64_t bytes = order_bytes(R, K);
+        if (R >= (int64_t)kCountSat) { out->order_off = kOrderOffNoRoom; continue; }
+        const int64_t bytes = order_bytes(R, K, A.order_align);
         // plain prefix sum: a unit that does not fit still advances the offset (so orders_needed is the true total)
-        if (off + bytes > A.order_arena_bytes) { out->status = ST_ERR_ORDERS_CAPACITY; off += bytes; continue; }
+        if (off + bytes > A.order_arena_bytes) { out->order_off = kOrderOffNoRoom; off += bytes; continue; }
         out->order_off = A.arena_base + off;
         off += bytes;
         blk += (R + 256ll * T - 1) / (256ll * T);   // one work block = 256*T rows = one workgroup (4 waves x 64*T)
@@ -754,9 +760,21 @@ AMBI_HD FinishWork carve_finish(uint8_t* base, int n, int m, int bkp_cap, int pa
     return W;
 }
 
+// A unit the plan stage had no room for ends with ORDERS_CAPACITY whatever the scan made of it (the scan may have run
+// beside the plan stage).  Every unit passes through a finish stage after both: this is where the verdict lands.
+template <class G>
+AMBI_HD bool plan_refused(const G& g, UnitOut* out) {
+    if (out->order_off != kOrderOffNoRoom) return false;
+    g.sync();
+    if (g.tid() == 0) out->status = ST_ERR_ORDERS_CAPACITY;
+    g.sync();
+    return true;
+}
+
 template <class G>
 AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     UnitOut* out = unit_out(A.results, u);
+    if (plan_refused(g, out)) return;
     const UnitIn U = A.units[u];
     const int n = U.n_seg, m = U.n_junc;
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
@@ -863,6 +881,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     int32_t* gpath = reinterpret_cast<int32_t*>(res + Lay.path);
     OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
     const int base = U.seg_base;
+    if (plan_refused(g, out)) return;
     const int status = out->status;
     if (out->reserved) return;                        // reconstructed by the express stage already
     if (U.direct_full && A.direct_full_on) return;   // taken by the full stage from the start (its kernel runs beside this one)

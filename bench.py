@@ -80,7 +80,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.slices > 0:
         os.environ["AMBI_SLICES"] = str(args.slices)
-    lib = api.load()                       # the HIP engine; raises if it has not been built (no CPU fallback)
+    # the HIP engine; raises if it has not been built (no CPU fallback).  AMBI_BENCH_LIB: another BUILD of the same engine
+    # library (profiles/tools/ab.sh compares two builds on one box with it)
+    lib = api.load(os.environ.get("AMBI_BENCH_LIB") or None)
+    if os.environ.get("AMBI_BENCH_LIB"): api._preload_hip_runtime()
     lib.ambi_set_device(local_rank)
 
     # ---- workload: B samples per rank, seeds as SURVEY.md 8d (seed = 1000*config + sample index) ----

@@ -62,7 +62,7 @@ class HostSimBackend : public Backend {
 
     void bind(uint32_t flags) {
         A_.n_units = (int32_t)units_.size(); A_.unit_base = 0; A_.arena_base = 0;   // one slice
-        A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
+        A_.flags = flags; A_.order_align = 16; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         { const char* envm = getenv("AMBI_BLOCK_MAX"); int bm = envm ? atoi(envm) : cfg_.block_max;   // as HipBackend::upload
           if (bm < 1) bm = 1; if (bm > kBlockMaxLimit) bm = kBlockMaxLimit; A_.block_max = bm; }
         A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
@@ -115,6 +115,7 @@ class HostSimBackend : public Backend {
                 fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, block_max, bscratch.data(), (int64_t)bscratch.size(),
                                          image.data(), block_lds, H);
                 dfs = false;
+                if (getenv("AMBI_HOSTSIM_TRACE")) { BuildTables d2; fprintf(stderr, "hostsim: unit %d K=%d R=%lld nI=%d nC=%d nB=%d suf_words=%d image_bytes=%d scratch=%lld\n", u, K, (long long)R, H.nI, H.nC, H.nB, H.suf_words, H.image_bytes, (long long)carve_build_tables(bscratch.data(), H.nI, H.nC, d2)); }
                 if (!fast) {   // ambi_blocks_build_kernel's second form: tables + suffix rows, walked at emission
                     BuildTables dummy;
                     const int64_t scr = carve_build_tables(bscratch.data(), tbl.counter[0], tbl.counter[1], dummy);
@@ -212,7 +213,7 @@ class HostSimBackend : public Backend {
             if (express)   // the lattice stage does not rewrite the header: take back what the plan pass decided against the small arena
                 for (int u = 0; u < Un; u++) {
                     UnitOut* o = unit_out(A_.results, u);
-                    if (o->status == ST_ERR_ORDERS_CAPACITY && o->num_orders < (int64_t)kCountSat) { o->status = ST_OK; o->order_off = -1; }
+                    if (o->order_off == kOrderOffNoRoom && o->num_orders < (int64_t)kCountSat) o->order_off = kOrderOffWanted;
                 }
         }
         enumerate_all();
