@@ -963,8 +963,10 @@ class HipBackend : public Backend {
         { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? atoi(e9) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
-            // the scan / finish kernels fill the gaps the enumerate kernel leaves: lowest dispatch priority (AMBI_BACK_PRIORITY=0: default)
-            { const char* e8 = getenv("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : true;
+            // the stream of the lean finish kernel: default dispatch priority (AMBI_BACK_PRIORITY=1: lowest, round 1's setting
+            // -- with the scan out of the way early the finish kernels have the whole enumerate kernel to hide behind, and
+            // holding them back only lengthens the tail after it: 1.185 -> 1.168 ms per step, four interleaved runs)
+            { const char* e8 = getenv("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : false;
               int least = 0, greatest = 0;
               if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
                   HIP_CK(hipStreamCreateWithPriority(&back_stream_, hipStreamNonBlocking, least));
@@ -992,7 +994,8 @@ class HipBackend : public Backend {
                     if ((rc = dalloc(&d_direct_list_, dl.size()))) return rc;
                     HIP_CK(hipMemcpy(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
                     int least = 0, greatest = 0;
-                    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&full_stream_, hipStreamNonBlocking, least)); }
+                    const char* e9 = getenv("AMBI_FULL_PRIORITY"); const bool low_full = e9 ? atoi(e9) != 0 : true;   // the direct full-finish stream: lowest priority
+                    if (low_full && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&full_stream_, hipStreamNonBlocking, least)); }
                     else HIP_CK(hipStreamCreateWithFlags(&full_stream_, hipStreamNonBlocking));
                 }
             }

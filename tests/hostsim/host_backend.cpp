@@ -62,7 +62,7 @@ class HostSimBackend : public Backend {
 
     void bind(uint32_t flags) {
         A_.n_units = (int32_t)units_.size(); A_.unit_base = 0; A_.arena_base = 0;   // one slice
-        A_.flags = flags; A_.order_align = 16; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
+        A_.flags = flags; A_.order_align = 4096 /* as HipBackend's default */; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         { const char* envm = getenv("AMBI_BLOCK_MAX"); int bm = envm ? atoi(envm) : cfg_.block_max;   // as HipBackend::upload
           if (bm < 1) bm = 1; if (bm > kBlockMaxLimit) bm = kBlockMaxLimit; A_.block_max = bm; }
         A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
