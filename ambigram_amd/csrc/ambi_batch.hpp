@@ -149,6 +149,8 @@ struct BatchArgs {
     int32_t* express_seq;        // pinned host int: the express kernel's last workgroup stores run_seq here (the host spins on it)
     int32_t run_seq;
     int32_t* express_left;       // pinned host int: set to 1 by the express kernel when a unit is left to the ordinary scan / finish kernels
+    int32_t finish_retry;        // 1 (a full-stage launch whose path area, finish_path_cells, is smaller than the units' capacities): a path that
+                                 // does not fit the area is handed to the list kernel behind (refin_list), which has the full area
     int32_t direct_full_on;      // 1: units with UnitIn::direct_full are served by a full-stage launch of their own (the lean stage skips them)
     int32_t* refin_count;        // [1] entries of refin_list; zeroed before the lean kernel, read by the full-stage kernel behind it
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)

@@ -736,6 +736,7 @@ class HipBackend : public Backend {
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr, ev_first_ = nullptr, ev_full_ = nullptr;
     hipStream_t full_stream_ = nullptr;
     bool first_launched_ = false; hipEvent_t ev_plan_ = nullptr;
+    int direct_cells_ = 0; bool direct_retry_ = false;   // path area of the direct full-finish launch (0: the batch's capacity bound); env AMBI_DIRECT_CELLS
     int full_threads_ = 1024;  // env AMBI_FULL_THREADS: threads per workgroup of the direct full-finish launch (256 / 512 / 1024)
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
@@ -1046,7 +1047,7 @@ class HipBackend : public Backend {
         A_.blk_off = d_blk_off_; A_.rows_per_lane = d_rows_; A_.n_pending = d_npending_; A_.orders_needed = d_needed_;
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
-        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0;
+        A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = getenv("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
     }
     BatchArgs slice_args(int s) const {
@@ -1199,7 +1200,16 @@ class HipBackend : public Backend {
         if (direct_n_ > 0 && overlap_back_ && full_stream_) {
             (void)hipStreamWaitEvent(full_stream_, ev_first_, 0);
             const int dgrid = direct_n_ < direct_grid_ ? direct_n_ : direct_grid_;
-            hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(full_threads_), lds_finish_, full_stream_, A, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
+            // path area of this launch: the capacity bound of the batch, or (experiment switch AMBI_DIRECT_CELLS, see wait())
+            // fewer cells -- a path that does not fit then goes through the list kernel behind, which has the full area
+            BatchArgs Ad = A;
+            int lds_direct = lds_finish_;
+            if (direct_cells_ > 0 && direct_cells_ < finish_path_cells_) {
+                Ad.finish_path_cells = direct_cells_; Ad.finish_retry = 1;
+                lds_direct = (int)finish_work_bytes(hb_.max_n, hb_.max_m, hb_.max_bkp, direct_cells_, hb_.max_out);
+            }
+            direct_retry_ = Ad.finish_retry != 0;
+            hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(full_threads_), lds_direct, full_stream_, Ad, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
             (void)hipEventRecord(ev_full_, full_stream_);
         }
         tick("ambi_finish_kernel", s, 5, true, sb);
@@ -1209,7 +1219,10 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
             // device (an empty list costs one launch of workgroups that exit at once)
-            if (hb_.any_sv) hipLaunchKernelGGL(ambi_finish_kernel, dim3(U < 1024 ? U : 1024), dim3(256), lds_finish_, sb, A, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_, -1);
+            if (hb_.any_sv) {
+                if (direct_retry_ && direct_n_ > 0 && overlap_back_ && full_stream_) (void)hipStreamWaitEvent(sb, ev_full_, 0);   // the direct launch may add to the list
+                hipLaunchKernelGGL(ambi_finish_kernel, dim3(U < 256 ? U : 256), dim3(256), lds_finish_, sb, A, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_, -1);   // (at most one such workgroup fits a CU: more than 256 gain nothing)
+            }
         } else hipLaunchKernelGGL(ambi_finish_kernel, dim3(U), dim3(256), lds_finish_, sb, A, (const int32_t*)nullptr, (const int32_t*)nullptr, -1);
         tick("ambi_finish_kernel", s, 5, false, sb);
         if (overlap_back_) {
@@ -1347,6 +1360,23 @@ class HipBackend : public Backend {
             HIP_CK(hipMemcpy(fb.data(), d_fallback_, fb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
             general_path_ = 0;
             for (int32_t f : fb) general_path_ += f != 0;
+            if (direct_n_ > 0) {
+                // Path area of the direct full-finish launch.  Default: the capacity bound of the batch (82 KB of group memory
+                // per workgroup on the bench batch, one per CU).  AMBI_DIRECT_CELLS=n: n cells, -1: what the paths of these
+                // units needed in this first run plus a quarter (53 KB there, three per CU; longer paths then go through the
+                // list kernel) -- measured SLOWER, 1.18 vs 1.155 ms per step: more of these 16-wave workgroups get onto the
+                // CUs while the table is being written and take the places of enumerate workgroups.
+                const char* e = getenv("AMBI_DIRECT_CELLS");
+                direct_cells_ = e ? atoi(e) : 0;
+                if (direct_cells_ < 0) {
+                    std::vector<UnitOut> hdr(hb_.units.size());
+                    HIP_CK(hipMemcpy(hdr.data(), d_results_, hdr.size() * sizeof(UnitOut), hipMemcpyDeviceToHost));
+                    int mx = 0;
+                    for (size_t u2 = 0; u2 < hdr.size(); u2++)
+                        if (hb_.units[u2].direct_full) { mx = std::max(mx, hdr[u2].path_len); mx = std::max(mx, hdr[u2].path_indel_len); }
+                    direct_cells_ = mx > 0 ? ((mx + mx / 4 + 256 + 2047) & ~2047) : 0;
+                }
+            }
             // ... and whether any unit's table is shared by several workgroups (only those go through the build kernel
             // when single-block units build their image in the enumerate workgroup): if none, later runs do not launch it
             if (n_slices_ == 1) {

@@ -812,13 +812,22 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
     }
     g.sync();
     AMBI_MARK(A, g, u, 17);
+    // a launch with a reduced path area (finish_retry): what does not fit it goes to the list kernel behind this one
+    const bool may_retry = A.finish_retry && A.refin_list && pcap < U.path_cap;
+    auto hand_over = [&]() {
+        g.sync();
+        if (g.tid() == 0) { out->status = ST_REFINISH; A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }
+        g.sync();
+    };
     int P = expand_bkp(g, W.bkp, L, W.path, pcap, W.offs, gpath, base);
+    if (P == ST_ERR_PATH_CAPACITY && may_retry) { hand_over(); return; }
     if (P < 0) { if (g.tid() == 0) out->status = P; g.sync(); return; }
     int P2 = P;
     AMBI_MARK(A, g, u, 18);
     IndelScratch S{W.sv, W.taken, W.has_ext, A.scratch_i32 + A.scratch_off[u], W.first, W.last};
     bool edited = false;
     int printed = indel_bfb(g, n, W.ends, m, W.path, &P2, pcap, S, &edited);
+    if (printed == ST_ERR_PATH_CAPACITY && may_retry) { hand_over(); return; }
     if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
     AMBI_MARK(A, g, u, 19);
     // the edited path is materialised only when indelBFB changed something; otherwise readers take `path`

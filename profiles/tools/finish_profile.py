@@ -8,9 +8,10 @@ import torch
 from ambigram_amd import api, synth
 lib = api.load(); lib.ambi_set_device(0); torch.cuda.set_device(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+lean = len(sys.argv) > 2 and sys.argv[2] == "lean"     # units without SVs: the lean finish stage
 tmp = tempfile.mkdtemp(); b = api.Batch(lib); keep = []
 for i in range(n):
-    s = synth.make_sample(256, 512, "wide", 19, seed=2000 + 8 * i + 7, n_del=2, n_dup=1)
+    s = synth.make_sample(256, 512, "wide", 19, seed=2000 + 8 * i + 7, n_del=0 if lean else 2, n_dup=0 if lean else 1)
     lh, sols = s.write(tmp, "s%d" % i)
     g = api.Graph(lib, lh); keep.append(g); b.add_chromosome_sol(g, 0, sols[0])
 b.upload(); st = torch.cuda.current_stream().cuda_stream

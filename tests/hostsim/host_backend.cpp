@@ -77,7 +77,7 @@ class HostSimBackend : public Backend {
         A_.n_pending = &n_pending_; A_.orders_needed = &orders_needed_;
         A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
         refin_list_.assign(units_.size() + 1, 0); refin_count_ = 0;
-        A_.refin_list = refin_list_.data(); A_.refin_count = &refin_count_; A_.direct_full_on = 0;
+        A_.refin_list = refin_list_.data(); A_.refin_count = &refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
         A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
         A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
     }

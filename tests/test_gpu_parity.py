@@ -332,3 +332,50 @@ def test_express_path_equals_kernel_chain(hip_lib, oracle, workdir, monkeypatch)
         for u, (x, y) in enumerate(zip(a, c)):
             x.pop("reserved", None); y.pop("reserved", None)
             assert x == y, (flags, u, items[u][0])
+
+
+@pytest.mark.gpu
+def test_direct_full_finish_with_a_small_path_area(hip_lib, oracle, workdir, monkeypatch):
+    """Units with deletion / duplication candidates get a full-stage launch of their own.  Its path area can be made smaller
+    than the capacity bound of the batch (AMBI_DIRECT_CELLS: n cells, -1: sized from the paths of the batch's first run); a
+    path that does not fit then goes through the list kernel behind it, which has the full area.  Forced here with areas
+    far too small and just too small for the paths: same results as the launch with the whole area and as the run without
+    the direct launch."""
+    from ambigram_amd import synth
+    items = []
+    for i in range(48):   # more than the express path takes
+        s = synth.make_sample(96, 192, "wide" if i % 3 else "chain", 9, seed=9100 + i, n_del=2 if i % 2 else 0, n_dup=1 if i % 4 == 1 else 0)
+        lh, sols = s.write(workdir, "dfa%d" % i)
+        items.append((lh, sols[0]))
+
+    def run(cells, direct="1", flags=0):
+        monkeypatch.setenv("AMBI_DIRECT_FULL", direct)
+        if cells is None: monkeypatch.delenv("AMBI_DIRECT_CELLS", raising=False)
+        else: monkeypatch.setenv("AMBI_DIRECT_CELLS", str(cells))
+        graphs, b = [], api.Batch(hip_lib)
+        for lh, sol in items:
+            g = api.Graph(hip_lib, lh); graphs.append(g)
+            b.add_chromosome_sol(g, 0, sol)
+        b.upload()
+        out = []
+        for rep in range(3):                    # run 1 sizes the arena, run 2 the path area, run 3 uses it
+            b.run(flags); b.wait()
+        b.download()
+        for u in range(len(items)):
+            r = dict(b.unit_result(u))
+            if r["status"] == 0:
+                r["path"] = b.unit_path(u, 0).tolist(); r["path_indel"] = b.unit_path(u, 1).tolist(); r["out"] = b.unit_out_juncs(u)
+            out.append(r)
+        b.close()
+        for g in graphs:
+            g.close()
+        return out
+
+    for flags in (0, api.FLAG_REVERSED):
+        ref = run(None, direct="0", flags=flags)
+        assert sum(1 for r in ref if r["status"] == 0 and r["path"] != r["path_indel"]) >= 3, "the batch has no path-editing units"
+        longest = max(len(r["path"]) for r in ref if r["status"] == 0)
+        for cells in (None, -1, 64, longest - 8, longest + 8):
+            got = run(cells, flags=flags)
+            for u, (x, y) in enumerate(zip(got, ref)):
+                assert x == y, (flags, cells, u, items[u][0])
