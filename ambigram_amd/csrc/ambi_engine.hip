@@ -364,18 +364,7 @@ __global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A
         const int64_t wlo = blo + (int64_t)wave * per;
         int64_t whi = wlo + per;
         if (whi > bhi) whi = bhi;
-        if (!dfs && A.emit_interleave == 2) {   // TIMING EXPERIMENT (wrong bytes): flat 1 KB pieces, no block logic
-            const int64_t nvec = (R * row_stride(K)) >> 4;
-            uint4* o4 = reinterpret_cast<uint4*>(A.order_arena + out->order_off);
-            for (int64_t p = wave; p * 64 < nvec; p += nwave) {
-                const int64_t idx = p * 64 + lane;
-                if (idx < nvec) {
-                    const uint32_t rel = (uint32_t)(idx * 4) & 2047u, k = rel % 5u;
-                    uint4 v; v.x = image[rel] | image[k]; v.y = image[rel + 1] | image[k + 1]; v.z = image[rel + 2] | image[k + 2]; v.w = image[rel + 3] | image[k + 3];
-                    o4[idx] = v;
-                }
-            }
-        } else if (!dfs && A.emit_interleave) {   // the blocks of the whole work block dealt round-robin to the waves
+        if (!dfs && A.emit_interleave) {   // the blocks of the whole work block dealt round-robin to the waves
             if (blo < bhi)
                 emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)blo, (uint32_t)bhi, A.order_arena + out->order_off, lane, lane + 1, wave, nwave);
         } else if (wlo < whi) {
@@ -961,7 +950,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
         { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e9 = getenv("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
-        { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? atoi(e9) : 1; }
+        { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         if (want_overlap_ && n_slices_ == 1) {
             // the stream of the lean finish kernel: default dispatch priority (AMBI_BACK_PRIORITY=1: lowest, round 1's setting
