@@ -1243,14 +1243,17 @@ class HipBackend : public Backend {
             }
             if (total > arena_bytes_) {
                 // the new arena first, the old one goes only when that worked: a failed growth leaves the batch as it was,
-                // and the units whose tables do not fit the old arena end with ORDERS_CAPACITY (plan kernel), one by one
+                // and the units whose tables do not fit the old arena end with ORDERS_CAPACITY (plan kernel), one by one.
+                // AMBI_ARENA_MAX_BYTES: an upper limit for the arena (a memory budget; the tests use it to reach this path)
+                int64_t want = total;
+                { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }
                 uint8_t* fresh = nullptr;
-                if (hipMalloc((void**)&fresh, (size_t)total) == hipSuccess) {
+                if (want > arena_bytes_ && hipMalloc((void**)&fresh, (size_t)want) == hipSuccess) {
                     (void)hipFree(d_arena_);
                     d_arena_ = fresh;
-                    arena_bytes_ = total;
-                } else {
-                    (void)hipGetLastError();
+                    arena_bytes_ = want;
+                } else if (want > arena_bytes_) (void)hipGetLastError();
+                if (arena_bytes_ < total) {
                     fprintf(stderr, "ambigram_hip: order-table arena of %lld bytes not available; keeping %lld bytes (units beyond it report ORDERS_CAPACITY)\n",
                             (long long)total, (long long)arena_bytes_);
                     for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(order_align_ - 1); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(order_align_ - 1); }

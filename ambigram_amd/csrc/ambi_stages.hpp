@@ -766,7 +766,11 @@ template <class G>
 AMBI_HD bool plan_refused(const G& g, UnitOut* out) {
     if (out->order_off != kOrderOffNoRoom) return false;
     g.sync();
-    if (g.tid() == 0) out->status = ST_ERR_ORDERS_CAPACITY;
+    if (g.tid() == 0) {   // ... and nothing of what the scan (or the express stage) found stays in the header
+        out->status = ST_ERR_ORDERS_CAPACITY;
+        out->bkp_len = 0; out->path_len = 0; out->path_indel_len = 0; out->indel_printed = 0; out->n_out_junc = 0;
+        out->first_forward = -1; out->evaluated = 0; out->path_ind_stored = 0; out->first_valid = -1;
+    }
     g.sync();
     return true;
 }

@@ -501,3 +501,67 @@ def check_all_two_forms(lib, workdir, seeds=range(300, 420)):
         for u, (x, y) in enumerate(zip(a, c)):
             assert x == y, (rev, u, items[u][0], x[:2], y[:2])
     assert sum(1 for x in got[("1", 0)] if x[0] == 0 and len(x[2]) > 1) >= 2
+
+
+def check_arena_limit(lib, workdir, n_units=40, budget=3, seeds=range(9300, 9340)):
+    """The order-table arena has an upper limit (AMBI_ARENA_MAX_BYTES): the plan stage gives rows to the units that fit, in
+    unit order, and the others end with ORDERS_CAPACITY (-15) -- whatever the scan for the first valid order, which may run
+    BESIDE the plan stage, made of them.  Units that got their rows are exactly what they are without the limit; runs are
+    repeatable; the same batch without the limit reconstructs every unit."""
+    import os
+    from ambigram_amd import synth
+    items = []
+    for i, seed in zip(range(n_units), seeds):
+        s = synth.make_sample(48, 100, ("chain", "wide", "mixed")[i % 3], 9 + 2 * (i % 3), seed=seed, imperfect=i % 2, n_del=(i % 5 == 4) * 2, n_dup=(i % 7 == 6) * 1)
+        lh, sols = s.write(workdir, "al%d_%d" % (n_units, i))
+        items.append((lh, sols[0]))
+
+    def run(cap):
+        os.environ.pop("AMBI_ARENA_MAX_BYTES", None)
+        if cap:
+            os.environ["AMBI_ARENA_MAX_BYTES"] = str(cap)
+        try:
+            graphs, b = [], api.Batch(lib)
+            b.configure(order_arena_bytes=4096, first_budget=budget)
+            for lh, sol in items:
+                g = api.Graph(lib, lh); graphs.append(g)
+                b.add_chromosome_sol(g, 0, sol)
+            b.upload()
+            outs = []
+            for flags in (0, 0, api.FLAG_REVERSED):
+                b.run(flags); b.wait(); b.download()
+                out = []
+                for u in range(len(items)):
+                    r = dict(b.unit_result(u))
+                    if r["status"] == 0:
+                        r["path"] = b.unit_path(u, 0).tolist(); r["path_indel"] = b.unit_path(u, 1).tolist(); r["out"] = b.unit_out_juncs(u)
+                        r["orders"] = b.unit_orders(u, 0, min(r["num_orders"], 200), r["n_nodes"]).tolist()
+                    out.append(r)
+                outs.append(out)
+            b.close()
+            for g in graphs:
+                g.close()
+            return outs
+        finally:
+            os.environ.pop("AMBI_ARENA_MAX_BYTES", None)
+
+    free = run(None)
+    assert all(r["status"] != -15 for out in free for r in out)
+    with_rows = [u for u, r in enumerate(free[0]) if r["status"] == 0 and r["num_orders"] > 0]
+    assert len(with_rows) >= n_units // 2
+    cap = 4096 * (len(with_rows) // 2)                      # every table of these small units is one 4 KB granule
+    lim = run(cap)
+    for u, (x, y) in enumerate(zip(lim[0], lim[1])):
+        assert x == y, ("two runs of the limited batch differ", u, {k: (x.get(k), y.get(k)) for k in set(x) | set(y) if x.get(k) != y.get(k)})
+    n_refused = 0
+    for flags_i in (0, 2):
+        refused = [u for u, r in enumerate(lim[flags_i]) if r["status"] == -15]
+        wanted = [u for u, r in enumerate(free[flags_i]) if r["num_orders"] > 0 and free[flags_i][u]["status"] not in (1, 2)]
+        assert refused and len(refused) < len(wanted), (cap, refused)
+        assert refused == [u for u in wanted if u >= refused[0]], (refused, wanted)   # unit order: the tail of the units with rows
+        for u, (x, y) in enumerate(zip(lim[flags_i], free[flags_i])):
+            if u in refused:
+                continue
+            assert x == y, (flags_i, u, items[u][0])
+        n_refused = len(refused)
+    return n_refused

@@ -208,12 +208,15 @@ class HostSimBackend : public Backend {
             }
             plan_serial(A_);
             if (orders_needed_ <= (int64_t)arena_.size()) break;
-            arena_.assign((size_t)orders_needed_, 0);   // grow the arena and redo (first run only)
+            int64_t want = orders_needed_;
+            { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }   // as HipBackend::run
+            if (want <= (int64_t)arena_.size()) break;   // cannot grow further: the units beyond it end with ORDERS_CAPACITY
+            arena_.assign((size_t)want, 0);              // grow the arena and redo (first run only)
             bind(flags);
             if (express)   // the lattice stage does not rewrite the header: take back what the plan pass decided against the small arena
                 for (int u = 0; u < Un; u++) {
                     UnitOut* o = unit_out(A_.results, u);
-                    if (o->order_off == kOrderOffNoRoom && o->num_orders < (int64_t)kCountSat) o->order_off = kOrderOffWanted;
+                    if (o->order_off != kOrderOffNone && o->num_orders < (int64_t)kCountSat) o->order_off = kOrderOffWanted;   // offsets and refusals alike
                 }
         }
         enumerate_all();

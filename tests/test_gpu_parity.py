@@ -174,6 +174,13 @@ def test_all_mode_two_forms(hip_lib, workdir):
     ec.check_all_two_forms(hip_lib, workdir)
 
 
+def test_arena_limit_refuses_the_units_beyond_it(hip_lib, workdir):
+    """ORDERS_CAPACITY with the scan for the first valid order running beside the plan kernel (ordinary chain, 40 units) and
+    through the express chain (6 units)."""
+    assert ec.check_arena_limit(hip_lib, workdir, n_units=40) > 0
+    assert ec.check_arena_limit(hip_lib, workdir, n_units=6, seeds=range(9400, 9406)) > 0
+
+
 def test_mixed_batch(hip_lib, oracle, workdir):
     ec.check_mixed_batch(hip_lib, oracle, workdir, big=True)
 

@@ -63,6 +63,12 @@ def test_mixed_batch(hostsim_lib, oracle, workdir):
     ec.check_mixed_batch(hostsim_lib, oracle, workdir)
 
 
+def test_arena_limit_refuses_the_units_beyond_it(hostsim_lib, workdir):
+    """ORDERS_CAPACITY: ordinary chain (40 units) and express chain (6 units)."""
+    assert ec.check_arena_limit(hostsim_lib, workdir, n_units=40) > 0
+    assert ec.check_arena_limit(hostsim_lib, workdir, n_units=6, seeds=range(9400, 9406)) > 0
+
+
 def test_full_finish_stage_on_every_unit(hostsim_lib, oracle, workdir, monkeypatch):
     """By default the lean finish stage takes every unit and the full one only those it hands over; here the full stage
     (path cells in group memory, edits in place) runs on every unit, as it does when SVs chain or edit the path."""
