@@ -158,6 +158,7 @@ class HostSimBackend : public Backend {
         for (size_t u = 0; u < units_.size(); u++) {
             UnitOut* out = unit_out(A_.results, (int)u);
             if (out->status != ST_PENDING) continue;
+            if (out->order_off < 0) continue;   // no table to search (the plan stage had no room): the finish stage behind turns this into ORDERS_CAPACITY, as on the device, where the finish kernels run before the search
             const UnitIn& U = units_[u];
             std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
             FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);

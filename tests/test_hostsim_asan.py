@@ -27,6 +27,8 @@ with tempfile.TemporaryDirectory() as d:
     ec.check_injected_validity(lib, oracle_py, d)                 # parallel search stages, --all bitmaps with mixed verdicts
     ec.check_all_two_forms(lib, d, seeds=range(300, 330))         # one thread per order vs one wavefront per order
     ec.check_mixed_batch(lib, oracle_py, d)                       # > 32 units: ordinary chain; the runs above: express path
+    ec.check_arena_limit(lib, d, n_units=40)                      # units the plan stage has no room for
+    ec.check_arena_limit(lib, d, n_units=6, seeds=range(9400, 9406))
 print("SANITIZED RUN CLEAN")
 """
 
