@@ -34,7 +34,9 @@ extern "C" {
 #define AMBI_ERR_REF_UB (-12)     /* the reference reads out of bounds on this input; refused instead of guessed */
 #define AMBI_ERR_BKP_CAPACITY (-13)
 #define AMBI_ERR_PATH_CAPACITY (-14)
-#define AMBI_ERR_ORDERS_CAPACITY (-15)
+#define AMBI_ERR_ORDERS_CAPACITY (-15)  /* the unit's order table does not fit the arena (it could not grow: out of memory, or the
+                                        * limit AMBI_ARENA_MAX_BYTES of the environment); units are given rows in unit order, the
+                                        * others end with this status and carry no results */
 #define AMBI_ERR_IDEALS_CAPACITY (-16)
 #define AMBI_ERR_BAD_INPUT (-17)
 #define AMBI_ERR_OUTJUNC_CAPACITY (-18)

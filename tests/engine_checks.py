@@ -565,3 +565,52 @@ def check_arena_limit(lib, workdir, n_units=40, budget=3, seeds=range(9300, 9340
             assert x == y, (flags_i, u, items[u][0])
         n_refused = len(refused)
     return n_refused
+
+
+def check_large_batch_of_pending_units(lib, oracle, workdir, seeds=range(20000, 20600), budget=1, runs=2):
+    """ONE batch of many random decompositions with a scan budget of one order: most of them have no valid order at all and
+    more orders than the budget, so their scan ends PENDING and the parallel search resolves them -- while, in the same
+    launch, the plan stage hands out rows beside the scan (they run on two streams and must not share a word: round 1 let
+    the plan stage read the status the scan rewrites).  Every unit equals its own oracle run: status, counts, the order
+    table, paths.  The batch is run twice (first run: arena sizing; second: the resident path)."""
+    units = []
+    for seed in seeds:
+        lh, sols = cases.random_decomposition(workdir, seed)
+        o = oracle.run_bfb(lh, sols, keep_orders=True)
+        assert o["ok"], o["err"]
+        oc = o["chr"][0]
+        if oc["shortcut"]:
+            continue
+        units.append((seed, lh, sols[0], oc))
+    graphs, b = [], api.Batch(lib)
+    b.configure(first_budget=budget)
+    for _, lh, sol, _ in units:
+        g = api.Graph(lib, lh); graphs.append(g)
+        b.add_chromosome_sol(g, 0, sol)
+    b.upload()
+    stats = dict(units=len(units), none_pending=0, valid=0, refused=0)
+    for run in range(runs):
+        b.run(0); b.wait(); b.download()
+        for u, (seed, lh, sol, oc) in enumerate(units):
+            r = b.unit_result(u)
+            if oc["ub_valid"]:
+                assert r["status"] == -12, (run, seed, r)
+                stats["refused"] += run == 0
+                continue
+            assert r["num_orders"] == oc["num_orders"], (run, seed)
+            if 0 < oc["num_orders"] <= 5000:
+                assert b.unit_orders(u, 0, r["num_orders"], r["n_nodes"]).tolist() == oc["orders"], (run, seed)
+            if oc["first_valid"] < 0:
+                assert r["status"] == api.ST_NO_VALID_ORDER, (run, seed, r)
+                assert r["evaluated"] == oc["evaluated"], (run, seed, r["evaluated"], oc["evaluated"])
+                stats["none_pending"] += run == 0 and oc["num_orders"] > budget
+            else:
+                assert r["status"] == 0, (run, seed, r)
+                assert (r["first_valid"], r["first_forward"], r["evaluated"]) == (oc["first_valid"], oc["first_forward"], oc["evaluated"]), (run, seed)
+                assert b.unit_bkp(u).tolist() == oc["bkp"] and b.unit_path(u, 0).tolist() == oc["path"] and b.unit_path(u, 1).tolist() == oc["path_indel"], (run, seed)
+                stats["valid"] += run == 0
+    b.close()
+    for g in graphs:
+        g.close()
+    assert stats["none_pending"] >= len(units) // 3, stats
+    return stats

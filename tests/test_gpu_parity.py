@@ -174,6 +174,13 @@ def test_all_mode_two_forms(hip_lib, workdir):
     ec.check_all_two_forms(hip_lib, workdir)
 
 
+def test_large_batch_of_pending_units(hip_lib, oracle, workdir):
+    """~1500 units in one launch, scan budget 1: the plan kernel (one workgroup looping over the units) runs beside the
+    scan kernel, whose units end PENDING / NO_VALID_ORDER all the time."""
+    st = ec.check_large_batch_of_pending_units(hip_lib, oracle, workdir, seeds=range(20000, 21500))
+    assert st["units"] >= 1000 and st["none_pending"] >= 500, st
+
+
 def test_arena_limit_refuses_the_units_beyond_it(hip_lib, workdir):
     """ORDERS_CAPACITY with the scan for the first valid order running beside the plan kernel (ordinary chain, 40 units) and
     through the express chain (6 units)."""

@@ -63,6 +63,11 @@ def test_mixed_batch(hostsim_lib, oracle, workdir):
     ec.check_mixed_batch(hostsim_lib, oracle, workdir)
 
 
+def test_large_batch_of_pending_units(hostsim_lib, oracle, workdir):
+    st = ec.check_large_batch_of_pending_units(hostsim_lib, oracle, workdir, seeds=range(20000, 20150))
+    assert st["units"] >= 100
+
+
 def test_arena_limit_refuses_the_units_beyond_it(hostsim_lib, workdir):
     """ORDERS_CAPACITY: ordinary chain (40 units) and express chain (6 units)."""
     assert ec.check_arena_limit(hostsim_lib, workdir, n_units=40) > 0
