@@ -537,6 +537,16 @@ __global__ __launch_bounds__(1024) void ambi_finish_kernel(BatchArgs A, const in
     if (A.host_pending && !unit_list && blockIdx.x == 0 && threadIdx.x == 0) *A.host_pending = *A.n_pending;
     stage_finish(g, A, u, ambi_lds);
 }
+// The direct full-stage launch with the path cells in device memory (stage_finish<true>): entry i of the list works in
+// slot i of `cells` (stride bytes apart).
+__global__ __launch_bounds__(1024) void ambi_finish_ext_kernel(BatchArgs A, const int32_t* unit_list, int count, uint8_t* cells, int64_t stride) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
+        if (!unit_out(A.results, unit_list[i])->reserved) stage_finish<true>(g, A, unit_list[i], ambi_lds, reinterpret_cast<cell_t*>(cells + (int64_t)i * stride));
+        __syncthreads();
+    }
+}
 
 // Lean finish (ambi_stages.hpp: stage_finish_lean): every unit of the slice; units it cannot take are counted in
 // n_pending with status ST_REFINISH.  The last workgroup to finish reports n_pending to the host.
@@ -725,6 +735,7 @@ class HipBackend : public Backend {
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr, ev_first_ = nullptr, ev_full_ = nullptr;
     hipStream_t full_stream_ = nullptr;
     bool first_launched_ = false; hipEvent_t ev_plan_ = nullptr;
+    uint8_t* d_direct_cells_ = nullptr; int64_t direct_stride_ = 0; int lds_finish_ext_ = 0; bool direct_ext_ = true;   // env AMBI_DIRECT_EXT: the direct launch keeps its path cells in device memory
     int direct_cells_ = 0; bool direct_retry_ = false;   // path area of the direct full-finish launch (0: the batch's capacity bound); env AMBI_DIRECT_CELLS
     int full_threads_ = 1024;  // env AMBI_FULL_THREADS: threads per workgroup of the direct full-finish launch (256 / 512 / 1024)
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
@@ -761,14 +772,14 @@ class HipBackend : public Backend {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
-                        d_all_bits_, d_all_off_, d_all_count_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_};
+                        d_all_bits_, d_all_off_, d_all_count_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_, d_direct_cells_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
         d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
-        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr;
+        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr; d_direct_cells_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         if (h_express_left_) (void)hipHostFree(h_express_left_);
@@ -911,6 +922,7 @@ class HipBackend : public Backend {
         HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_ext_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
@@ -964,7 +976,11 @@ class HipBackend : public Backend {
                   HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
               } }
             { const char* e = getenv("AMBI_FIRST_AHEAD"); first_ahead_ = e ? atoi(e) : 3; }
-            { const char* e = getenv("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : 1024; if (full_threads_ != 256 && full_threads_ != 512) full_threads_ = 1024; }
+            // (direct full-stage launch: 512 threads with the path cells in device memory, 1024 with the cells in group memory --
+            // measured, four interleaved runs: cells in group memory 1.151 ms per step; in device memory 256 / 512 / 1024
+            // threads = 1.133 / 1.110 / 1.200)
+            { const char* ee = getenv("AMBI_DIRECT_EXT"); direct_ext_ = ee ? atoi(ee) != 0 : true; }
+            { const char* e = getenv("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : (direct_ext_ ? 512 : 1024); if (full_threads_ != 256 && full_threads_ != 512 && full_threads_ != 1024) full_threads_ = direct_ext_ ? 512 : 1024; }
             if (first_ahead_ >= 2) {
                 int least = 0, greatest = 0;
                 if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&first_stream_, hipStreamNonBlocking, greatest)); }
@@ -983,6 +999,11 @@ class HipBackend : public Backend {
                 if (direct_n_ > 0) {
                     if ((rc = dalloc(&d_direct_list_, dl.size()))) return rc;
                     HIP_CK(hipMemcpy(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    if (direct_ext_) {   // one path area per unit of the list in device memory
+                        direct_stride_ = (2ll * hb.max_path + 16 + 15) & ~int64_t(15);
+                        if ((rc = dalloc(&d_direct_cells_, (size_t)(direct_stride_ * (int64_t)dl.size())))) return rc;
+                        lds_finish_ext_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, 0, hb.max_out);
+                    }
                     int least = 0, greatest = 0;
                     const char* e9 = getenv("AMBI_FULL_PRIORITY"); const bool low_full = e9 ? atoi(e9) != 0 : true;   // the direct full-finish stream: lowest priority
                     if (low_full && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&full_stream_, hipStreamNonBlocking, least)); }
@@ -1198,6 +1219,10 @@ class HipBackend : public Backend {
                 lds_direct = (int)finish_work_bytes(hb_.max_n, hb_.max_m, hb_.max_bkp, direct_cells_, hb_.max_out);
             }
             direct_retry_ = Ad.finish_retry != 0;
+            if (direct_ext_ && d_direct_cells_) {   // path cells in device memory: a 13 KB workgroup that fits where a lean one fits
+                direct_retry_ = false;
+                hipLaunchKernelGGL(ambi_finish_ext_kernel, dim3(dgrid), dim3(full_threads_), lds_finish_ext_, full_stream_, A, (const int32_t*)d_direct_list_, direct_n_, d_direct_cells_, direct_stride_);
+            } else
             hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(full_threads_), lds_direct, full_stream_, Ad, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
             (void)hipEventRecord(ev_full_, full_stream_);
         }

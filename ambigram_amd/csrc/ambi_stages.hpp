@@ -775,8 +775,12 @@ AMBI_HD bool plan_refused(const G& g, UnitOut* out) {
     return true;
 }
 
-template <class G>
-AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+// EXT: the path cells live in `ext_path` (device memory of the caller: 2 * path_cap + 16 bytes, 16-byte aligned) instead of
+// group memory -- the work area then holds everything but the cells (13 KB for the bench unit instead of 82 KB), so that
+// the workgroup fits where a lean finish workgroup fits.  Same code, same results; the cells are reached through global
+// loads / stores that stay in the L2 of the workgroup's XCD (28 KB per unit).
+template <bool EXT = false, class G>
+AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, cell_t* ext_path = nullptr) {
     UnitOut* out = unit_out(A.results, u);
     if (plan_refused(g, out)) return;
     const UnitIn U = A.units[u];
@@ -805,8 +809,9 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work) 
         return;
     }
     if (status != ST_OK) return;
-    const int pcap = lds_path_cap(A, U.path_cap);
-    FinishWork W = carve_finish(work, n, m, U.bkp_cap, pcap, U.out_cap);
+    const int pcap = EXT ? U.path_cap : lds_path_cap(A, U.path_cap);
+    FinishWork W = carve_finish(work, n, m, U.bkp_cap, EXT ? 0 : pcap, U.out_cap);
+    if (EXT) W.path = ext_path;
     const int L = out->bkp_len;
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));

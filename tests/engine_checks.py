@@ -341,8 +341,9 @@ def check_mixed_batch(lib, oracle, workdir, big=False):
 
 def check_max_sizes(lib, oracle, workdir):
     """The engine's documented limits (DESIGN.md section 8): 63 DAG nodes per unit work, 64 are refused when the unit is added;
-    a path longer than the 65 536 cells the full finish stage holds in group memory is served by the lean stage (runs
-    only) -- unless its SVs edit the path, which is ST_ERR_PATH_CAPACITY."""
+    a path longer than the 65 536 cells the full finish stage can hold in group memory is served by the lean stage (runs
+    only); if its SVs edit the path, by the direct full-stage launch with the cells in device memory -- ST_ERR_PATH_CAPACITY
+    only where the group-memory form runs."""
     import pytest
     from ambigram_amd import synth
     for tier, K in (("chain", 63), ("skew", 63)):
@@ -373,7 +374,11 @@ def check_max_sizes(lib, oracle, workdir):
     b = api.Batch(lib)
     b.add_chromosome_sol(g, 0, sols[0])
     b.upload(); b.run(0); b.download()
-    assert b.unit_result(0)["status"] == -14
+    r = b.unit_result(0)
+    if r["status"] == 0:    # the direct full-stage launch keeps the path cells in device memory: no limit but the unit's own capacity
+        assert b.unit_path(0, 0).tolist() == o["path"] and b.unit_path(0, 1).tolist() == o["path_indel"]
+    else:                   # the form with the cells in group memory (AMBI_DIRECT_EXT=0, or a unit the lean stage handed over)
+        assert r["status"] == -14
     b.close(); g.close()
 
 

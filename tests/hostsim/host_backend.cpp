@@ -238,6 +238,17 @@ class HostSimBackend : public Backend {
             const UnitIn& U = units_[u];
             if (unit_out(A_.results, u)->reserved) continue;   // done by the express stage
             if (lean && unit_out(A_.results, u)->status != ST_REFINISH) continue;
+            // units with deletion / duplication candidates: the form with the path cells outside the work area (what the HIP
+            // backend's direct full-stage launch runs), in buffers of exactly its sizes; AMBI_HOSTSIM_EXT_PATH=0: the ordinary form
+            const char* ep = getenv("AMBI_HOSTSIM_EXT_PATH");
+            if (U.direct_full && !(ep && atoi(ep) == 0)) {
+                std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, 0, U.out_cap));
+                std::vector<cell_t> cells((size_t)U.path_cap + 8 + 8);   // 2 * path_cap + 16 bytes, aligned to 16 below
+                cell_t* base = cells.data();
+                while (reinterpret_cast<uintptr_t>(base) & 15) base++;
+                stage_finish<true>(g, A_, u, work.data(), base);
+                continue;
+            }
             std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, lds_path_cap(A_, U.path_cap), U.out_cap));
             stage_finish(g, A_, u, work.data());
         }
