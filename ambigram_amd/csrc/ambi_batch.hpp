@@ -62,10 +62,14 @@ struct UnitOut {
 //   target_cn i32  (n+1)
 //   inv_src   i16  (n+1)   inv_tgt i16 (n+1)   inv_junc i32 (n+1)
 //   bkp       i16  bkp_cap
-//   path      i32  path_cap      absolute signed ids (getBFB result)
-//   path_ind  i32  path_cap      after indelBFB
+//   path      i16  path_cap      LOCAL signed ids (getBFB result); absolute id = abs_cell(id, seg_base)
+//   path_ind  i16  path_cap      after indelBFB
 //   out_junc  OutJunc out_cap
 AMBI_HD int64_t pad8(int64_t b) { return (b + 7) & ~int64_t(7); }
+// A path cell of the result blob: the local signed segment id (2 bytes; round 1 stored absolute ids in 4 -- the paths are
+// 0.2 GB per step of the bench batch, written beside the store-bound enumerate kernel).  Readers add the unit's base.
+typedef int16_t rcell_t;
+AMBI_HD int32_t abs_cell(int v, int seg_base) { return v > 0 ? v + seg_base : v - seg_base; }
 struct UnitLayout {
     int64_t junc_cn, seg_cn, target_cn, inv_src, inv_tgt, inv_junc, bkp, path, path_ind, out_junc, total;
 };
@@ -79,8 +83,8 @@ AMBI_HD UnitLayout unit_layout(int n, int bkp_cap, int path_cap, int out_cap) {
     L.inv_tgt = o; o += pad8(int64_t(2) * (n + 1));
     L.inv_junc = o; o += pad8(int64_t(4) * (n + 1));
     L.bkp = o; o += pad8(int64_t(2) * bkp_cap);
-    L.path = o; o += pad8(int64_t(4) * path_cap);
-    L.path_ind = o; o += pad8(int64_t(4) * path_cap);
+    L.path = o; o += pad8(int64_t(sizeof(rcell_t)) * path_cap);
+    L.path_ind = o; o += pad8(int64_t(sizeof(rcell_t)) * path_cap);
     L.out_junc = o; o += pad8(int64_t(sizeof(OutJunc)) * out_cap);
     L.total = o;
     return L;

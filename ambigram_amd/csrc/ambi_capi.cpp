@@ -287,9 +287,9 @@ int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int
     const UnitIn& U = b->hb.units[unit];
     UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
     // the path after indelBFB is stored separately only when indelBFB changed it
-    const int32_t* src = reinterpret_cast<const int32_t*>(b->blob.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
+    const rcell_t* src = reinterpret_cast<const rcell_t*>(b->blob.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
     int len = which ? h->path_indel_len : h->path_len;
-    if (out) for (int i = 0; i < len && i < cap; i++) out[i] = src[i];
+    if (out) for (int i = 0; i < len && i < cap; i++) out[i] = abs_cell(src[i], U.seg_base);   // the blob holds local ids
     return len;
 }
 int ambi_batch_unit_bkp(const ambi_batch_t* b, int32_t unit, int32_t* out, int32_t cap) {

@@ -594,29 +594,29 @@ __global__ __launch_bounds__(256) void ambi_pack_copy_kernel(BatchArgs A, int wh
     const UnitIn& U = A.units[u];
     const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
     const bool stored = which && unit_out(A.results, u)->path_ind_stored;   // else the edited path equals `path`
-    const int32_t* src = reinterpret_cast<const int32_t*>(A.results + U.res_off + (stored ? L.path_ind : L.path));
+    const rcell_t* src = reinterpret_cast<const rcell_t*>(A.results + U.res_off + (stored ? L.path_ind : L.path));
     const int64_t off = pack_off[u], len = pack_off[u + 1] - off;
     for (int64_t i = threadIdx.x; i < len; i += blockDim.x)
-        if (off + i < cap) cells[off + i] = src[i];
+        if (off + i < cap) cells[off + i] = abs_cell(src[i], U.seg_base);
 }
 
 // ---- run-length form of the final paths (payload of the end-of-batch exchange) ----
 // A run starts where a cell is not its predecessor + 1.  One workgroup per unit, two passes over the path in the result
 // blob: count the runs (all units) -> offsets (one scan) -> write {start value, length}.
-__device__ inline const int32_t* unit_final_path(const BatchArgs& A, int u, int which, int* len) {
+__device__ inline const rcell_t* unit_final_path(const BatchArgs& A, int u, int which, int* len) {
     const UnitIn& U = A.units[u];
     const UnitOut* h = unit_out(A.results, u);
     const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
     const bool stored = which && h->path_ind_stored;   // else the edited path equals `path`
     *len = which ? h->path_indel_len : h->path_len;
-    return reinterpret_cast<const int32_t*>(A.results + U.res_off + (stored ? L.path_ind : L.path));
+    return reinterpret_cast<const rcell_t*>(A.results + U.res_off + (stored ? L.path_ind : L.path));
 }
 __global__ __launch_bounds__(256) void ambi_pack_runs_count_kernel(BatchArgs A, int which, int32_t* lengths, int32_t* run_counts) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int u = blockIdx.x;
     int P;
-    const int32_t* src = unit_final_path(A, u, which, &P);
+    const rcell_t* src = unit_final_path(A, u, which, &P);
     int mine = 0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) mine += (i == 0 || src[i] != src[i - 1] + 1) ? 1 : 0;
     const int total = g.sum_i32(mine);
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void ambi_pack_runs_write_kernel(BatchArgs A, 
     BlockGroup g(scratch);
     const int u = blockIdx.x;
     int P;
-    const int32_t* src = unit_final_path(A, u, which, &P);
+    const rcell_t* src = unit_final_path(A, u, which, &P);
     const int64_t off = run_off[u];
     const int n = (int)(run_off[u + 1] - off);
     if (off + n > cap) return;   // the caller's buffers are too small: nothing is written for this unit (totals tell)
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void ambi_pack_runs_write_kernel(BatchArgs A, 
         const int flag = (i < P && (i == 0 || src[i] != src[i - 1] + 1)) ? 1 : 0;
         int tot;
         const int ex = g.exscan_i32(flag, &tot);
-        if (flag) { run_start[off + done + ex] = src[i]; run_len[off + done + ex] = i; }
+        if (flag) { run_start[off + done + ex] = abs_cell(src[i], A.units[u].seg_base); run_len[off + done + ex] = i; }
         done += tot;
     }
     __syncthreads();

@@ -268,8 +268,8 @@ AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forwar
 
 // LGM.cpp:3661-3670: breakpoint pairs -> per-segment path (int16 local signed ids).  `offs` = scratch of
 // L/2+1 ints.  Returns P or a negative Status.
-template <class G>
-AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int pcap, int32_t* offs, int32_t* gpath = nullptr,
+template <class G, class GP = int16_t>
+AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int pcap, int32_t* offs, GP* gpath = nullptr,
                        int seg_base = 0) {
     int np = L / 2;
     int carry = 0;
@@ -300,7 +300,8 @@ AMBI_HD int expand_bkp(const G& g, const cell_t* bkp, int L, cell_t* path, int p
         for (int k = lane; k < len; k += lanes) {
             const int v = a + k;
             if (path) path[o0 + k] = (cell_t)v;
-            if (gpath) gpath[o0 + k] = v > 0 ? v + seg_base : v - seg_base;
+            // the result blob holds local ids in 2 bytes (readers add the base); 4-byte callers (--all paths) get absolute ids
+            if (gpath) gpath[o0 + k] = sizeof(GP) == 2 ? (GP)v : (GP)(v > 0 ? v + seg_base : v - seg_base);
         }
     }
     g.sync();

@@ -504,7 +504,7 @@ AMBI_HD int run_offsets(const G& g, const cell_t* bkp, int L, int32_t* offs) {
 // cells of every run to the result blob (absolute signed ids); with `first` != nullptr also the occurrence tables
 // (initialised by the caller) -- run-major, one sub-group (wavefront) per run as in expand_bkp
 template <class G>
-AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* offs, int32_t* gpath, int seg_base, int n,
+AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* offs, int16_t* gpath, int seg_base, int n,
                          int32_t* first, int32_t* last) {
     const int lanes = g.size() < 64 ? g.size() : 64;
     const int sub = g.tid() / lanes, nsub = g.size() / lanes, lane = g.tid() - sub * lanes;
@@ -512,7 +512,7 @@ AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* o
         const int a = bkp[2 * j], o0 = offs[j], len = offs[j + 1] - o0;
         for (int k = lane; k < len; k += lanes) {
             const int v = a + k;
-            gpath[o0 + k] = v > 0 ? v + seg_base : v - seg_base;
+            gpath[o0 + k] = (int16_t)v;   // local id; readers add the base
             if (first) { atomic_min_i32(&first[v + n], o0 + k); atomic_max_i32(&last[v + n], o0 + k); }
         }
     }

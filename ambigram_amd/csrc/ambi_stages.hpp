@@ -787,8 +787,8 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, 
     const int n = U.n_seg, m = U.n_junc;
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
     uint8_t* res = A.results + U.res_off;
-    int32_t* gpath = reinterpret_cast<int32_t*>(res + Lay.path);
-    int32_t* gpath2 = reinterpret_cast<int32_t*>(res + Lay.path_ind);
+    rcell_t* gpath = reinterpret_cast<rcell_t*>(res + Lay.path);
+    rcell_t* gpath2 = reinterpret_cast<rcell_t*>(res + Lay.path_ind);
     OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
     const int base = U.seg_base;
     int status = out->status;
@@ -800,7 +800,7 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, 
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
         // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
         int P = n <= U.path_cap ? n : U.path_cap;
-        for (int i = g.tid(); i < P; i += g.size()) gpath[i] = i + 1 + base;
+        for (int i = g.tid(); i < P; i += g.size()) gpath[i] = (rcell_t)(i + 1);
         if (g.tid() == 0) {
             out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
             if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
@@ -840,7 +840,7 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, 
     if (printed < 0) { if (g.tid() == 0) { out->status = printed; out->path_len = P; } g.sync(); return; }
     AMBI_MARK(A, g, u, 19);
     // the edited path is materialised only when indelBFB changed something; otherwise readers take `path`
-    if (edited) for (int i = g.tid(); i < P2; i += g.size()) { int v = W.path[i]; gpath2[i] = v > 0 ? v + base : v - base; }
+    if (edited) for (int i = g.tid(); i < P2; i += g.size()) gpath2[i] = W.path[i];
     // output junctions of the final path; records go straight into the blob (absolute ids)
     int nout = synth_out_juncs(g, W.path, P2, gout, U.out_cap, W.cand, finish_cand_cap(U.bkp_cap, U.out_cap), base);
     AMBI_MARK(A, g, u, 20);
@@ -896,7 +896,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     const int n = U.n_seg, m = U.n_junc;
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
     uint8_t* res = A.results + U.res_off;
-    int32_t* gpath = reinterpret_cast<int32_t*>(res + Lay.path);
+    rcell_t* gpath = reinterpret_cast<rcell_t*>(res + Lay.path);
     OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
     const int base = U.seg_base;
     if (plan_refused(g, out)) return;
@@ -906,7 +906,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
         // reference path 1+ .. n+ (localhap.cpp:165-169 / :214-219); no indelBFB on this branch
         int P = n <= U.path_cap ? n : U.path_cap;
-        for (int i = g.tid(); i < P; i += g.size()) gpath[i] = i + 1 + base;
+        for (int i = g.tid(); i < P; i += g.size()) gpath[i] = (rcell_t)(i + 1);
         if (g.tid() == 0) {
             out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
             if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;

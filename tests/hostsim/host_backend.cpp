@@ -362,9 +362,9 @@ class HostSimBackend : public Backend {
             const UnitIn& U = units_[u];
             UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
             int len = which ? h->path_indel_len : h->path_len;
-            const int32_t* src = reinterpret_cast<const int32_t*>(results_.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
+            const rcell_t* src = reinterpret_cast<const rcell_t*>(results_.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
             lengths[u] = len;
-            for (int i = 0; i < len && off + i < cap; i++) cells[off + i] = src[i];
+            for (int i = 0; i < len && off + i < cap; i++) cells[off + i] = abs_cell(src[i], U.seg_base);
             off += len;
         }
         if (total) *total = off;
@@ -378,11 +378,11 @@ class HostSimBackend : public Backend {
             const UnitIn& U = units_[u];
             UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
             const int len = which ? h->path_indel_len : h->path_len;
-            const int32_t* src = reinterpret_cast<const int32_t*>(results_.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
+            const rcell_t* src = reinterpret_cast<const rcell_t*>(results_.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
             lengths[u] = len;
             int n = 0;
             for (int i = 0; i < len; i++) {
-                if (i == 0 || src[i] != src[i - 1] + 1) { if (off + n < cap) { run_start[off + n] = src[i]; run_len[off + n] = 0; } n++; }
+                if (i == 0 || src[i] != src[i - 1] + 1) { if (off + n < cap) { run_start[off + n] = abs_cell(src[i], U.seg_base); run_len[off + n] = 0; } n++; }
                 if (off + n - 1 < cap) run_len[off + n - 1]++;
             }
             run_counts[u] = n;
