@@ -117,6 +117,7 @@ struct BatchArgs {
     const UnitIn* units;
     const double* seg_cn;
     const Junction* juncs;
+    const JuncEnds* junc_ends;  // [sum m] the strand-signed ends of every junction (4 bytes; the finish stages need nothing else of a junction)
     const Element* elems;
     Dag* dags;                   // [U]
     uint8_t* results;            // result blob; UnitOut[U] at the front

@@ -694,7 +694,7 @@ class HipBackend : public Backend {
     uint32_t timing_mask_ = ~0u;   // kernels that get events (bit = kernel index)
     hipStream_t stream_ = nullptr;
     // device buffers
-    UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; Element* d_elems_ = nullptr;
+    UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; JuncEnds* d_junc_ends_ = nullptr; Element* d_elems_ = nullptr;
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; uint32_t* d_ilink_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
     int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
@@ -772,14 +772,14 @@ class HipBackend : public Backend {
         void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
                         d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
                         d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
-                        d_all_bits_, d_all_off_, d_all_count_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_, d_direct_cells_};
+                        d_all_bits_, d_all_off_, d_all_count_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_, d_direct_cells_, d_junc_ends_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
         d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
         d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
         d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
         d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
-        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr; d_direct_cells_ = nullptr;
+        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr; d_direct_cells_ = nullptr; d_junc_ends_ = nullptr;
         if (h_npending_) (void)hipHostFree(h_npending_);
         if (h_needed_) (void)hipHostFree(h_needed_);
         if (h_express_left_) (void)hipHostFree(h_express_left_);
@@ -840,6 +840,7 @@ class HipBackend : public Backend {
         if ((rc = dalloc(&d_units_, U))) return rc;
         if ((rc = dalloc(&d_seg_cn_, hb.seg_cn.size()))) return rc;
         if ((rc = dalloc(&d_juncs_, hb.juncs.size()))) return rc;
+        if ((rc = dalloc(&d_junc_ends_, hb.junc_ends.size()))) return rc;
         if ((rc = dalloc(&d_elems_, hb.elems.size()))) return rc;
         if ((rc = dalloc(&d_dags_, U))) return rc;
         if ((rc = dalloc(&d_results_, (size_t)hb.result_bytes))) return rc;
@@ -877,6 +878,7 @@ class HipBackend : public Backend {
         HIP_CK(hipMemcpy(d_units_, hb.units.data(), U * sizeof(UnitIn), hipMemcpyHostToDevice));
         HIP_CK(hipMemcpy(d_seg_cn_, hb.seg_cn.data(), hb.seg_cn.size() * sizeof(double), hipMemcpyHostToDevice));
         if (!hb.juncs.empty()) HIP_CK(hipMemcpy(d_juncs_, hb.juncs.data(), hb.juncs.size() * sizeof(Junction), hipMemcpyHostToDevice));
+        if (!hb.junc_ends.empty()) HIP_CK(hipMemcpy(d_junc_ends_, hb.junc_ends.data(), hb.junc_ends.size() * sizeof(JuncEnds), hipMemcpyHostToDevice));
         if (!hb.elems.empty()) HIP_CK(hipMemcpy(d_elems_, hb.elems.data(), hb.elems.size() * sizeof(Element), hipMemcpyHostToDevice));
         HIP_CK(hipMemcpy(d_scratch_off_, hb.scratch_off.data(), U * sizeof(int64_t), hipMemcpyHostToDevice));
         HIP_CK(hipMemset(d_results_, 0, (size_t)hb.result_bytes));
@@ -1049,7 +1051,7 @@ class HipBackend : public Backend {
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
         A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.emit_interleave = emit_interleave_; A_.order_align = order_align_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
-        A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.elems = d_elems_;
+        A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.junc_ends = d_junc_ends_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
         A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_link = d_ilink_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
         A_.first_rows = d_first_rows_;

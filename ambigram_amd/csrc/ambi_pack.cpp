@@ -26,6 +26,7 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
         J.src = j_src[j]; J.tgt = j_tgt[j]; J.sdir = j_sdir[j] > 0 ? 1 : -1; J.tdir = j_tdir[j] > 0 ? 1 : -1;
         J.same_chr = 1; J.cn = j_cn[j];
         juncs.push_back(J);
+        junc_ends.push_back(ambi::junc_ends(J));
     }
     U.elem_off = (int64_t)elems.size();
     int64_t L = 0;

@@ -816,8 +816,8 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, 
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
     {
-        const Junction* gj = A.juncs + U.junc_off;
-        for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(gj[j]);
+        const JuncEnds* ge = A.junc_ends + U.junc_off;   // 4 bytes per junction instead of the 24-byte record
+        for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = ge[j];
     }
     g.sync();
     AMBI_MARK(A, g, u, 17);
@@ -920,8 +920,8 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
     {
-        const Junction* gj = A.juncs + U.junc_off;
-        for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(gj[j]);
+        const JuncEnds* ge = A.junc_ends + U.junc_off;   // 4 bytes per junction instead of the 24-byte record
+        for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = ge[j];
     }
     g.sync();
     AMBI_MARK(A, g, u, 17);
