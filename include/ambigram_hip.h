@@ -150,7 +150,10 @@ int ambi_batch_wait_results(ambi_batch_t* b);
 /* Copies the result blob to the host (implies wait).  After this the getters below are valid. */
 int ambi_batch_download(ambi_batch_t* b);
 
-/* Device-side view for collectives: the result blob (header [n_units] + per-unit arrays) lives in device memory. */
+/* Device-side view for collectives: the result blob (header [n_units] + per-unit arrays) lives in device memory.  Its
+ * layout is the engine's own (csrc/ambi_batch.hpp: UnitOut, unit_layout; path cells are 2-byte LOCAL signed segment ids --
+ * absolute id = id +- the chromosome's first segment id - 1); portable consumers use ambi_batch_pack_paths / _pack_runs, which
+ * deliver absolute ids, or the getters after ambi_batch_download. */
 int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes);
 /* Packs the final paths of all units into caller-provided DEVICE buffers: lengths[n_units] (int32) and the
  * concatenation of the paths (int32, absolute signed ids) -- the payload of the end-of-batch RCCL gather.
