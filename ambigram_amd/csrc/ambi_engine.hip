@@ -537,13 +537,13 @@ __global__ __launch_bounds__(1024) void ambi_finish_kernel(BatchArgs A, const in
     if (A.host_pending && !unit_list && blockIdx.x == 0 && threadIdx.x == 0) *A.host_pending = *A.n_pending;
     stage_finish(g, A, u, ambi_lds);
 }
-// The direct full-stage launch with the path cells in device memory (stage_finish<true>): entry i of the list works in
-// slot i of `cells` (stride bytes apart).
+// The direct full-stage launch with the path cells in device memory (stage_finish<true>): a workgroup works in its own
+// slot of `cells` (stride bytes apart; gridDim.x slots) for every unit it takes.
 __global__ __launch_bounds__(1024) void ambi_finish_ext_kernel(BatchArgs A, const int32_t* unit_list, int count, uint8_t* cells, int64_t stride) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
-        if (!unit_out(A.results, unit_list[i])->reserved) stage_finish<true>(g, A, unit_list[i], ambi_lds, reinterpret_cast<cell_t*>(cells + (int64_t)i * stride));
+        if (!unit_out(A.results, unit_list[i])->reserved) stage_finish<true>(g, A, unit_list[i], ambi_lds, reinterpret_cast<cell_t*>(cells + (int64_t)blockIdx.x * stride));
         __syncthreads();
     }
 }
@@ -1003,7 +1003,8 @@ class HipBackend : public Backend {
                     HIP_CK(hipMemcpy(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
                     if (direct_ext_) {   // one path area per unit of the list in device memory
                         direct_stride_ = (2ll * hb.max_path + 16 + 15) & ~int64_t(15);
-                        if ((rc = dalloc(&d_direct_cells_, (size_t)(direct_stride_ * (int64_t)dl.size())))) return rc;
+                        const int64_t slots = (int64_t)dl.size() < direct_grid_ ? (int64_t)dl.size() : direct_grid_;   // one per workgroup of the launch
+                        if ((rc = dalloc(&d_direct_cells_, (size_t)(direct_stride_ * slots)))) return rc;
                         lds_finish_ext_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, 0, hb.max_out);
                     }
                     int least = 0, greatest = 0;
