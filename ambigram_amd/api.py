@@ -127,6 +127,9 @@ def _preload_hip_runtime():
     if _RUNTIME:
         return
     _RUNTIME.append(None)
+    # four engine streams + the caller's (+ RCCL's) want more than the runtime's default of 4 hardware queues per process, or
+    # two of them share a queue and serialize (bench.py, DESIGN.md "Launch order"); no effect if the runtime is already up
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")

@@ -1,4 +1,5 @@
 // ambi_capi.cpp -- implementation of the C ABI declared in include/ambigram_hip.h on top of a Backend.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -63,7 +64,11 @@ const char* ambi_backend_name(void) {
     return nm.c_str();
 }
 int ambi_device_count(int* count) { std::unique_ptr<Backend> b(make_backend()); return b->device_count(count); }
-int ambi_set_device(int device) { std::unique_ptr<Backend> b(make_backend()); return b->set_device(device); }
+int ambi_set_device(int device) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // (only honoured when this is the process's first HIP call: see INTEGRATION.md)
+    std::unique_ptr<Backend> b(make_backend());
+    return b->set_device(device);
+}
 
 // ---- graph ----
 int ambi_graph_read_lh(const char* lh_path, ambi_graph_t** out) {

@@ -240,6 +240,7 @@ int run_sc_bfb(Args& A) {
 }  // namespace
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // the engine's four streams on hardware queues of their own (before the HIP runtime starts)
     Args A = parse(argc, argv);
     if (A.help) {
         std::cout << "Local Haplotype constructer\nUsage:\n  Ambigram --op bfb|sc_bfb --in_lh <file[,file...]> --lp_prefix <name> [--juncdb <file> --junc_info true] "
