@@ -44,6 +44,7 @@ class Backend {
     virtual void set_timing_mask(uint32_t mask) { set_timing(mask != 0); }
     virtual const std::vector<KernelTime>& kernel_times() = 0;
     virtual int64_t order_bytes_written() const = 0;
+    virtual size_t object_bytes() const = 0;   // sizeof the concrete backend (diagnostics: ambi_batch_destroy's quarantine mode)
     virtual int slice_count() const { return 1; }   // launches of every kernel per run
     // --all (run with FLAG_ALL, after wait): valid orders of pass 0 (first orientation) / pass 1 (flipped orientation,
     // empty unless the last order of pass 0 is invalid), and the paths of a range of them (cells: count x stride int32)

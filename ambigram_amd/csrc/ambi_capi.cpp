@@ -166,7 +166,32 @@ int ambi_batch_create(ambi_batch_t** out) {
     *out = b;
     return 0;
 }
-void ambi_batch_destroy(ambi_batch_t* b) { delete b; }
+// AMBI_DEBUG_QUARANTINE=1 (diagnostics): destroyed batches are not returned to the allocator but filled with a pattern and
+// checked at every later destroy -- a write into a destroyed batch or backend object shows up with its offset.
+namespace {
+struct Quarantined { unsigned char* p; size_t n; const char* what; };
+std::vector<Quarantined>& quarantine() { static std::vector<Quarantined> q; return q; }
+void check_quarantine() {
+    for (auto& q : quarantine())
+        for (size_t i = 0; i < q.n; i++)
+            if (q.p[i] != 0xAB) { fprintf(stderr, "ambigram_hip QUARANTINE: destroyed %s object %p modified at offset %zu: 0x%02x\n", q.what, (void*)q.p, i, q.p[i]); q.p[i] = 0xAB; }
+}
+}  // namespace
+void ambi_batch_destroy(ambi_batch_t* b) {
+    static const bool quarantine_on = getenv("AMBI_DEBUG_QUARANTINE") != nullptr;
+    if (!quarantine_on || !b) { delete b; return; }
+    check_quarantine();
+    Backend* raw = b->be.release();
+    if (raw) {
+        const size_t n = raw->object_bytes();
+        raw->~Backend();
+        memset((void*)raw, 0xAB, n);
+        quarantine().push_back({reinterpret_cast<unsigned char*>(raw), n, "backend"});
+    }
+    b->~ambi_batch();
+    memset((void*)b, 0xAB, sizeof(ambi_batch));
+    quarantine().push_back({reinterpret_cast<unsigned char*>(b), sizeof(ambi_batch), "batch"});
+}
 
 int ambi_batch_add_chromosome(ambi_batch_t* b, const ambi_graph_t* g, int32_t chr, int32_t n_cols, const int32_t* col,
                               const int32_t* val, int32_t infeasible) {

@@ -61,7 +61,11 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
     opt.reversed = flags & 1; opt.all = flags & 2; opt.juncInfo = flags & 4; opt.keepOrders = flags & 8;
     if (maxOrders > 0) opt.maxOrders = (size_t)maxOrders;
     auto t0 = std::chrono::steady_clock::now();
-    RunResult R = runBfb(opt);
+    RunResult R;
+    try { R = runBfb(opt); }
+    catch (const std::exception& e) {   // (the reference would terminate here: std::stoi on a malformed token, say)
+        R = RunResult(); R.ok = false; R.err = std::string("exception: ") + e.what();
+    }
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     std::ostringstream o;

@@ -26,7 +26,7 @@ def build(ref=True):
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("AMBI_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (another build of the oracle: sanitizer runs)
         if not os.path.exists(path):
             build(ref=False)
         L = ctypes.CDLL(path)

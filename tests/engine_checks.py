@@ -1,4 +1,5 @@
 """Parity checks shared by the CPU host-simulation tests and the GPU tests (same assertions, different library)."""
+import os
 import numpy as np
 
 import cases
@@ -71,6 +72,11 @@ def check_random_decompositions(lib, oracle, workdir, seeds, budget=0):
                 if oc["first_forward"] == (1 if rev else 0):
                     stats["reversed_pass"] += 1
             b.close(); g.close()
+        for f in [lh] + list(sols):    # long runs (tests/soak.py) must not fill the temporary directory
+            try:
+                os.remove(f)
+            except OSError:
+                pass
     return stats
 
 

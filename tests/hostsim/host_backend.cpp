@@ -403,6 +403,7 @@ class HostSimBackend : public Backend {
     void set_timing(bool) override {}
     const std::vector<KernelTime>& kernel_times() override { return times_; }
     int64_t order_bytes_written() const override { return orders_needed_; }
+    size_t object_bytes() const override { return sizeof(HostSimBackend); }
 };
 
 Backend* make_backend() { return new HostSimBackend(); }
