@@ -74,6 +74,7 @@ def _declare(L):
         "ambi_batch_wait": (C.c_int, [vp]),
         "ambi_batch_wait_results": (C.c_int, [vp]),
         "ambi_batch_download": (C.c_int, [vp]),
+        "ambi_batch_fetch_paths": (C.c_int, [vp]),
         "ambi_batch_device_results": (C.c_int, [vp, _P(vp), pi64]),
         "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
         "ambi_batch_pack_runs": (C.c_int, [vp, i32, vp, vp, vp, vp, i64, vp, vp]),
@@ -360,6 +361,11 @@ class Batch:
 
     def download(self):
         self._ck(self.lib.ambi_batch_download(self.h), "download")
+
+    def fetch_paths(self):
+        """Headers, final paths and output junctions on the host (small batches: read from the pinned mailbox the
+        reconstruction kernel wrote, no copy command); unit_result / unit_path / unit_out_juncs are valid afterwards."""
+        self._ck(self.lib.ambi_batch_fetch_paths(self.h), "fetch_paths")
 
     def device_results(self):
         p, n = C.c_void_p(), C.c_int64()

@@ -33,6 +33,9 @@ class Backend {
     virtual int wait() = 0;
     virtual int wait_results() { return wait(); }   // results complete; order tables may still be in flight (express path)
     virtual int download(std::vector<uint8_t>& blob) = 0;
+    // Header, final path(s) and output junctions of a unit where the HOST can read them without a copy command (MailLayout,
+    // ambi_batch.hpp), valid after wait_results() / wait() of a small batch; nullptr: download the blob instead
+    virtual const uint8_t* mail_slot(int unit) { (void)unit; return nullptr; }
     virtual int device_results(void** ptr, int64_t* bytes) = 0;
     virtual int pack_runs(int which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start, int32_t* dev_run_len,
                           int64_t run_cap, int64_t* dev_totals, void* stream) = 0;

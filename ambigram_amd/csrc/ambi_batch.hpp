@@ -173,7 +173,27 @@ struct BatchArgs {
     int32_t all_rows_from_table; // experiment (env AMBI_ALL_TABLE=1): the lane kernel reads its orders from the order table instead of unranking them
     int32_t all_rank, all_world; // --all over several ranks (one wide sample): a rank evaluates the chunks c with c % world == rank,
                                  // plus the LAST chunk of every unit (every rank must know whether the orientation flips)
+    // small batches (express path): what a caller of ONE sample wants on the host -- header, final path(s), output junctions --
+    // is mirrored by the express kernel into a pinned host "mailbox" (one slot per unit, MailLayout), so that no copy command
+    // follows the kernel; and the two late verdicts that can still void an express result reach the host through pinned words
+    uint8_t* mail;               // device address of the pinned mailbox (nullptr: none)
+    const int64_t* mail_off;     // [U] byte offset of every unit's slot
+    int32_t* plan_seq;           // pinned host int: the plan kernel stores run_seq here once orders_needed / late_flag are final
+    int32_t* late_flag;          // pinned host int: != 0 when the lattice or plan stage refused a unit AFTER the express stage published it
 };
+
+// Mailbox slot of one unit: [UnitOut, 128 bytes] [path: path_cap cells] [path after indelBFB: path_cap cells] [output junctions:
+// out_cap records], each part on a 16-byte boundary; only the used prefix of every part is written.
+struct MailLayout { int64_t path, path_ind, out_junc, total; };
+AMBI_HD int64_t pad16(int64_t b) { return (b + 15) & ~int64_t(15); }
+AMBI_HD MailLayout mail_layout(int path_cap, int out_cap) {
+    MailLayout M;
+    M.path = 128;
+    M.path_ind = M.path + pad16(int64_t(sizeof(rcell_t)) * path_cap);
+    M.out_junc = M.path_ind + pad16(int64_t(sizeof(rcell_t)) * path_cap);
+    M.total = M.out_junc + pad16(int64_t(sizeof(OutJunc)) * out_cap);
+    return M;
+}
 
 // stage-level timing marks (diagnostics only; one predictable branch per mark when off)
 constexpr int kStageSlots = 32;

@@ -1,4 +1,5 @@
 // ambi_capi.cpp -- implementation of the C ABI declared in include/ambigram_hip.h on top of a Backend.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -20,6 +21,7 @@ struct ambi_batch {
     std::unique_ptr<Backend> be;
     std::vector<uint8_t> blob;
     bool uploaded = false, downloaded = false;
+    bool mail_view = false;   // header / final paths / output junctions are read from the backend's pinned mailbox (ambi_batch_fetch_paths)
 };
 
 static int64_t copy_text(const std::string& s, char* buf, int64_t cap) {
@@ -164,6 +166,12 @@ int ambi_batch_create(ambi_batch_t** out) {
     ambi_batch* b = new ambi_batch();
     b->be.reset(make_backend());
     *out = b;
+    if (getenv("AMBI_DEBUG_SIZES")) {   // diagnostics: heap objects the engine creates and frees per batch
+        static bool once = false;
+        if (!once) fprintf(stderr, "ambigram sizes: ambi_batch %zu, HostBatch %zu, backend %zu, BatchArgs (kernel argument block) %zu, UnitIn %zu, UnitOut %zu, Dag %zu\n",
+                           sizeof(ambi_batch), sizeof(HostBatch), b->be->object_bytes(), sizeof(BatchArgs), sizeof(UnitIn), sizeof(UnitOut), sizeof(Dag));
+        once = true;
+    }
     return 0;
 }
 // AMBI_DEBUG_QUARANTINE=1 (diagnostics): destroyed batches are not returned to the allocator but filled with a pattern and
@@ -262,7 +270,7 @@ int ambi_batch_upload(ambi_batch_t* b) {
 int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream) {
     if (!b) return AMBI_ERR_ARG;
     if (!b->uploaded) return AMBI_ERR_STATE;
-    b->downloaded = false;
+    b->downloaded = false; b->mail_view = false;
     return b->be->run(flags, hip_stream);
 }
 int ambi_batch_wait(ambi_batch_t* b) { return b ? b->be->wait() : AMBI_ERR_ARG; }
@@ -271,8 +279,17 @@ int ambi_batch_download(ambi_batch_t* b) {
     if (!b) return AMBI_ERR_ARG;
     if (!b->uploaded) return AMBI_ERR_STATE;
     int rc = b->be->download(b->blob);
-    if (rc == 0) b->downloaded = true;
+    if (rc == 0) { b->downloaded = true; b->mail_view = false; }
     return rc;
+}
+int ambi_batch_fetch_paths(ambi_batch_t* b) {
+    if (!b) return AMBI_ERR_ARG;
+    if (!b->uploaded) return AMBI_ERR_STATE;
+    int rc = b->be->wait_results();
+    if (rc) return rc;
+    if (b->downloaded) return 0;
+    if (b->be->mail_slot(0)) { b->mail_view = true; return 0; }
+    return ambi_batch_download(b);
 }
 int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes) {
     if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
@@ -300,24 +317,47 @@ static const UnitOut* header(const ambi_batch_t* b, int unit) {
     if (!b || !b->downloaded || unit < 0 || unit >= (int)b->hb.units.size()) return nullptr;
     return reinterpret_cast<const UnitOut*>(b->blob.data()) + unit;
 }
+// The parts of a unit's results that ambi_batch_fetch_paths makes available: from the downloaded blob, or straight from the
+// backend's pinned mailbox (MailLayout) when the batch took the express path.
+struct PathView { const UnitOut* h; const rcell_t* path; const rcell_t* path_ind; const OutJunc* out; bool mail; };
+static bool path_view(const ambi_batch_t* b, int unit, PathView& v) {
+    if (!b || unit < 0 || unit >= (int)b->hb.units.size()) return false;
+    const UnitIn& U = b->hb.units[unit];
+    if (b->downloaded) {
+        const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+        const uint8_t* r = b->blob.data() + U.res_off;
+        v = PathView{reinterpret_cast<const UnitOut*>(b->blob.data()) + unit, reinterpret_cast<const rcell_t*>(r + L.path),
+                     reinterpret_cast<const rcell_t*>(r + L.path_ind), reinterpret_cast<const OutJunc*>(r + L.out_junc), false};
+        return true;
+    }
+    if (!b->mail_view) return false;
+    const uint8_t* slot = b->be->mail_slot(unit);
+    if (!slot) return false;
+    const MailLayout M = mail_layout(U.path_cap, U.out_cap);
+    v = PathView{reinterpret_cast<const UnitOut*>(slot), reinterpret_cast<const rcell_t*>(slot + M.path), reinterpret_cast<const rcell_t*>(slot + M.path_ind),
+                 reinterpret_cast<const OutJunc*>(slot + M.out_junc), true};
+    return true;
+}
 
 int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result_t* out) {
-    const UnitOut* h = header(b, unit);
-    if (!h || !out) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    PathView pv;
+    if (!path_view(b, unit, pv) || !out) return b && !b->downloaded && !b->mail_view ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitOut* h = pv.h;
     out->status = h->status; out->bias = h->bias; out->n_nodes = h->K; out->bkp_len = h->bkp_len;
     out->path_len = h->path_len; out->path_indel_len = h->path_indel_len; out->indel_printed = h->indel_printed;
     out->n_out_junc = h->n_out_junc; out->first_forward = h->first_forward; out->evaluated = h->evaluated;
     out->num_orders = h->num_orders; out->first_valid = h->first_valid; out->inv_cn_sum = h->inv_cn_sum;
     out->path_indel_stored = h->path_ind_stored; out->reserved = 0;
+    if (pv.mail) out->num_orders = -1;   // the order count comes from the lattice stage, behind the express kernel: not in the mailbox
     return 0;
 }
 int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int32_t* out, int32_t cap) {
-    const UnitOut* h = header(b, unit);
-    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    PathView pv;
+    if (!path_view(b, unit, pv)) return b && !b->downloaded && !b->mail_view ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitOut* h = pv.h;
     const UnitIn& U = b->hb.units[unit];
-    UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
     // the path after indelBFB is stored separately only when indelBFB changed it
-    const rcell_t* src = reinterpret_cast<const rcell_t*>(b->blob.data() + U.res_off + ((which && h->path_ind_stored) ? L.path_ind : L.path));
+    const rcell_t* src = (which && h->path_ind_stored) ? pv.path_ind : pv.path;
     int len = which ? h->path_indel_len : h->path_len;
     if (out) for (int i = 0; i < len && i < cap; i++) out[i] = abs_cell(src[i], U.seg_base);   // the blob holds local ids
     return len;
@@ -366,11 +406,10 @@ int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, 
     return h->K;
 }
 int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap) {
-    const UnitOut* h = header(b, unit);
-    if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
-    const UnitIn& U = b->hb.units[unit];
-    UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-    const OutJunc* src = reinterpret_cast<const OutJunc*>(b->blob.data() + U.res_off + L.out_junc);
+    PathView pv;
+    if (!path_view(b, unit, pv)) return b && !b->downloaded && !b->mail_view ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    const UnitOut* h = pv.h;
+    const OutJunc* src = pv.out;
     for (int i = 0; i < h->n_out_junc && i < cap; i++) {
         if (u) u[i] = src[i].u;
         if (v) v[i] = src[i].v;

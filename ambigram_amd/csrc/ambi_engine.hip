@@ -19,6 +19,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ambi_backend.hpp"
@@ -41,6 +42,40 @@ namespace ambi {
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __align__(16) uint8_t ambi_lds[];
 
+constexpr uint32_t kGuardWord = 0xA5B1C3D7u;
+// results of one unit as the express kernel mirrors them into the pinned mailbox (MailLayout); whole workgroup
+__device__ inline void mail_unit(const BatchArgs& A, int u) {
+    const UnitIn& U = A.units[u];
+    const UnitOut* h = unit_out(A.results, u);
+    const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
+    const MailLayout M = mail_layout(U.path_cap, U.out_cap);
+    uint8_t* slot = A.mail + A.mail_off[u];
+    const uint8_t* res = A.results + U.res_off;
+    auto copy8 = [&](uint8_t* dst, const uint8_t* src, int64_t bytes) {   // (every part is padded to 8 bytes on both sides)
+        for (int64_t i = threadIdx.x; i < (bytes + 7) / 8; i += blockDim.x) reinterpret_cast<uint64_t*>(dst)[i] = reinterpret_cast<const uint64_t*>(src)[i];
+    };
+    copy8(slot, reinterpret_cast<const uint8_t*>(h), (int64_t)sizeof(UnitOut));
+    copy8(slot + M.path, res + L.path, (int64_t)sizeof(rcell_t) * h->path_len);
+    if (h->path_ind_stored) copy8(slot + M.path_ind, res + L.path_ind, (int64_t)sizeof(rcell_t) * h->path_indel_len);
+    copy8(slot + M.out_junc, res + L.out_junc, (int64_t)sizeof(OutJunc) * h->n_out_junc);
+    __threadfence_system();
+}
+// guard words on both sides of every path area of the direct full-finish launch (AMBI_DEBUG: does that kernel leave its slot?)
+constexpr int kCellGuardBytes = 64;
+__global__ void ambi_guard_fill_kernel(uint8_t* cells, int64_t stride, int slots) {
+    const int s = blockIdx.x, t = threadIdx.x;   // 32 threads: 16 words in front of the area, 16 behind
+    if (s >= slots) return;
+    uint32_t* w = reinterpret_cast<uint32_t*>(cells + (int64_t)s * stride + (t < 16 ? 0 : stride - kCellGuardBytes));
+    w[t & 15] = kGuardWord;
+}
+__global__ void ambi_guard_check_kernel(const uint8_t* cells, int64_t stride, int slots, int32_t* bad) {
+    const int s = blockIdx.x, t = threadIdx.x;
+    if (s >= slots) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(cells + (int64_t)s * stride + (t < 16 ? 0 : stride - kCellGuardBytes));
+    if (w[t & 15] != kGuardWord) atomicAdd(bad, 1);
+}
+
+
 __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
     if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { *A.n_pending = 0; *A.refin_count = 0; }   // nothing counts pending / handed-over units before the scan
@@ -58,6 +93,7 @@ __global__ __launch_bounds__(256) void ambi_express_kernel(BatchArgs A) {
     const int wave = threadIdx.x >> 6, u = A.unit_base + (int)blockIdx.x;
     stage_express(gw, gb, wave < 2 ? wave : 2, A, u, ambi_lds);
     __syncthreads();
+    if (A.mail && unit_out(A.results, u)->reserved) { mail_unit(A, u); __syncthreads(); }   // header, final path(s), output junctions -> pinned host memory
     if (threadIdx.x == 0 && A.express_left) {
         if (!unit_out(A.results, u)->reserved) *A.express_left = 1;
         __threadfence_system();
@@ -140,14 +176,17 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
             A.rows_per_lane[u] = T;
             if (toobig) out->order_off = kOrderOffNoRoom;
             else if (live) out->order_off = fits ? A.arena_base + off : kOrderOffNoRoom;   // (no room: the finish stage turns the status into ORDERS_CAPACITY)
+            if ((toobig || (live && !fits)) && A.late_flag) { *A.late_flag = 1; __threadfence_system(); }   // a result the express stage published is void
         }
         off_carry += tot_b;
         blk_carry += tot_k;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         A.blk_off[A.n_units] = blk_carry;
         *A.orders_needed = off_carry;
         if (A.host_needed) *A.host_needed = off_carry;
+        if (A.plan_seq) { __threadfence_system(); *(volatile int32_t*)A.plan_seq = A.run_seq; }   // orders_needed and late_flag of this run are final
     }
 }
 
@@ -527,7 +566,7 @@ __global__ __launch_bounds__(1024) void ambi_finish_kernel(BatchArgs A, const in
     if (unit_list && (list_count || fixed_count >= 0)) {
         const int n = list_count ? *list_count : fixed_count;
         for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-            if (!unit_out(A.results, unit_list[i])->reserved) stage_finish(g, A, unit_list[i], ambi_lds);   // (reserved: done by the express kernel)
+            if (!plan_refused(g, unit_out(A.results, unit_list[i])) && !unit_out(A.results, unit_list[i])->reserved) stage_finish(g, A, unit_list[i], ambi_lds);   // (reserved: done by the express kernel; refusal first, as in the lean stage)
             __syncthreads();
         }
         return;
@@ -543,7 +582,8 @@ __global__ __launch_bounds__(1024) void ambi_finish_ext_kernel(BatchArgs A, cons
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
-        if (!unit_out(A.results, unit_list[i])->reserved) stage_finish<true>(g, A, unit_list[i], ambi_lds, reinterpret_cast<cell_t*>(cells + (int64_t)blockIdx.x * stride));
+        if (!plan_refused(g, unit_out(A.results, unit_list[i])) && !unit_out(A.results, unit_list[i])->reserved)
+            stage_finish<true>(g, A, unit_list[i], ambi_lds, reinterpret_cast<cell_t*>(cells + (int64_t)blockIdx.x * stride + kCellGuardBytes));
         __syncthreads();
     }
 }
@@ -685,15 +725,132 @@ __global__ __launch_bounds__(256) void ambi_expand_runs_kernel(const int32_t* ru
 constexpr int kLdsMaxDynamic = 160 * 1024 - 1024;
 
 // ------------------------------------------------------------------------------------------------
+// Per-device resources with PROCESS lifetime.
+//
+// Round 2 created and destroyed 3-4 streams (one of them with a dispatch priority), 6+ events and three pinned allocations
+// with every batch, and a long create / run / destroy loop showed rare stray writes into host memory of the process
+// (DESIGN.md 8b).  Nothing the HIP runtime hands out is destroyed per batch any more: a batch LEASES a context -- side
+// streams, events, the pinned words the kernels report through, a pinned staging block, a pinned result mailbox and
+// grow-only device blocks -- from a per-device free list and gives it back when it is destroyed (after synchronising every
+// stream it used).  Leases are never destroyed; at process exit they are left to the runtime.
+// ------------------------------------------------------------------------------------------------
+struct PinnedWords {                    // what kernels write into host memory (BatchArgs::host_pending, host_needed, express_*, plan_seq, late_flag)
+    uint32_t guard_lo[16];
+    int32_t npending, express_left, express_seq, plan_seq, late_flag, pad_[11];
+    int64_t needed[16];
+    uint32_t guard_hi[16];
+};
+struct TimingEvents { const char* name; hipEvent_t a, b; };
+struct Lease {
+    int device = 0;
+    hipStream_t side[3][3] = {};        // [back, full, first][default, lowest, highest priority], created on first use
+    hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_back = nullptr, ev_first = nullptr, ev_full = nullptr, ev_plan = nullptr, ev_express = nullptr;
+    PinnedWords* h_words = nullptr; PinnedWords* dh_words = nullptr;
+    uint8_t* d_block = nullptr; int64_t d_block_bytes = 0;      // inputs + working set + result blob of the batch
+    uint8_t* d_arena = nullptr; int64_t d_arena_bytes = 0;      // order tables
+    uint8_t* d_cells = nullptr; int64_t d_cells_bytes = 0;      // path areas of the direct full-finish launch
+    uint8_t* h_stage = nullptr; int64_t h_stage_bytes = 0;      // pinned image of the inputs (one H2D copy)
+    uint8_t* h_mail = nullptr; uint8_t* dh_mail = nullptr; int64_t h_mail_bytes = 0;   // pinned result mailbox (express path)
+    std::vector<TimingEvents> evs;
+    std::vector<hipStream_t> slice_streams; std::vector<hipEvent_t> slice_events;     // AMBI_SLICES experiments
+    long uses = 0;
+    int32_t seq = 0;   // run sequence numbers (the kernels report completion by storing the run's number into a pinned word)
+};
+// what stays cached in a lease between batches (larger blocks go back to the device when the batch is destroyed)
+constexpr int64_t kKeepBlock = 64ll << 20, kKeepArena = 256ll << 20, kKeepCells = 64ll << 20, kKeepStage = 16ll << 20, kKeepMail = 8ll << 20;
+
+class DevicePool {
+    std::mutex mu_;
+    std::vector<Lease*> free_;
+  public:
+    static DevicePool& get() { static DevicePool* p = new DevicePool(); return *p; }   // (never destroyed: no HIP call from a static destructor)
+    int acquire(Lease** out) {
+        int dev = 0;
+        HIP_CK(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i]->device == dev) { *out = free_[i]; free_.erase(free_.begin() + (long)i); (*out)->uses++; return 0; }
+        }
+        Lease* L = new Lease();
+        L->device = dev;
+        hipEvent_t* evs[] = {&L->ev_fork, &L->ev_prep, &L->ev_back, &L->ev_first, &L->ev_full, &L->ev_plan, &L->ev_express};
+        for (hipEvent_t* e : evs) HIP_CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        HIP_CK(hipHostMalloc((void**)&L->h_words, sizeof(PinnedWords)));
+        memset(L->h_words, 0, sizeof(PinnedWords));
+        for (int i = 0; i < 16; i++) { L->h_words->guard_lo[i] = kGuardWord; L->h_words->guard_hi[i] = kGuardWord; }
+        HIP_CK(hipHostGetDevicePointer((void**)&L->dh_words, L->h_words, 0));
+        L->uses = 1;
+        *out = L;
+        return 0;
+    }
+    void release(Lease* L) {
+        if (!L) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        free_.push_back(L);
+    }
+};
+// a side stream of the lease: kind 0 lean finish / scan, 1 direct full finish, 2 scan ahead; prio 0 default, 1 lowest, 2 highest
+static int lease_stream(Lease* L, int kind, int prio, hipStream_t* out) {
+    if (!L->side[kind][prio]) {
+        int least = 0, greatest = 0;
+        if (prio != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            HIP_CK(hipStreamCreateWithPriority(&L->side[kind][prio], hipStreamNonBlocking, prio == 1 ? least : greatest));
+        } else {
+            if (prio != 0) { (void)hipGetLastError(); return lease_stream(L, kind, 0, out); }   // no priorities on this device
+            HIP_CK(hipStreamCreateWithFlags(&L->side[kind][0], hipStreamNonBlocking));
+        }
+    }
+    *out = L->side[kind][prio];
+    return 0;
+}
+// grow-only block of the lease (device memory, or pinned host memory with its device address)
+static int lease_device_block(uint8_t** p, int64_t* have, int64_t want) {
+    if (*have >= want && *p) return 0;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+    want = (want + 4095) & ~int64_t(4095);
+    HIP_CK(hipMalloc((void**)p, (size_t)want));
+    *have = want;
+    return 0;
+}
+static int lease_pinned_block(uint8_t** p, uint8_t** dp, int64_t* have, int64_t want) {
+    if (*have >= want && *p) return 0;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
+    want = (want + 4095) & ~int64_t(4095);
+    HIP_CK(hipHostMalloc((void**)p, (size_t)want));
+    if (dp) HIP_CK(hipHostGetDevicePointer((void**)dp, *p, 0));
+    *have = want;
+    return 0;
+}
+
+// scoped device allocation / event pair for the helpers that allocate per call (freed on every return path)
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+// ------------------------------------------------------------------------------------------------
 // backend
 // ------------------------------------------------------------------------------------------------
 class HipBackend : public Backend {
-    HostBatch hb_;
+    const HostBatch* hbp_ = nullptr;   // the batch's packed inputs (owned by the ambi_batch that owns this backend)
+    const HostBatch& hb() const { return *hbp_; }
     EngineConfig cfg_;
     bool uploaded_ = false, timing_ = false, arena_checked_ = false, ran_ = false;
+    bool inflight_ = false;            // a run has been queued and not yet waited for
+    bool upload_pending_ = false;      // the input image sits in pinned staging: the first run queues its copy (and the zero fill) ahead of the kernels
+    bool late_refusal_ = false;        // a unit of this batch is refused by the lattice / plan stage (known after one complete run: inputs are immutable)
+    bool tuned_ = false;               // the launch parameters that depend on the first run's outcome have been chosen
     uint32_t timing_mask_ = ~0u;   // kernels that get events (bit = kernel index)
     hipStream_t stream_ = nullptr;
-    // device buffers
+    Lease* lease_ = nullptr;
+    // device buffers: all carved from ONE block of the lease (layout()); inputs first, in the order of the staging image
     UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; JuncEnds* d_junc_ends_ = nullptr; Element* d_elems_ = nullptr;
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; uint32_t* d_ilink_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
@@ -704,8 +861,12 @@ class HipBackend : public Backend {
     uint8_t* d_arena_ = nullptr; int64_t arena_bytes_ = 0;
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
-    int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned
+    int64_t* d_mail_off_ = nullptr; int32_t* d_guard_bad_ = nullptr;
+    int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned (words of the lease)
     int32_t* dh_npending_ = nullptr; int64_t* dh_needed_ = nullptr; // the same two, as the device addresses them
+    int64_t in_bytes_ = 0, zero_off_ = 0, zero_bytes_ = 0;          // input image / zero-filled region of the block
+    std::vector<uint8_t> stage_big_;                                // input image of a batch too large for the pinned staging block
+    std::vector<int64_t> mail_off_; int64_t mail_bytes_ = 0; bool mail_on_ = false, mail_valid_ = false;
     BatchArgs A_{};
     int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_finish_lean_ = 0, lds_enum_ = 0;
     bool lean_finish_ = true;   // env AMBI_LEAN_FINISH=0: every unit through the full finish stage
@@ -714,8 +875,8 @@ class HipBackend : public Backend {
     uint32_t* d_anblk_ = nullptr; uint8_t* d_adepth_ = nullptr;
     int finish_path_cells_ = 0;
     std::vector<KernelTime> times_;
-    struct Ev { const char* name; hipEvent_t a, b; };
-    std::vector<Ev> evs_;
+    typedef TimingEvents Ev;
+    std::vector<Ev>& evs() { return lease_->evs; }
     int64_t last_needed_ = 0;
     int general_path_ = -1;   // units that take the general enumerate path: -1 unknown (first run), else the count (inputs are immutable)
     int shared_units_ = -1;   // units whose table is written by several workgroups: -1 unknown, else the count
@@ -725,17 +886,17 @@ class HipBackend : public Backend {
     int n_slices_ = 1;
     std::vector<int> slice_lo_;                        // [n_slices_+1]
     std::vector<int64_t> slice_base_, slice_bytes_;    // arena regions
-    std::vector<hipStream_t> side_;                    // n_slices_-1 internal streams (slice 0 runs on the caller's)
+    std::vector<hipStream_t> side_;                    // n_slices_-1 internal streams (slice 0 runs on the caller's); owned by the lease
     hipEvent_t ev_fork_ = nullptr;
     std::vector<hipEvent_t> ev_join_, ev_stage_;
     bool stagger_ = true;
-    // overlap of [first valid order, finish] with the enumerate kernel (one slice, arena sized): own stream + two events
+    // overlap of [first valid order, finish] with the enumerate kernel (one slice, arena sized): own stream + two events (the lease's)
     bool overlap_back_ = false, want_overlap_ = true;
     hipStream_t back_stream_ = nullptr;
     hipEvent_t ev_prep_ = nullptr, ev_back_ = nullptr, ev_first_ = nullptr, ev_full_ = nullptr;
     hipStream_t full_stream_ = nullptr;
     bool first_launched_ = false; hipEvent_t ev_plan_ = nullptr;
-    uint8_t* d_direct_cells_ = nullptr; int64_t direct_stride_ = 0; int lds_finish_ext_ = 0; bool direct_ext_ = true;   // env AMBI_DIRECT_EXT: the direct launch keeps its path cells in device memory
+    uint8_t* d_direct_cells_ = nullptr; int64_t direct_stride_ = 0; int direct_slots_ = 0; int lds_finish_ext_ = 0; bool direct_ext_ = true;   // env AMBI_DIRECT_EXT: the direct launch keeps its path cells in device memory
     int direct_cells_ = 0; bool direct_retry_ = false;   // path area of the direct full-finish launch (0: the batch's capacity bound); env AMBI_DIRECT_CELLS
     int full_threads_ = 1024;  // env AMBI_FULL_THREADS: threads per workgroup of the direct full-finish launch (256 / 512 / 1024)
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
@@ -744,7 +905,7 @@ class HipBackend : public Backend {
     int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0;
     bool express_ = false;
     hipEvent_t ev_express_ = nullptr;
-    int32_t* h_express_left_ = nullptr; int32_t* dh_express_left_ = nullptr;   // [0] left flag, [1] sequence word
+    int32_t* h_express_left_ = nullptr; int32_t* dh_express_left_ = nullptr;   // [0] left flag, [1] sequence word (words of the lease)
     int32_t run_seq_ = 0;
     uint8_t* d_first_rows_ = nullptr;
     int build_in_emit_ = 1;   // env AMBI_BUILD_IN_EMIT=0: every image through the build kernel and HBM
@@ -767,48 +928,91 @@ class HipBackend : public Backend {
     bool emit_lds_tight_ = true;   // env AMBI_EMIT_LDS_TIGHT=0: the whole 160 KB / k share
     double avg_path_ = 0;
     int enum_threads_ = 256;  // threads per workgroup of the block-emission kernel (env AMBI_ENUM_THREADS: 256 / 512 / 1024)
+    bool debug_ = false;      // env AMBI_DEBUG: budgets and grids chosen; guard words of the direct path areas checked at wait()
 
+    // Everything this batch queued is complete when this returns: the caller's stream (only if a run is still in flight -- the
+    // stream must outlive its work) and every side stream of the lease, each synchronised EXPLICITLY (round 2 relied on
+    // hipFree's implicit device synchronisation and destroyed streams it had never synchronised).
+    void sync_all() {
+        if (!lease_) return;
+        if (inflight_) { (void)hipStreamSynchronize(stream_); inflight_ = false; }
+        for (auto& kind : lease_->side) for (hipStream_t s : kind) if (s) (void)hipStreamSynchronize(s);
+        for (hipStream_t s : lease_->slice_streams) (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+    }
+    // guard words around the pinned words the kernels write through (always) and around the path areas of the direct
+    // full-finish launch (AMBI_DEBUG); called with every stream idle
+    int check_guards(const char* when) {
+        if (!lease_) return 0;
+        int bad = 0;
+        for (int i = 0; i < 16; i++) bad += (lease_->h_words->guard_lo[i] != kGuardWord) + (lease_->h_words->guard_hi[i] != kGuardWord);
+        if (bad) fprintf(stderr, "ambigram_hip: GUARD: %d guard words around the pinned status words overwritten (%s)\n", bad, when);
+        if (debug_ && d_direct_cells_ && d_guard_bad_ && direct_slots_ > 0) {
+            int32_t n = 0;
+            hipLaunchKernelGGL(ambi_guard_check_kernel, dim3(direct_slots_), dim3(32), 0, nullptr, (const uint8_t*)d_direct_cells_, direct_stride_, direct_slots_, d_guard_bad_);
+            if (hipMemcpy(&n, d_guard_bad_, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess && n) {
+                fprintf(stderr, "ambigram_hip: GUARD: %d guard words around the path areas of the direct full-finish launch overwritten (%s)\n", n, when);
+                bad += n;
+                (void)hipMemset(d_guard_bad_, 0, sizeof(int32_t));
+            }
+        }
+        return bad;
+    }
     void free_all() {
-        void* ptrs[] = {d_units_, d_seg_cn_, d_juncs_, d_elems_, d_dags_, d_results_, d_ikeys_, d_icnt_, d_ilink_, d_ilvl_off_,
-                        d_icounter_, d_arena_, d_blk_off_, d_rows_, d_npending_, d_needed_, d_scratch_, d_scratch_off_, d_pack_off_, d_fallback_, d_blk_img_, d_blk_hdr_,
-                        d_ipos_, d_aavail_, d_acnt_, d_acbase_, d_achild_, d_stage_clk_, d_first_rows_, d_blocks_done_, d_anblk_, d_adepth_,
-                        d_all_bits_, d_all_off_, d_all_count_, d_inject_, d_inject_off_, d_refin_list_, d_refin_count_, d_direct_list_, d_direct_cells_, d_junc_ends_};
+        sync_all();
+        (void)check_guards("release");
+        // per-batch allocations outside the lease's blocks (--all bitmaps, stage profile)
+        void* ptrs[] = {d_all_bits_, d_all_off_, d_all_count_, d_stage_clk_};
         for (void* p : ptrs) if (p) (void)hipFree(p);
-        d_units_ = nullptr; d_seg_cn_ = nullptr; d_juncs_ = nullptr; d_elems_ = nullptr; d_dags_ = nullptr; d_results_ = nullptr;
-        d_ikeys_ = nullptr; d_icnt_ = nullptr; d_ilink_ = nullptr; d_ilvl_off_ = nullptr; d_icounter_ = nullptr; d_arena_ = nullptr;
-        d_blk_off_ = nullptr; d_rows_ = nullptr; d_npending_ = nullptr; d_needed_ = nullptr; d_scratch_ = nullptr; d_scratch_off_ = nullptr;
-        d_pack_off_ = nullptr; d_fallback_ = nullptr; d_blk_img_ = nullptr; d_blk_hdr_ = nullptr; d_ipos_ = nullptr; d_aavail_ = nullptr;
-        d_acnt_ = nullptr; d_acbase_ = nullptr; d_achild_ = nullptr; d_stage_clk_ = nullptr; d_first_rows_ = nullptr; d_blocks_done_ = nullptr; d_anblk_ = nullptr; d_adepth_ = nullptr;
-        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_inject_ = nullptr; d_inject_off_ = nullptr; all_bits_cap_ = 0; d_refin_list_ = nullptr; d_refin_count_ = nullptr; d_direct_list_ = nullptr; d_direct_cells_ = nullptr; d_junc_ends_ = nullptr;
-        if (h_npending_) (void)hipHostFree(h_npending_);
-        if (h_needed_) (void)hipHostFree(h_needed_);
-        if (h_express_left_) (void)hipHostFree(h_express_left_);
-        h_express_left_ = nullptr; dh_express_left_ = nullptr;
-        if (ev_express_) (void)hipEventDestroy(ev_express_);
-        ev_express_ = nullptr;
-        h_npending_ = nullptr; h_needed_ = nullptr;
-        for (auto& e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        evs_.clear();
-        for (auto st : side_) (void)hipStreamDestroy(st);
-        side_.clear();
-        if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-        ev_fork_ = nullptr;
-        for (auto e : ev_join_) (void)hipEventDestroy(e);
-        ev_join_.clear();
-        for (auto e : ev_stage_) (void)hipEventDestroy(e);
-        ev_stage_.clear();
-        if (back_stream_) (void)hipStreamDestroy(back_stream_);
-        if (full_stream_) (void)hipStreamDestroy(full_stream_);
-        if (first_stream_) (void)hipStreamDestroy(first_stream_);
-        first_stream_ = nullptr;
-        if (ev_first_) (void)hipEventDestroy(ev_first_);
-        if (ev_full_) (void)hipEventDestroy(ev_full_);
-        full_stream_ = nullptr; ev_first_ = ev_full_ = nullptr; direct_n_ = 0;
-        if (ev_plan_) (void)hipEventDestroy(ev_plan_);
-        ev_plan_ = nullptr;
-        if (ev_prep_) (void)hipEventDestroy(ev_prep_);
-        if (ev_back_) (void)hipEventDestroy(ev_back_);
-        back_stream_ = nullptr; ev_prep_ = ev_back_ = nullptr;
+        d_all_bits_ = nullptr; d_all_off_ = nullptr; d_all_count_ = nullptr; d_all_flags_ = nullptr; d_stage_clk_ = nullptr; all_bits_cap_ = 0;
+        d_units_ = nullptr; d_results_ = nullptr; d_arena_ = nullptr; d_direct_cells_ = nullptr; direct_n_ = 0;
+        if (lease_) {
+            Lease* L = lease_;
+            // what a large batch grew goes back to the device; small blocks stay with the lease for the next batch
+            if (L->d_block_bytes > kKeepBlock) { (void)hipFree(L->d_block); L->d_block = nullptr; L->d_block_bytes = 0; }
+            if (L->d_arena_bytes > kKeepArena) { (void)hipFree(L->d_arena); L->d_arena = nullptr; L->d_arena_bytes = 0; }
+            if (L->d_cells_bytes > kKeepCells) { (void)hipFree(L->d_cells); L->d_cells = nullptr; L->d_cells_bytes = 0; }
+            if (L->h_stage_bytes > kKeepStage) { (void)hipHostFree(L->h_stage); L->h_stage = nullptr; L->h_stage_bytes = 0; }
+            if (L->h_mail_bytes > kKeepMail) { (void)hipHostFree(L->h_mail); L->h_mail = nullptr; L->dh_mail = nullptr; L->h_mail_bytes = 0; }
+            lease_ = nullptr;
+            DevicePool::get().release(L);
+        }
+        stage_big_.clear(); stage_big_.shrink_to_fit();
+        mail_valid_ = false;
+    }
+
+    // Layout of the device block: [inputs, in the order of the staging image] [zero-filled: result blob, image headers, flags,
+    // counters] [working set].  pass 0 measures, pass 1 assigns the pointers.
+    struct Carver {
+        uint8_t* base; int64_t off = 0;
+        template <class T> void take(T** p, size_t count) {
+            if (base) *p = reinterpret_cast<T*>(base + off);
+            off = (off + (int64_t)((count ? count : 1) * sizeof(T)) + 255) & ~int64_t(255);
+        }
+    };
+    int64_t layout(uint8_t* base, const std::vector<int32_t>& direct_list) {
+        const HostBatch& H = hb();
+        const size_t U = H.units.size();
+        Carver c{base};
+        c.take(&d_units_, U); c.take(&d_seg_cn_, H.seg_cn.size()); c.take(&d_juncs_, H.juncs.size()); c.take(&d_junc_ends_, H.junc_ends.size());
+        c.take(&d_elems_, H.elems.size()); c.take(&d_scratch_off_, U); c.take(&d_direct_list_, direct_list.size()); c.take(&d_mail_off_, U);
+        c.take(&d_inject_, H.inject.size()); c.take(&d_inject_off_, H.inject.empty() ? 0 : 2 * U);
+        in_bytes_ = c.off;
+        zero_off_ = c.off;
+        c.take(&d_results_, (size_t)H.result_bytes); c.take(&d_blk_hdr_, U * 8); c.take(&d_fallback_, U);
+        c.take(&d_refin_count_, 1); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1);
+        zero_bytes_ = c.off - zero_off_;
+        c.take(&d_dags_, U);
+        c.take(&d_ikeys_, (size_t)H.ideal_slots); c.take(&d_icnt_, (size_t)H.ideal_slots); c.take(&d_ilink_, (size_t)H.ideal_slots * 4 + 8);
+        c.take(&d_ilvl_off_, U * (kMaxNodes + 3)); c.take(&d_icounter_, 2 * U); c.take(&d_ipos_, (size_t)H.ideal_slots);
+        c.take(&d_aavail_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_acnt_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_acbase_, (size_t)H.ideal_slots / 2 + U + 1);
+        c.take(&d_achild_, (size_t)H.ideal_slots * 4 + 8); c.take(&d_anblk_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_adepth_, (size_t)H.ideal_slots / 2 + 8);
+        c.take(&d_blk_off_, U + kMaxSlices + 1); c.take(&d_rows_, U); c.take(&d_needed_, kMaxSlices);
+        c.take(&d_scratch_, (size_t)H.scratch_ints + 8); c.take(&d_pack_off_, U + 1); c.take(&d_refin_list_, U);
+        c.take(&d_first_rows_, U * (size_t)(cfg_.first_budget > 0 ? cfg_.first_budget : 1) * kFirstRowStride);
+        const size_t img_stride = (size_t)std::max(block_lds_, ((160 * 1024) / 3) & ~15);   // (the budget per workgroup may be re-chosen after the first run)
+        c.take(&d_blk_img_, U * img_stride);
+        return c.off;
     }
 
   public:
@@ -828,78 +1032,40 @@ class HipBackend : public Backend {
         return 0;
     }
 
-    int upload(const HostBatch& hb, const EngineConfig& cfg) override {
+    int upload(const HostBatch& hb_in, const EngineConfig& cfg) override {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
-        if (uploaded_) { free_all(); uploaded_ = false; ran_ = false; general_path_ = -1; timed_runs_ = 0; }
+        if (uploaded_) { free_all(); uploaded_ = false; }   // a second upload replaces the first (every stream idle first)
+        ran_ = false; general_path_ = -1; timed_runs_ = 0; tuned_ = false; late_refusal_ = false; last_needed_ = 0;
         express_ = false;
-        shared_units_ = -1;   // a second upload replaces the first
-        hb_ = hb; cfg_ = cfg;
-        const size_t U = hb.units.size();
+        shared_units_ = -1;
+        hbp_ = &hb_in; cfg_ = cfg;
+        const HostBatch& H = hb();
+        const size_t U = H.units.size();
         int rc;
-        if ((rc = dalloc(&d_units_, U))) return rc;
-        if ((rc = dalloc(&d_seg_cn_, hb.seg_cn.size()))) return rc;
-        if ((rc = dalloc(&d_juncs_, hb.juncs.size()))) return rc;
-        if ((rc = dalloc(&d_junc_ends_, hb.junc_ends.size()))) return rc;
-        if ((rc = dalloc(&d_elems_, hb.elems.size()))) return rc;
-        if ((rc = dalloc(&d_dags_, U))) return rc;
-        if ((rc = dalloc(&d_results_, (size_t)hb.result_bytes))) return rc;
-        if ((rc = dalloc(&d_ikeys_, (size_t)hb.ideal_slots))) return rc;
-        if ((rc = dalloc(&d_icnt_, (size_t)hb.ideal_slots))) return rc;
-        if ((rc = dalloc(&d_ilink_, (size_t)hb.ideal_slots * 4 + 8))) return rc;
-        if ((rc = dalloc(&d_ilvl_off_, U * (kMaxNodes + 3)))) return rc;
-        if ((rc = dalloc(&d_icounter_, 2 * U))) return rc;
-        if ((rc = dalloc(&d_ipos_, (size_t)hb.ideal_slots))) return rc;
-        if ((rc = dalloc(&d_aavail_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
-        if ((rc = dalloc(&d_acnt_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
-        if ((rc = dalloc(&d_acbase_, (size_t)hb.ideal_slots / 2 + U + 1))) return rc;
-        if ((rc = dalloc(&d_achild_, (size_t)hb.ideal_slots * 4 + 8))) return rc;
-        if ((rc = dalloc(&d_anblk_, (size_t)hb.ideal_slots / 2 + 1))) return rc;
-        if ((rc = dalloc(&d_adepth_, (size_t)hb.ideal_slots / 2 + 8))) return rc;
-        if ((rc = dalloc(&d_blk_off_, U + kMaxSlices + 1))) return rc;
-        if ((rc = dalloc(&d_rows_, U))) return rc;
-        if ((rc = dalloc(&d_npending_, 1))) return rc;
-        if ((rc = dalloc(&d_needed_, kMaxSlices))) return rc;
-        if ((rc = dalloc(&d_scratch_, (size_t)hb.scratch_ints + 8))) return rc;
-        if ((rc = dalloc(&d_scratch_off_, U))) return rc;
-        if ((rc = dalloc(&d_pack_off_, U + 1))) return rc;
-        if ((rc = dalloc(&d_fallback_, U))) return rc;
+        debug_ = getenv("AMBI_DEBUG") != nullptr;
+        if ((rc = DevicePool::get().acquire(&lease_))) return rc;
+        Lease* L = lease_;
+        h_npending_ = &L->h_words->npending; h_needed_ = L->h_words->needed;
+        dh_npending_ = &L->dh_words->npending; dh_needed_ = L->dh_words->needed;
+        h_express_left_ = &L->h_words->express_left; dh_express_left_ = &L->dh_words->express_left;
+        L->h_words->npending = 0; L->h_words->express_left = 1; L->h_words->late_flag = 0;
+        ev_fork_ = L->ev_fork; ev_prep_ = L->ev_prep; ev_back_ = L->ev_back; ev_first_ = L->ev_first; ev_full_ = L->ev_full; ev_plan_ = L->ev_plan; ev_express_ = L->ev_express;
         if (getenv("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
-        HIP_CK(hipHostMalloc((void**)&h_npending_, sizeof(int32_t)));
-        HIP_CK(hipHostMalloc((void**)&h_needed_, sizeof(int64_t) * kMaxSlices));
-        *h_npending_ = 0;
-        dh_npending_ = nullptr; dh_needed_ = nullptr;
-        if (hipHostGetDevicePointer((void**)&dh_npending_, h_npending_, 0) != hipSuccess) dh_npending_ = nullptr;
-        if (hipHostGetDevicePointer((void**)&dh_needed_, h_needed_, 0) != hipSuccess) dh_needed_ = nullptr;
-        (void)hipGetLastError();
         { const char* e9 = getenv("AMBI_ORDER_ALIGN"); order_align_ = e9 ? atoi(e9) : 4096; if (order_align_ < 16 || (order_align_ & (order_align_ - 1))) order_align_ = 4096; }
-        arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
-        HIP_CK(hipMalloc((void**)&d_arena_, (size_t)arena_bytes_));
-        HIP_CK(hipMemcpy(d_units_, hb.units.data(), U * sizeof(UnitIn), hipMemcpyHostToDevice));
-        HIP_CK(hipMemcpy(d_seg_cn_, hb.seg_cn.data(), hb.seg_cn.size() * sizeof(double), hipMemcpyHostToDevice));
-        if (!hb.juncs.empty()) HIP_CK(hipMemcpy(d_juncs_, hb.juncs.data(), hb.juncs.size() * sizeof(Junction), hipMemcpyHostToDevice));
-        if (!hb.junc_ends.empty()) HIP_CK(hipMemcpy(d_junc_ends_, hb.junc_ends.data(), hb.junc_ends.size() * sizeof(JuncEnds), hipMemcpyHostToDevice));
-        if (!hb.elems.empty()) HIP_CK(hipMemcpy(d_elems_, hb.elems.data(), hb.elems.size() * sizeof(Element), hipMemcpyHostToDevice));
-        HIP_CK(hipMemcpy(d_scratch_off_, hb.scratch_off.data(), U * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_CK(hipMemset(d_results_, 0, (size_t)hb.result_bytes));
         // LDS budgets (dynamic shared memory), sized for the largest unit of the batch
-        lds_prepare_ = (int)prepare_work_bytes(hb.max_n, hb.max_m, hb.max_k);
-        lds_first_ = (int)first_work_bytes(hb.max_n, hb.max_bkp);
+        lds_prepare_ = (int)prepare_work_bytes(H.max_n, H.max_m, H.max_k);
+        lds_first_ = (int)first_work_bytes(H.max_n, H.max_bkp);
         // the full finish stage keeps the path cells in LDS: as many as fit beside its other arrays (longer paths are
         // served by the lean stage alone)
-        finish_path_cells_ = hb.max_path < kPathLdsCells ? hb.max_path : kPathLdsCells;
-        while (finish_path_cells_ > 4096 && finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, finish_path_cells_, hb.max_out) > 160 * 1024 - 1024)
+        finish_path_cells_ = H.max_path < kPathLdsCells ? H.max_path : kPathLdsCells;
+        while (finish_path_cells_ > 4096 && finish_work_bytes(H.max_n, H.max_m, H.max_bkp, finish_path_cells_, H.max_out) > 160 * 1024 - 1024)
             finish_path_cells_ -= 2048;
-        lds_finish_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, finish_path_cells_, hb.max_out);
-        lds_finish_lean_ = (int)finish_lean_work_bytes(hb.max_n, hb.max_m, hb.max_bkp);
+        lds_finish_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, finish_path_cells_, H.max_out);
+        lds_finish_lean_ = (int)finish_lean_work_bytes(H.max_n, H.max_m, H.max_bkp);
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
-        if ((rc = dalloc(&d_blocks_done_, 1))) return rc;
-        if ((rc = dalloc(&d_refin_list_, U))) return rc;
-        if ((rc = dalloc(&d_refin_count_, 1))) return rc;
-        HIP_CK(hipMemset(d_refin_count_, 0, sizeof(int32_t)));
-        HIP_CK(hipMemset(d_blocks_done_, 0, sizeof(int32_t)));
-        enum_stack_lds_ = (int)enum_stack_bytes(hb.max_k > 0 ? hb.max_k : 1);
+        enum_stack_lds_ = (int)enum_stack_bytes(H.max_k > 0 ? H.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
         { const char* env = getenv("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
@@ -910,32 +1076,30 @@ class HipBackend : public Backend {
         { const char* env = getenv("AMBI_BLOCK_SCRATCH_LDS"); block_scratch_lds_ = ((env ? atoi(env) : cfg.block_scratch_lds) + 15) & ~15; }
         if (block_scratch_lds_ > kLdsLimit) block_scratch_lds_ = kLdsLimit & ~15;
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
-        if ((rc = dalloc(&d_blk_img_, U * (size_t)block_lds_))) return rc;
-        if ((rc = dalloc(&d_blk_hdr_, U * 8))) return rc;
-        HIP_CK(hipMemset(d_blk_hdr_, 0, U * 8 * sizeof(int32_t)));   // a header never written reads as "no image" (fits == 0)
-        HIP_CK(hipMemset(d_fallback_, 0, U * sizeof(int32_t)));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_blocks_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
             fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
                     lds_prepare_, lds_first_, lds_finish_);
             return ST_ERR_BAD_INPUT;
         }
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_ext_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_finish_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
+        {   // the dynamic-LDS ceiling of every kernel: a per-function, process-wide attribute, set once
+            static std::mutex mu; static uint64_t done = 0; hipError_t err = hipSuccess;   // (per device: one bit each)
+            std::lock_guard<std::mutex> lk(mu);
+            if (!((done >> (L->device & 63)) & 1ull)) {
+                done |= 1ull << (L->device & 63);
+                const void* fns[] = {(const void*)ambi_blocks_build_kernel, (const void*)ambi_prepare_kernel, (const void*)ambi_first_kernel, (const void*)ambi_resolve_kernel,
+                                     (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel,
+                                     (const void*)ambi_enumerate_kernel<0>, (const void*)ambi_enumerate_kernel<1>, (const void*)ambi_enumerate_kernel<2>,
+                                     (const void*)ambi_enumerate_blocks_kernel<0>, (const void*)ambi_enumerate_blocks_kernel<1>, (const void*)ambi_enumerate_blocks_kernel<2>,
+                                     (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
+                                     (const void*)ambi_all_lanes_kernel, (const void*)ambi_order_paths_kernel};
+                for (const void* f : fns) { hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic); if (e != hipSuccess) err = e; }
+            }
+            HIP_CK(err);
+        }
         enum_classes_ = 0;
-        for (const UnitIn& un : hb.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
+        for (const UnitIn& un : H.units) if (un.n_elem > 0) enum_classes_ |= 1 << enum_class_of(un.n_elem);
         avg_path_ = 0;
-        for (const UnitIn& un : hb.units) avg_path_ += un.path_cap;
+        for (const UnitIn& un : H.units) avg_path_ += un.path_cap;
         avg_path_ /= (double)(U > 0 ? U : 1);
         // slices: env AMBI_SLICES or the configuration; 0 = automatic (4 when the batch is large enough to fill the
         // chip four times over, else 1)
@@ -951,106 +1115,127 @@ class HipBackend : public Backend {
             slice_lo_.assign(n_slices_ + 1, 0);
             for (int s = 0; s <= n_slices_; s++) slice_lo_[s] = (int)((int64_t)U * s / n_slices_);
             slice_base_.assign(n_slices_, 0); slice_bytes_.assign(n_slices_, 0);
-            for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(order_align_ - 1); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(order_align_ - 1); }
-            for (int s = 1; s < n_slices_; s++) { hipStream_t st; HIP_CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); side_.push_back(st); }
-            HIP_CK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-            for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_join_.push_back(e); }
-            for (int s = 1; s < n_slices_; s++) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_stage_.push_back(e); }
+            // (streams and events of the slices belong to the lease: created once, reused by every later batch)
+            while ((int)L->slice_streams.size() < n_slices_ - 1) { hipStream_t st; HIP_CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); L->slice_streams.push_back(st); }
+            while ((int)L->slice_events.size() < 2 * (n_slices_ - 1)) { hipEvent_t e; HIP_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); L->slice_events.push_back(e); }
+            side_.assign(L->slice_streams.begin(), L->slice_streams.begin() + (n_slices_ - 1));
+            ev_join_.assign(L->slice_events.begin(), L->slice_events.begin() + (n_slices_ - 1));
+            ev_stage_.assign(L->slice_events.begin() + (n_slices_ - 1), L->slice_events.begin() + 2 * (n_slices_ - 1));
             { const char* e2 = getenv("AMBI_STAGGER"); stagger_ = e2 ? atoi(e2) != 0 : true; }
             { const char* e4 = getenv("AMBI_ENUM_THREADS"); enum_threads_ = e4 ? atoi(e4) : 256; if (enum_threads_ != 512 && enum_threads_ != 1024) enum_threads_ = 256; }
             { const char* e3 = getenv("AMBI_ENUM_GRID"); enum_grid_ = e3 ? atoi(e3) : 16384; if (enum_grid_ < 1) enum_grid_ = 1; }   // >= work blocks: one block per workgroup, the rest exit (measured: 2048 -> 16384 workgroups = -8 % kernel time)
         }
-        // first orders of every unit, written by the prepare stage (takes the enumerate kernel off the critical path of the scan)
-        if ((rc = dalloc(&d_first_rows_, U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride))) return rc;
         { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e9 = getenv("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
+        back_stream_ = nullptr; full_stream_ = nullptr; first_stream_ = nullptr; direct_n_ = 0; d_direct_cells_ = nullptr; direct_slots_ = 0;
+        std::vector<int32_t> dl;
         if (want_overlap_ && n_slices_ == 1) {
             // the stream of the lean finish kernel: default dispatch priority (AMBI_BACK_PRIORITY=1: lowest, round 1's setting
             // -- with the scan out of the way early the finish kernels have the whole enumerate kernel to hide behind, and
             // holding them back only lengthens the tail after it: 1.185 -> 1.168 ms per step, four interleaved runs)
             { const char* e8 = getenv("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : false;
-              int least = 0, greatest = 0;
-              if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
-                  HIP_CK(hipStreamCreateWithPriority(&back_stream_, hipStreamNonBlocking, least));
-              } else {
-                  HIP_CK(hipStreamCreateWithFlags(&back_stream_, hipStreamNonBlocking));
-              } }
+              if ((rc = lease_stream(L, 0, low ? 1 : 0, &back_stream_))) return rc; }
             { const char* e = getenv("AMBI_FIRST_AHEAD"); first_ahead_ = e ? atoi(e) : 3; }
             // (direct full-stage launch: 512 threads with the path cells in device memory, 1024 with the cells in group memory --
             // measured, four interleaved runs: cells in group memory 1.151 ms per step; in device memory 256 / 512 / 1024
             // threads = 1.133 / 1.110 / 1.200)
             { const char* ee = getenv("AMBI_DIRECT_EXT"); direct_ext_ = ee ? atoi(ee) != 0 : true; }
             { const char* e = getenv("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : (direct_ext_ ? 512 : 1024); if (full_threads_ != 256 && full_threads_ != 512 && full_threads_ != 1024) full_threads_ = direct_ext_ ? 512 : 1024; }
-            if (first_ahead_ >= 2) {
-                int least = 0, greatest = 0;
-                if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&first_stream_, hipStreamNonBlocking, greatest)); }
-            }
-            HIP_CK(hipEventCreateWithFlags(&ev_plan_, hipEventDisableTiming));
-            HIP_CK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
-            HIP_CK(hipEventCreateWithFlags(&ev_back_, hipEventDisableTiming));
-            HIP_CK(hipEventCreateWithFlags(&ev_first_, hipEventDisableTiming));
-            HIP_CK(hipEventCreateWithFlags(&ev_full_, hipEventDisableTiming));
+            if (first_ahead_ >= 2) { if ((rc = lease_stream(L, 2, 2, &first_stream_))) return rc; }
             {   // units that go straight to the full finish stage (env AMBI_DIRECT_FULL=0: none, they pass through the lean stage first)
                 const char* e7 = getenv("AMBI_DIRECT_FULL"); const bool on = e7 ? atoi(e7) != 0 : true;
                 const char* e8 = getenv("AMBI_DIRECT_GRID"); direct_grid_ = e8 ? atoi(e8) : 1024; if (direct_grid_ < 1) direct_grid_ = 1;   // one workgroup per unit up to 1024 (measured: 64 / 128 / 256 / 512 workgroups for 512 units = 1.63 / 1.37 / 1.25 / 1.23 ms per step; without this launch 1.30)
-                std::vector<int32_t> dl;
-                if (on && lean_finish_) for (size_t u2 = 0; u2 < U; u2++) if (hb.units[u2].direct_full) dl.push_back((int32_t)u2);
+                if (on && lean_finish_) for (size_t u2 = 0; u2 < U; u2++) if (H.units[u2].direct_full) dl.push_back((int32_t)u2);
                 direct_n_ = (int)dl.size();
                 if (direct_n_ > 0) {
-                    if ((rc = dalloc(&d_direct_list_, dl.size()))) return rc;
-                    HIP_CK(hipMemcpy(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-                    if (direct_ext_) {   // one path area per unit of the list in device memory
-                        direct_stride_ = (2ll * hb.max_path + 16 + 15) & ~int64_t(15);
-                        const int64_t slots = (int64_t)dl.size() < direct_grid_ ? (int64_t)dl.size() : direct_grid_;   // one per workgroup of the launch
-                        if ((rc = dalloc(&d_direct_cells_, (size_t)(direct_stride_ * slots)))) return rc;
-                        lds_finish_ext_ = (int)finish_work_bytes(hb.max_n, hb.max_m, hb.max_bkp, 0, hb.max_out);
-                    }
-                    int least = 0, greatest = 0;
-                    // the direct full-finish stream: default priority.  Lowest priority (AMBI_FULL_PRIORITY=1, the setting until late in round 2) was
-                    // a few per cent faster on some boxes, but a long soak with it shows rare stray writes into HOST memory of the process
-                    // (profiles/r02_notes.md, "Open defect"); not seen so far at default priority.  Cause NOT established -- this is a workaround.
+                    // the direct full-finish stream: default priority, or the lowest (AMBI_FULL_PRIORITY=1: a few per cent on some
+                    // boxes).  The stream belongs to the lease and is never destroyed -- with round 2's per-batch create / destroy of
+                    // this priority stream a long soak showed stray writes into host memory.
                     const char* e9 = getenv("AMBI_FULL_PRIORITY"); const bool low_full = e9 ? atoi(e9) != 0 : false;
-                    if (low_full && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) { HIP_CK(hipStreamCreateWithPriority(&full_stream_, hipStreamNonBlocking, least)); }
-                    else HIP_CK(hipStreamCreateWithFlags(&full_stream_, hipStreamNonBlocking));
+                    if ((rc = lease_stream(L, 1, low_full ? 1 : 0, &full_stream_))) return rc;
+                    if (direct_ext_) lds_finish_ext_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, 0, H.max_out);
                 }
             }
             // AMBI_ENUM_LDS_FLOOR (experiments): make the enumerate kernel ask for more LDS than its image needs, i.e. fewer
             // of its workgroups per CU.  Measured (profiles/r01_slices.md): no floor is best -- the scan / finish
             // workgroups slip in as enumerate workgroups retire.
             { const char* e6 = getenv("AMBI_ENUM_LDS_FLOOR"); const int floor_lds = e6 ? atoi(e6) : 0; if (lds_blocks_ < floor_lds && floor_lds <= kLdsLimit) lds_blocks_ = floor_lds; }
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_enumerate_blocks_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-        }
-        if (!hb.inject.empty()) {   // diagnostics hook: verdict overrides (ambi_batch_debug_inject_validity)
-            if ((rc = dalloc(&d_inject_, hb.inject.size()))) return rc;
-            if ((rc = dalloc(&d_inject_off_, 2 * U))) return rc;
-            HIP_CK(hipMemcpy(d_inject_, hb.inject.data(), hb.inject.size(), hipMemcpyHostToDevice));
-            HIP_CK(hipMemcpy(d_inject_off_, hb.inject_off.data(), 2 * U * sizeof(int64_t), hipMemcpyHostToDevice));
         }
         {   // express path: small batches only, and only if a unit's whole working set fits one workgroup's group memory
             const char* e9 = getenv("AMBI_EXPRESS_UNITS"); express_units_ = e9 ? atoi(e9) : 32;
-            lds_express_ = (int)express_work_bytes(hb.max_n, hb.max_m, hb.max_k, hb.max_bkp, finish_path_cells_, hb.max_out) + 64;
+            lds_express_ = (int)express_work_bytes(H.max_n, H.max_m, H.max_k, H.max_bkp, finish_path_cells_, H.max_out) + 64;
             lds_lattice_ = (int)(64 * 8 + kPrepLatticeBytes + 64);
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_express_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
-            if (!ev_express_) HIP_CK(hipEventCreateWithFlags(&ev_express_, hipEventDisableTiming));
-            if (!h_express_left_) {
-                HIP_CK(hipHostMalloc((void**)&h_express_left_, 2 * sizeof(int32_t)));
-                h_express_left_[0] = 1; h_express_left_[1] = 0;
-                if (hipHostGetDevicePointer((void**)&dh_express_left_, h_express_left_, 0) != hipSuccess) dh_express_left_ = nullptr;
-                (void)hipGetLastError();
-            }
+        }
+        // result mailbox in pinned host memory: batches that can take the express path, while the slots stay small
+        mail_off_.assign(U, 0); mail_bytes_ = 0; mail_on_ = false; mail_valid_ = false;
+        if ((int)U <= express_units_ && n_slices_ == 1) {
+            for (size_t u2 = 0; u2 < U; u2++) { mail_off_[u2] = mail_bytes_; mail_bytes_ += mail_layout(H.units[u2].path_cap, H.units[u2].out_cap).total; }
+            mail_on_ = mail_bytes_ <= kKeepMail;
+            if (mail_on_ && (rc = lease_pinned_block(&L->h_mail, &L->dh_mail, &L->h_mail_bytes, mail_bytes_))) return rc;
+        }
+        // ---- the device block and the input image ----
+        const int64_t total = layout(nullptr, dl);
+        if ((rc = lease_device_block(&L->d_block, &L->d_block_bytes, total))) return rc;
+        (void)layout(L->d_block, dl);
+        if (H.inject.empty()) { d_inject_ = nullptr; d_inject_off_ = nullptr; }
+        if (dl.empty()) d_direct_list_ = nullptr;
+        if (direct_n_ > 0 && direct_ext_) {   // one path area per workgroup of the direct launch, guard words on both sides of each
+            direct_stride_ = ((2ll * H.max_path + 16 + 15) & ~int64_t(15)) + 2 * kCellGuardBytes;
+            direct_slots_ = direct_n_ < direct_grid_ ? direct_n_ : direct_grid_;
+            if ((rc = lease_device_block(&L->d_cells, &L->d_cells_bytes, direct_stride_ * direct_slots_))) return rc;
+            d_direct_cells_ = L->d_cells;
+        }
+        arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
+        { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); const bool capped = cap && atoll(cap) > 0;
+          // a configured size or a memory budget is taken literally; otherwise whatever the lease already holds is used
+          if (cfg.order_arena_bytes <= 0 && !capped && L->d_arena_bytes > arena_bytes_) arena_bytes_ = L->d_arena_bytes;
+          if (capped && arena_bytes_ > atoll(cap)) arena_bytes_ = atoll(cap); }
+        if ((rc = lease_device_block(&L->d_arena, &L->d_arena_bytes, arena_bytes_))) return rc;
+        d_arena_ = L->d_arena;
+        for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(order_align_ - 1); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(order_align_ - 1); }
+        // input image: same layout as the front of the device block; pinned staging (one asynchronous copy, queued by the
+        // first run ahead of its kernels) or, for large batches, a plain buffer copied at once
+        uint8_t* img;
+        const bool pinned = in_bytes_ <= kKeepStage;
+        if (pinned) { if ((rc = lease_pinned_block(&L->h_stage, nullptr, &L->h_stage_bytes, in_bytes_))) return rc; img = L->h_stage; }
+        else { stage_big_.assign((size_t)in_bytes_, 0); img = stage_big_.data(); }
+        auto put = [&](const void* dptr, const void* src, size_t bytes) { if (bytes) memcpy(img + (reinterpret_cast<const uint8_t*>(dptr) - L->d_block), src, bytes); };
+        put(d_units_, H.units.data(), U * sizeof(UnitIn));
+        put(d_seg_cn_, H.seg_cn.data(), H.seg_cn.size() * sizeof(double));
+        put(d_juncs_, H.juncs.data(), H.juncs.size() * sizeof(Junction));
+        put(d_junc_ends_, H.junc_ends.data(), H.junc_ends.size() * sizeof(JuncEnds));
+        put(d_elems_, H.elems.data(), H.elems.size() * sizeof(Element));
+        put(d_scratch_off_, H.scratch_off.data(), U * sizeof(int64_t));
+        if (!dl.empty()) put(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t));
+        put(d_mail_off_, mail_off_.data(), U * sizeof(int64_t));
+        if (!H.inject.empty()) { put(d_inject_, H.inject.data(), H.inject.size()); put(d_inject_off_, H.inject_off.data(), 2 * U * sizeof(int64_t)); }
+        if (pinned) upload_pending_ = true;
+        else {
+            HIP_CK(hipMemcpy(L->d_block, img, (size_t)in_bytes_, hipMemcpyHostToDevice));
+            HIP_CK(hipMemset(L->d_block + zero_off_, 0, (size_t)zero_bytes_));
+            if (d_direct_cells_) { hipLaunchKernelGGL(ambi_guard_fill_kernel, dim3(direct_slots_), dim3(32), 0, nullptr, d_direct_cells_, direct_stride_, direct_slots_); HIP_CK(hipDeviceSynchronize()); }
+            stage_big_.clear(); stage_big_.shrink_to_fit();
+            upload_pending_ = false;
         }
         uploaded_ = true; arena_checked_ = false;
+        return 0;
+    }
+    // the input image and the zero fill of a freshly uploaded batch, queued on the caller's stream ahead of the first kernels
+    int flush_upload(hipStream_t st) {
+        if (!upload_pending_) return 0;
+        Lease* L = lease_;
+        HIP_CK(hipMemcpyAsync(L->d_block, L->h_stage, (size_t)in_bytes_, hipMemcpyHostToDevice, st));
+        HIP_CK(hipMemsetAsync(L->d_block + zero_off_, 0, (size_t)zero_bytes_, st));
+        if (d_direct_cells_) hipLaunchKernelGGL(ambi_guard_fill_kernel, dim3(direct_slots_), dim3(32), 0, st, d_direct_cells_, direct_stride_, direct_slots_);
+        upload_pending_ = false;
         return 0;
     }
 
     // whole-batch argument block (pack kernels, slow path); slice_args() narrows it to one slice
     void bind(uint32_t flags) {
-        A_.n_units = (int32_t)hb_.units.size(); A_.unit_base = 0; A_.arena_base = 0;
+        A_.n_units = (int32_t)hb().units.size(); A_.unit_base = 0; A_.arena_base = 0;
         A_.flags = flags; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
         A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.emit_interleave = emit_interleave_; A_.order_align = order_align_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
@@ -1064,6 +1249,8 @@ class HipBackend : public Backend {
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
+        A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
+        A_.plan_seq = &lease_->dh_words->plan_seq; A_.late_flag = &lease_->dh_words->late_flag; A_.run_seq = run_seq_;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = getenv("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
     }
     BatchArgs slice_args(int s) const {
@@ -1085,13 +1272,13 @@ class HipBackend : public Backend {
         if (!timing_ || !((timing_mask_ >> idx) & 1u)) return;
         const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
         const size_t at = (slot * n_slices_ + slice) * kTimedKernels + idx;
-        while (evs_.size() <= at) {
+        while (evs().size() <= at) {
             Ev e{name, nullptr, nullptr};
             (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
-            evs_.push_back(e);
+            evs().push_back(e);
         }
-        evs_[at].name = name;
-        (void)hipEventRecord(begin ? evs_[at].a : evs_[at].b, on == (hipStream_t)-1 ? slice_stream(slice) : on);
+        evs()[at].name = name;
+        (void)hipEventRecord(begin ? evs()[at].a : evs()[at].b, on == (hipStream_t)-1 ? slice_stream(slice) : on);
     }
 
     void fork() {   // the side streams start behind everything already queued on the caller's stream
@@ -1116,7 +1303,7 @@ class HipBackend : public Backend {
             Ax.refin_list = nullptr;
             Ax.express_left = dh_express_left_;
             Ax.express_seq = dh_express_left_ + 1;
-            Ax.run_seq = ++run_seq_;
+            Ax.run_seq = run_seq_;
             h_express_left_[0] = 0;
             tick("ambi_express_kernel", s, 0, true);
             hipLaunchKernelGGL(ambi_express_kernel, dim3(A.n_units), dim3(256), lds_express_, st, Ax);
@@ -1168,7 +1355,7 @@ class HipBackend : public Backend {
         if (finish_grid_ > 0) return U < finish_grid_ ? U : finish_grid_;          // env AMBI_FINISH_GRID
         if (!overlap_back_) return U;
         const double enum_us = (double)last_needed_ / 5.2e6;                        // order-table bytes of the previous run at an optimistic 5.2 TB/s
-        const double unit_us = 4.0 + avg_path_ / 900.0 + hb_.max_m / 64.0;          // one unit through the lean finish stage (mean path capacity of the batch)
+        const double unit_us = 4.0 + avg_path_ / 900.0 + hb().max_m / 64.0;          // one unit through the lean finish stage (mean path capacity of the batch)
         if (enum_us < 8.0 * unit_us) return U;
         // (measured with the SV-carrying bench batch, 40 KB images: 160 / 192 / 256 / 320 workgroups = 1.24 / 1.17 / 1.20 / 1.24 ms
         // per step, profiles/r02_notes.md; the rule lands on 192 there)
@@ -1222,7 +1409,7 @@ class HipBackend : public Backend {
             int lds_direct = lds_finish_;
             if (direct_cells_ > 0 && direct_cells_ < finish_path_cells_) {
                 Ad.finish_path_cells = direct_cells_; Ad.finish_retry = 1;
-                lds_direct = (int)finish_work_bytes(hb_.max_n, hb_.max_m, hb_.max_bkp, direct_cells_, hb_.max_out);
+                lds_direct = (int)finish_work_bytes(hb().max_n, hb().max_m, hb().max_bkp, direct_cells_, hb().max_out);
             }
             direct_retry_ = Ad.finish_retry != 0;
             if (direct_ext_ && d_direct_cells_) {   // path cells in device memory: a 13 KB workgroup that fits where a lean one fits
@@ -1234,12 +1421,12 @@ class HipBackend : public Backend {
         }
         tick("ambi_finish_kernel", s, 5, true, sb);
         const int fgrid = finish_grid_for(U);
-        if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d\n", fgrid, block_lds_);
+        if (debug_) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d\n", fgrid, block_lds_);
         if (lean_finish_) {
             hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
             // device (an empty list costs one launch of workgroups that exit at once)
-            if (hb_.any_sv) {
+            if (hb().any_sv) {
                 if (direct_retry_ && direct_n_ > 0 && overlap_back_ && full_stream_) (void)hipStreamWaitEvent(sb, ev_full_, 0);   // the direct launch may add to the list
                 hipLaunchKernelGGL(ambi_finish_kernel, dim3(U < 256 ? U : 256), dim3(256), lds_finish_, sb, A, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_, -1);   // (at most one such workgroup fits a CU: more than 256 gain nothing)
             }
@@ -1251,17 +1438,25 @@ class HipBackend : public Backend {
         }
     }
 
+    // Everything of one run, queued on the caller's stream and the lease's side streams.  The FIRST run of a batch takes what
+    // arena the lease has: the plan kernel reports what the tables need, and wait() grows the arena and runs the batch again
+    // if that was not enough (round 2 ran prepare + plan, synchronised, sized the arena and only then queued the run --
+    // two host round trips in front of every fresh batch).  AMBI_SLICES > 1 (an experiment) keeps the sizing pass.
     int run(uint32_t flags, void* stream) override {
         if (!uploaded_) return -32;
+        if (ran_ && !tuned_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
+        if (int rc = flush_upload(stream_)) return rc;
+        run_seq_ = ++lease_->seq;
+        mail_valid_ = false;
         bind(flags);
         all_done_ = false;
         const int U = A_.n_units;
-        // one slice, arena sized: no copy commands around the kernels (see BatchArgs::zero_pending)
-        const bool direct = arena_checked_ && n_slices_ == 1 && dh_npending_ && dh_needed_;
+        // one slice: no copy commands around the kernels (see BatchArgs::zero_pending)
+        const bool direct = n_slices_ == 1 && dh_npending_ && dh_needed_;
         if (!direct) { HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_)); HIP_CK(hipMemsetAsync(d_refin_count_, 0, sizeof(int32_t), stream_)); }
-        if (!arena_checked_) {
-            // first run of this batch: size the arena regions of the slices from what their order tables need
+        if (!arena_checked_ && n_slices_ > 1) {
+            // first run of a sliced batch: size the arena regions of the slices from what their order tables need
             for (int s = 0; s < n_slices_; s++) launch_front(0, slice_args(s));   // all on the caller's stream
             HIP_CK(hipGetLastError());
             HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
@@ -1273,29 +1468,16 @@ class HipBackend : public Backend {
                 total += slice_bytes_[s];
             }
             if (total > arena_bytes_) {
-                // the new arena first, the old one goes only when that worked: a failed growth leaves the batch as it was,
-                // and the units whose tables do not fit the old arena end with ORDERS_CAPACITY (plan kernel), one by one.
-                // AMBI_ARENA_MAX_BYTES: an upper limit for the arena (a memory budget; the tests use it to reach this path)
-                int64_t want = total;
-                { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }
-                uint8_t* fresh = nullptr;
-                if (want > arena_bytes_ && hipMalloc((void**)&fresh, (size_t)want) == hipSuccess) {
-                    (void)hipFree(d_arena_);
-                    d_arena_ = fresh;
-                    arena_bytes_ = want;
-                } else if (want > arena_bytes_) (void)hipGetLastError();
-                if (arena_bytes_ < total) {
-                    fprintf(stderr, "ambigram_hip: order-table arena of %lld bytes not available; keeping %lld bytes (units beyond it report ORDERS_CAPACITY)\n",
-                            (long long)total, (long long)arena_bytes_);
+                (void)grow_arena(total);
+                if (arena_bytes_ < total)
                     for (int s = 0; s < n_slices_; s++) { slice_base_[s] = (arena_bytes_ / n_slices_ * s) & ~int64_t(order_align_ - 1); slice_bytes_[s] = (arena_bytes_ / n_slices_) & ~int64_t(order_align_ - 1); }
-                }
                 bind(flags);
             }
             arena_checked_ = true;
         }
-        overlap_back_ = want_overlap_ && back_stream_ != nullptr && arena_checked_ && n_slices_ == 1;
+        overlap_back_ = want_overlap_ && back_stream_ != nullptr && n_slices_ == 1;
         A_.direct_full_on = (overlap_back_ && direct_n_ > 0 && full_stream_ != nullptr) ? 1 : 0;
-        express_ = arena_checked_ && n_slices_ == 1 && U <= express_units_ && lds_express_ <= kLdsMaxDynamic && dh_express_left_ != nullptr && direct;
+        express_ = n_slices_ == 1 && U <= express_units_ && lds_express_ <= kLdsMaxDynamic && dh_express_left_ != nullptr && direct;
         if (direct) { A_.zero_pending = 1; A_.host_pending = dh_npending_; A_.host_needed = dh_needed_; }
         // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
         // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
@@ -1317,8 +1499,118 @@ class HipBackend : public Backend {
             HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
             HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
         }
-        ran_ = true;
+        ran_ = true; inflight_ = true;
         if (timing_) timed_runs_++;
+        return 0;
+    }
+    // A larger arena: the new one first, the old one goes only when that worked -- a failed growth leaves the batch as it was,
+    // and the units whose tables do not fit the old arena end with ORDERS_CAPACITY (plan kernel), one by one.
+    // AMBI_ARENA_MAX_BYTES: an upper limit for the arena (a memory budget; the tests use it to reach this path).  Every stream idle.
+    bool grow_arena(int64_t total) {
+        int64_t want = total;
+        { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }
+        bool grown = false;
+        uint8_t* fresh = nullptr;
+        want = (want + 4095) & ~int64_t(4095);
+        if (want > arena_bytes_ && hipMalloc((void**)&fresh, (size_t)want) == hipSuccess) {
+            (void)hipFree(lease_->d_arena);
+            lease_->d_arena = fresh; lease_->d_arena_bytes = want;
+            d_arena_ = fresh; arena_bytes_ = want;
+            grown = true;
+        } else if (want > arena_bytes_) (void)hipGetLastError();
+        if (arena_bytes_ < total)
+            fprintf(stderr, "ambigram_hip: order-table arena of %lld bytes not available; keeping %lld bytes (units beyond it report ORDERS_CAPACITY)\n",
+                    (long long)total, (long long)arena_bytes_);
+        return grown;
+    }
+    // the first complete run of a batch (every stream idle): did its tables fit the arena the lease had?
+    int settle_first_run() {
+        if (arena_checked_) return 0;
+        arena_checked_ = true;
+        if (n_slices_ != 1) return 0;
+        const int64_t need = h_needed_[0];
+        if (need > arena_bytes_) {
+            const int64_t total = (need + (need >> 4) + 4096 + order_align_ - 1) & ~int64_t(order_align_ - 1);
+            if (grow_arena(total)) {   // the whole batch again, now with room for every table (prepare resets what the first pass refused)
+                slice_base_[0] = 0; slice_bytes_[0] = arena_bytes_ & ~int64_t(order_align_ - 1);
+                lease_->h_words->late_flag = 0;
+                ran_ = false;   // (the run below is still this batch's FIRST complete one: nothing is tuned from the refused pass)
+                const bool t = timing_; timing_ = false;
+                int rc = run(A_.flags, (void*)stream_);
+                timing_ = t;
+                if (rc) return rc;
+                HIP_CK(hipStreamSynchronize(stream_));
+                inflight_ = false;
+            }
+        }
+        return 0;
+    }
+    // Launch parameters that depend on what the first run found (the batch is resident and immutable): which units need the
+    // general enumerate kernel, whether any table is shared by several workgroups, the group-memory budget of the emission
+    // workgroups.  Called before the SECOND run: a batch that is run once (one sample through the CLI) never pays for it.
+    int tune_after_first_run() {
+        if (int rc = wait()) return rc;
+        tuned_ = true;
+        {
+            std::vector<int32_t> fb(hb().units.size());
+            HIP_CK(hipMemcpy(fb.data(), d_fallback_, fb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            general_path_ = 0;
+            for (int32_t f : fb) general_path_ += f != 0;
+            if (direct_n_ > 0) {
+                // Path area of the direct full-finish launch.  Default: the capacity bound of the batch (82 KB of group memory
+                // per workgroup on the bench batch, one per CU).  AMBI_DIRECT_CELLS=n: n cells, -1: what the paths of these
+                // units needed in this first run plus a quarter (53 KB there, three per CU; longer paths then go through the
+                // list kernel) -- measured SLOWER, 1.18 vs 1.155 ms per step: more of these 16-wave workgroups get onto the
+                // CUs while the table is being written and take the places of enumerate workgroups.
+                const char* e = getenv("AMBI_DIRECT_CELLS");
+                direct_cells_ = e ? atoi(e) : 0;
+                if (direct_cells_ < 0) {
+                    std::vector<UnitOut> hdr(hb().units.size());
+                    HIP_CK(hipMemcpy(hdr.data(), d_results_, hdr.size() * sizeof(UnitOut), hipMemcpyDeviceToHost));
+                    int mx = 0;
+                    for (size_t u2 = 0; u2 < hdr.size(); u2++)
+                        if (hb().units[u2].direct_full) { mx = std::max(mx, hdr[u2].path_len); mx = std::max(mx, hdr[u2].path_indel_len); }
+                    direct_cells_ = mx > 0 ? ((mx + mx / 4 + 256 + 2047) & ~2047) : 0;
+                }
+            }
+            // ... and whether any unit's table is shared by several workgroups (only those go through the build kernel
+            // when single-block units build their image in the enumerate workgroup): if none, later runs do not launch it
+            if (n_slices_ == 1) {
+                std::vector<int64_t> bo(hb().units.size() + 1);
+                HIP_CK(hipMemcpy(bo.data(), d_blk_off_, bo.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+                shared_units_ = 0;
+                for (size_t u2 = 0; u2 + 1 < bo.size(); u2++) shared_units_ += (bo[u2 + 1] - bo[u2] > 1) ? 1 : 0;
+                // Group memory per enumerate workgroup for the runs to come.  k workgroups share a CU's 160 KB and its store
+                // bandwidth, so W work blocks take about ceil(W / (CUs * k)) * k "slot rounds": pick the k in 3..5 with the
+                // fewest, among those whose budget 160 KB / k still holds every image of this batch (measured on the bench
+                // batch, 4096 work blocks on 256 CUs: k = 3 (48 KB) 0.92-0.95 ms, k = 4 (40 KB) 0.86-0.87 ms).
+                if (emit_lds_auto_ && general_path_ == 0 && bo.back() > 0) {
+                    std::vector<int32_t> hd(hb().units.size() * 8);
+                    HIP_CK(hipMemcpy(hd.data(), d_blk_hdr_, hd.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                    int need = 0;
+                    for (size_t u2 = 0; u2 < hb().units.size(); u2++) if (hd[8 * u2] > 0 && hd[8 * u2 + 3] > need) need = hd[8 * u2 + 3];
+                    int ncu = 256;
+                    { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+                    const int64_t W = bo.back();
+                    int best_k = 0; int64_t best = 0;
+                    for (int k = 3; k <= 5; k++) {
+                        const int budget = ((160 * 1024) / k) & ~15;
+                        if (need <= 0 || need > budget) continue;
+                        const int64_t rounds = ((W + (int64_t)ncu * k - 1) / ((int64_t)ncu * k)) * k;
+                        if (!best_k || rounds < best) { best_k = k; best = rounds; }
+                    }
+                    if (debug_) fprintf(stderr, "ambigram_hip: image need %d bytes, %lld work blocks on %d CUs -> %d workgroups per CU\n", need, (long long)W, ncu, best_k);
+                    // ... and ask for no more than the images need (512-byte granules): what the k enumerate workgroups leave of
+                    // the CU's group memory is where the scan / finish workgroups run WITHOUT pushing an enumerate workgroup out
+                    if (best_k) {
+                        block_lds_ = ((160 * 1024) / best_k) & ~15;
+                        const int tight = (need + 511) & ~511;
+                        if (emit_lds_tight_ && tight < block_lds_) block_lds_ = tight;
+                        lds_blocks_ = block_lds_;
+                    }
+                }
+            }
+        }
         return 0;
     }
 
@@ -1346,14 +1638,14 @@ class HipBackend : public Backend {
         for (int p = 0; p < np; p++) coff[p + 1] = coff[p] + (hdr[pend[p]].num_orders + chunk - 1) / chunk;
         std::vector<int32_t> fin(pend);
         fin.insert(fin.end(), refin.begin(), refin.end());
-        int32_t* d_pend; int64_t* d_coff; SearchSlot* d_slots;
-        HIP_CK(hipMalloc((void**)&d_pend, nfin * sizeof(int32_t)));
-        HIP_CK(hipMalloc((void**)&d_coff, (np + 1) * sizeof(int64_t)));
-        HIP_CK(hipMalloc((void**)&d_slots, (np + 1) * sizeof(SearchSlot)));
+        DevBuf b_pend, b_coff, b_slots;
+        HIP_CK(b_pend.alloc(nfin * sizeof(int32_t)));
+        HIP_CK(b_coff.alloc((np + 1) * sizeof(int64_t)));
+        HIP_CK(b_slots.alloc((np + 1) * sizeof(SearchSlot)));
+        int32_t* d_pend = b_pend.as<int32_t>(); int64_t* d_coff = b_coff.as<int64_t>(); SearchSlot* d_slots = b_slots.as<SearchSlot>();
         HIP_CK(hipMemcpy(d_pend, fin.data(), nfin * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_CK(hipMemcpy(d_coff, coff.data(), (np + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         int waves = (4 * lds_first_ <= 150 * 1024) ? 4 : 1;
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         bool fwd = !(A_.flags & FLAG_REVERSED);
         // both passes are queued back to back: a unit resolved by pass 0 is skipped by pass 1 (its status is no longer PENDING)
         for (int pass = 0; pass < 2 && np > 0; pass++) {
@@ -1370,75 +1662,18 @@ class HipBackend : public Backend {
         hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend, (const int32_t*)nullptr, -1);
         HIP_CK(hipGetLastError());
         HIP_CK(hipStreamSynchronize(stream_));
-        (void)hipFree(d_pend); (void)hipFree(d_coff); (void)hipFree(d_slots);
         return 0;
     }
 
     int wait() override {
         if (!ran_) return 0;
         HIP_CK(hipStreamSynchronize(stream_));
+        inflight_ = false;
+        if (int rc = settle_first_run()) return rc;
+        if (check_guards("wait")) return -31;
         last_needed_ = 0;
-        if (general_path_ < 0) {   // the batch is resident and immutable: which units need the general enumerate kernel is known after one run
-            std::vector<int32_t> fb(hb_.units.size());
-            HIP_CK(hipMemcpy(fb.data(), d_fallback_, fb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-            general_path_ = 0;
-            for (int32_t f : fb) general_path_ += f != 0;
-            if (direct_n_ > 0) {
-                // Path area of the direct full-finish launch.  Default: the capacity bound of the batch (82 KB of group memory
-                // per workgroup on the bench batch, one per CU).  AMBI_DIRECT_CELLS=n: n cells, -1: what the paths of these
-                // units needed in this first run plus a quarter (53 KB there, three per CU; longer paths then go through the
-                // list kernel) -- measured SLOWER, 1.18 vs 1.155 ms per step: more of these 16-wave workgroups get onto the
-                // CUs while the table is being written and take the places of enumerate workgroups.
-                const char* e = getenv("AMBI_DIRECT_CELLS");
-                direct_cells_ = e ? atoi(e) : 0;
-                if (direct_cells_ < 0) {
-                    std::vector<UnitOut> hdr(hb_.units.size());
-                    HIP_CK(hipMemcpy(hdr.data(), d_results_, hdr.size() * sizeof(UnitOut), hipMemcpyDeviceToHost));
-                    int mx = 0;
-                    for (size_t u2 = 0; u2 < hdr.size(); u2++)
-                        if (hb_.units[u2].direct_full) { mx = std::max(mx, hdr[u2].path_len); mx = std::max(mx, hdr[u2].path_indel_len); }
-                    direct_cells_ = mx > 0 ? ((mx + mx / 4 + 256 + 2047) & ~2047) : 0;
-                }
-            }
-            // ... and whether any unit's table is shared by several workgroups (only those go through the build kernel
-            // when single-block units build their image in the enumerate workgroup): if none, later runs do not launch it
-            if (n_slices_ == 1) {
-                std::vector<int64_t> bo(hb_.units.size() + 1);
-                HIP_CK(hipMemcpy(bo.data(), d_blk_off_, bo.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-                shared_units_ = 0;
-                for (size_t u2 = 0; u2 + 1 < bo.size(); u2++) shared_units_ += (bo[u2 + 1] - bo[u2] > 1) ? 1 : 0;
-                // Group memory per enumerate workgroup for the runs to come.  k workgroups share a CU's 160 KB and its store
-                // bandwidth, so W work blocks take about ceil(W / (CUs * k)) * k "slot rounds": pick the k in 3..5 with the
-                // fewest, among those whose budget 160 KB / k still holds every image of this batch (measured on the bench
-                // batch, 4096 work blocks on 256 CUs: k = 3 (48 KB) 0.92-0.95 ms, k = 4 (40 KB) 0.86-0.87 ms).
-                if (emit_lds_auto_ && general_path_ == 0 && bo.back() > 0) {
-                    std::vector<int32_t> hd(hb_.units.size() * 8);
-                    HIP_CK(hipMemcpy(hd.data(), d_blk_hdr_, hd.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-                    int need = 0;
-                    for (size_t u2 = 0; u2 < hb_.units.size(); u2++) if (hd[8 * u2] > 0 && hd[8 * u2 + 3] > need) need = hd[8 * u2 + 3];
-                    int ncu = 256;
-                    { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
-                    const int64_t W = bo.back();
-                    int best_k = 0; int64_t best = 0;
-                    for (int k = 3; k <= 5; k++) {
-                        const int budget = ((160 * 1024) / k) & ~15;
-                        if (need <= 0 || need > budget) continue;
-                        const int64_t rounds = ((W + (int64_t)ncu * k - 1) / ((int64_t)ncu * k)) * k;
-                        if (!best_k || rounds < best) { best_k = k; best = rounds; }
-                    }
-                    if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: image need %d bytes, %lld work blocks on %d CUs -> %d workgroups per CU\n", need, (long long)W, ncu, best_k);
-                    // ... and ask for no more than the images need (512-byte granules): what the k enumerate workgroups leave of
-                    // the CU's group memory is where the scan / finish workgroups run WITHOUT pushing an enumerate workgroup out
-                    if (best_k) {
-                        block_lds_ = ((160 * 1024) / best_k) & ~15;
-                        const int tight = (need + 511) & ~511;
-                        if (emit_lds_tight_ && tight < block_lds_) block_lds_ = tight;
-                        lds_blocks_ = block_lds_;
-                    }
-                }
-            }
-        }
         for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s];
+        late_refusal_ = lease_->h_words->late_flag != 0;
         if (*h_npending_ > 0) {
             int rc = slow_path();
             if (rc) return rc;
@@ -1449,6 +1684,8 @@ class HipBackend : public Backend {
             if (rc) return rc;
             all_done_ = true;
         }
+        // the mailbox of a small batch holds what the express kernel published; nothing behind it changed a header
+        mail_valid_ = express_ && mail_on_ && !(A_.flags & FLAG_ALL) && *(volatile int32_t*)h_express_left_ == 0 && !late_refusal_;
         if (timing_ && timed_runs_ > 0) {
             // average duration of ONE launch of every kernel over the slices and the slots filled since timing was
             // switched on (every run launches each kernel once per slice)
@@ -1462,9 +1699,9 @@ class HipBackend : public Backend {
                 for (long sl = 0; sl < filled; sl++) {
                     for (int sc = 0; sc < n_slices_; sc++) {
                         size_t at = ((size_t)sl * n_slices_ + sc) * kTimedKernels + k;
-                        if (at >= evs_.size() || !evs_[at].a) continue;
+                        if (at >= evs().size() || !evs()[at].a) continue;
                         float ms = 0;
-                        if (hipEventElapsedTime(&ms, evs_[at].a, evs_[at].b) == hipSuccess) { sum += ms; cnt++; nm = evs_[at].name; }
+                        if (hipEventElapsedTime(&ms, evs()[at].a, evs()[at].b) == hipSuccess) { sum += ms; cnt++; nm = evs()[at].name; }
                     }
                 }
                 times_.push_back({nm, cnt ? (float)(sum / cnt) : -1.0f});
@@ -1478,32 +1715,52 @@ class HipBackend : public Backend {
         return 0;
     }
     // Results complete (paths, breakpoints, output junctions of every unit) -- which, for a small batch on the express path,
-    // is before the order tables behind them are written: returns once the express kernel is done and it left no unit to
-    // the ordinary kernels; otherwise the same as wait().
+    // is before the order tables behind them are written.  Returns early only when NOTHING behind the express kernel can
+    // still void a result it published: no unit left to the ordinary kernels, and no unit that the lattice or plan stage
+    // refuses afterwards (more order ideals than the table holds, an order table the arena has no room for).  For a batch
+    // that has completed a run that is known (inputs are immutable); for a fresh batch the host also waits for the plan
+    // kernel's verdict, which reaches it through pinned memory like the express kernel's.  Otherwise the same as wait().
     int wait_results() override {
         if (!ran_) return 0;
-        if (express_ && !(A_.flags & FLAG_ALL) && ev_express_) {
+        if (express_ && !(A_.flags & FLAG_ALL) && ev_express_ && !late_refusal_) {
             // the kernel's last workgroup stores the run's sequence number into pinned host memory: a short spin on it
             // returns microseconds before an event wait would; the event wait is the fallback
             volatile int32_t* seq = h_express_left_ + 1;
             bool seen = false;
             for (int spin = 0; spin < 400000 && !(seen = (*seq == run_seq_)); spin++) __builtin_ia32_pause();
             if (!seen) HIP_CK(hipEventSynchronize(ev_express_));
-            if (*(volatile int32_t*)h_express_left_ == 0) return 0;
+            if (*(volatile int32_t*)h_express_left_ == 0) {
+                if (arena_checked_) { mail_valid_ = mail_on_; return 0; }
+                volatile int32_t* pseq = &lease_->h_words->plan_seq;
+                seen = false;
+                for (int spin = 0; spin < 400000 && !(seen = (*pseq == run_seq_)); spin++) __builtin_ia32_pause();
+                if (seen && *(volatile int32_t*)&lease_->h_words->late_flag == 0 && *(volatile int64_t*)h_needed_ <= slice_bytes_[0]) {
+                    arena_checked_ = true;     // every table of this batch fits the arena: true for all its runs
+                    mail_valid_ = mail_on_;
+                    return 0;
+                }
+            }
         }
         return wait();
+    }
+    // header + final paths + output junctions of a unit on the HOST without a copy command: the pinned mailbox slot the
+    // express kernel filled (nullptr: not available -- the caller downloads the result blob instead)
+    const uint8_t* mail_slot(int unit) override {
+        if (!mail_valid_ || !lease_ || unit < 0 || unit >= (int)mail_off_.size()) return nullptr;
+        return lease_->h_mail + mail_off_[unit];
     }
     int download(std::vector<uint8_t>& blob) override {
         int rc = wait();
         if (rc) return rc;
-        blob.resize((size_t)hb_.result_bytes);
-        HIP_CK(hipMemcpy(blob.data(), d_results_, (size_t)hb_.result_bytes, hipMemcpyDeviceToHost));
+        if (upload_pending_) { if ((rc = flush_upload(nullptr))) return rc; HIP_CK(hipStreamSynchronize(nullptr)); }   // never run: the blob is all zeroes
+        blob.resize((size_t)hb().result_bytes);
+        HIP_CK(hipMemcpy(blob.data(), d_results_, (size_t)hb().result_bytes, hipMemcpyDeviceToHost));
         if (d_stage_clk_) dump_stage_profile();
         return 0;
     }
     // AMBI_STAGE_PROFILE=1: mean shader-clock distance between consecutive marks of the per-unit stages (last run)
     void dump_stage_profile() {
-        const size_t U = hb_.units.size();
+        const size_t U = hb().units.size();
         std::vector<int64_t> clk(U * kStageSlots);
         if (hipMemcpy(clk.data(), d_stage_clk_, clk.size() * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return;
         // marks 0-8 and 22-31: prepare (22-24 inside constructDAG, 26-28 inside the lattice); 9-12: scan; 16-21: finish
@@ -1522,7 +1779,7 @@ class HipBackend : public Backend {
     }
     int device_results(void** ptr, int64_t* bytes) override {
         if (ptr) *ptr = d_results_;
-        if (bytes) *bytes = hb_.result_bytes;
+        if (bytes) *bytes = hb().result_bytes;
         return 0;
     }
     int pack_paths(int which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap, int64_t* dev_total, void* stream) override {
@@ -1574,7 +1831,7 @@ class HipBackend : public Backend {
     // and unit stay in HBM, the host reads the per-unit counts (one copy) and a unit's bitmap only when its indices are
     // asked for; the paths are produced on demand by all_paths().
     int compute_all() {
-        const int U = (int)hb_.units.size();
+        const int U = (int)hb().units.size();
         std::vector<UnitOut> hdr(U);
         HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));
         all_off_.assign(U + 1, 0);
@@ -1604,28 +1861,27 @@ class HipBackend : public Backend {
         if (chunks > 0) {
             const int wave_lds = (int)((lds_first_ + 64 * kFirstRowStride + 15) & ~15);
             const int waves = (4 * wave_lds <= 64 * 1024) ? 4 : ((2 * wave_lds <= 150 * 1024) ? 2 : 1);
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
             int64_t nblk = (chunks + waves - 1) / waves;
             if (nblk > (1 << 20)) nblk = 1 << 20;   // grid-stride beyond
-            hipEvent_t ea = nullptr, eb = nullptr;
+            EventPair ev;
+            hipEvent_t& ea = ev.a; hipEvent_t& eb = ev.b;
             if (timing_) { HIP_CK(hipEventCreate(&ea)); HIP_CK(hipEventCreate(&eb)); HIP_CK(hipEventRecord(ea, stream_)); }
             // units with a short breakpoint path (the rule): one thread per order; the others: one wavefront per order
             int lane_cap = 0, lanes_units = 0, wave_units = 0;
             { const char* e = getenv("AMBI_ALL_LANES"); lane_cap = (e && atoi(e) == 0) ? 0 : kAllLaneMaxCells; }
-            for (int u = 0; u < U; u++) if (all_off_[u + 1] > all_off_[u]) { if (hb_.units[u].bkp_cap <= lane_cap) lanes_units++; else wave_units++; }
+            for (int u = 0; u < U; u++) if (all_off_[u + 1] > all_off_[u]) { if (hb().units[u].bkp_cap <= lane_cap) lanes_units++; else wave_units++; }
             int max_lane_cells = 8;
-            for (int u = 0; u < U; u++) if (hb_.units[u].bkp_cap <= lane_cap && hb_.units[u].bkp_cap > max_lane_cells) max_lane_cells = hb_.units[u].bkp_cap;
-            const int head_bytes = (int)((first_work_bytes(hb_.max_n, 8) + 15) & ~15);
+            for (int u = 0; u < U; u++) if (hb().units[u].bkp_cap <= lane_cap && hb().units[u].bkp_cap > max_lane_cells) max_lane_cells = hb().units[u].bkp_cap;
+            const int head_bytes = (int)((first_work_bytes(hb().max_n, 8) + 15) & ~15);
             // group memory for a staged copy of the unit's automaton (env AMBI_ALL_AUTO_LDS): 0 = the lanes unrank through L2.
             // Measured (4096 bench units): 0 / 4096 / 8192 bytes = 561 / 489 / 390 M orders/s -- the kernel lives on the number
             // of resident wavefronts (group-memory latency), and every KB of group memory costs some.
             int auto_bytes = 0;
             { const char* e = getenv("AMBI_ALL_AUTO_LDS"); if (e) auto_bytes = atoi(e) & ~15; if (auto_bytes < 0) auto_bytes = 0; }
-            const int rows_bytes = 64 * ((hb_.max_k + 3) & ~3);   // transposed orders: one 64-lane row per position
+            const int rows_bytes = 64 * ((hb().max_k + 3) & ~3);   // transposed orders: one 64-lane row per position
             const int lane_wave_lds = (head_bytes + rows_bytes + max_lane_cells * 64 * (int)sizeof(cell_t) + auto_bytes + 15) & ~15;
             int lane_waves = 1;   // wavefronts per workgroup (measured 1 / 2 / 4 = 563 / 553 / 379 M orders/s: group-memory allocation granularity)
             { const char* e = getenv("AMBI_ALL_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 4) lane_waves = atoi(e); }
-            HIP_CK(hipFuncSetAttribute((const void*)ambi_all_lanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
             int64_t lblk = (chunks + lane_waves - 1) / lane_waves;
             if (lblk > (1 << 20)) lblk = 1 << 20;
             for (int pass = 0; pass < 2; pass++) {
@@ -1637,7 +1893,7 @@ class HipBackend : public Backend {
             HIP_CK(hipGetLastError());
             HIP_CK(hipMemcpyAsync(all_counts_.data(), d_all_count_, 2 * (size_t)U * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
             HIP_CK(hipStreamSynchronize(stream_));
-            if (timing_) { (void)hipEventElapsedTime(&all_kernel_ms_, ea, eb); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); }
+            if (timing_) (void)hipEventElapsedTime(&all_kernel_ms_, ea, eb);
         }
         return 0;
     }
@@ -1654,7 +1910,7 @@ class HipBackend : public Backend {
     }
     int all_finish() override {
         if (!d_all_bits_) return 0;
-        const int U = (int)hb_.units.size();
+        const int U = (int)hb().units.size();
         hipLaunchKernelGGL(ambi_all_finalize_kernel, dim3((U + 255) / 256), dim3(256), 0, stream_, A_);
         HIP_CK(hipGetLastError());
         HIP_CK(hipMemcpyAsync(all_counts_.data(), d_all_count_, 2 * (size_t)U * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
@@ -1702,22 +1958,21 @@ class HipBackend : public Backend {
         const auto& v = *vp;
         if (first < 0 || count < 0 || first + count > (int64_t)v.size() || stride <= 0) return ST_ERR_BAD_INPUT;
         if (count == 0) return 0;
-        const UnitIn& Uin = hb_.units[unit];
+        const UnitIn& Uin = hb().units[unit];
         const bool fwd0 = !(A_.flags & FLAG_REVERSED), fwd = pass == 0 ? fwd0 : !fwd0;
-        int64_t* d_idx = nullptr; int32_t* d_len = nullptr; int32_t* d_cells = nullptr;
-        HIP_CK(hipMalloc((void**)&d_idx, (size_t)count * sizeof(int64_t)));
-        HIP_CK(hipMalloc((void**)&d_len, (size_t)count * sizeof(int32_t)));
-        HIP_CK(hipMalloc((void**)&d_cells, (size_t)count * (size_t)stride * sizeof(int32_t)));
+        DevBuf b_idx, b_len, b_cells;
+        HIP_CK(b_idx.alloc((size_t)count * sizeof(int64_t)));
+        HIP_CK(b_len.alloc((size_t)count * sizeof(int32_t)));
+        HIP_CK(b_cells.alloc((size_t)count * (size_t)stride * sizeof(int32_t)));
+        int64_t* d_idx = b_idx.as<int64_t>(); int32_t* d_len = b_len.as<int32_t>(); int32_t* d_cells = b_cells.as<int32_t>();
         HIP_CK(hipMemcpy(d_idx, v.data() + first, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice));
         const int lds = (int)(first_work_bytes(Uin.n_seg, Uin.bkp_cap) + 4ll * (Uin.bkp_cap / 2 + 2) + 16);
-        HIP_CK(hipFuncSetAttribute((const void*)ambi_order_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic));
         hipLaunchKernelGGL(ambi_order_paths_kernel, dim3((unsigned)count), dim3(64), lds, stream_, A_, unit, fwd ? 1 : 0, (const int64_t*)d_idx, d_len,
                            d_cells, stride);
         HIP_CK(hipGetLastError());
         HIP_CK(hipMemcpyAsync(lengths, d_len, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_CK(hipMemcpyAsync(cells, d_cells, (size_t)count * (size_t)stride * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIP_CK(hipStreamSynchronize(stream_));
-        (void)hipFree(d_idx); (void)hipFree(d_len); (void)hipFree(d_cells);
         return 0;
     }
 };

@@ -277,7 +277,10 @@ AMBI_HD void stage_lattice(const G& g, const BatchArgs& A, int u, uint8_t* work 
     const int st = prep_lattice(g, A, u, pred, out->K, work + 64 * 8, &R);
     if (g.tid() == 0) {
         out->num_orders = (int64_t)R;
-        if (st != ST_OK) { out->status = st; out->order_off = kOrderOffNone; }   // as the one-piece prepare stage reports it (a path the express stage may have written is void then)
+        if (st != ST_OK) {   // as the one-piece prepare stage reports it (a path the express stage may have written is void then: the host is told)
+            out->status = st; out->order_off = kOrderOffNone;
+            if (A.late_flag) *A.late_flag = 1;
+        }
     }
     g.sync();
 }

@@ -135,10 +135,14 @@ int ambi_batch_configure(ambi_batch_t* b, int64_t order_arena_bytes, int32_t ide
  * real assembly leaves. */
 int ambi_batch_debug_inject_validity(ambi_batch_t* b, int32_t unit, const int8_t* verdicts, int64_t count);
 
-/* Packs the units and copies the inputs to HBM on the current device (inputs stay resident across runs). */
+/* Packs the units and hands the inputs to the current device (they stay resident in HBM across runs).  Streams, events,
+ * pinned words and device blocks come from a per-device pool with process lifetime (created on first use, reused by every
+ * later batch, never destroyed per batch).  Small batches: the input image is written into pinned host memory here and its
+ * ONE copy to HBM is queued by the first ambi_batch_run ahead of that run's kernels. */
 int ambi_batch_upload(ambi_batch_t* b);
-/* Enqueues one pass of the whole pipeline over the batch on `hip_stream` (a hipStream_t; NULL = default stream).
- * Asynchronous unless the order arena has to grow. */
+/* Enqueues one pass of the whole pipeline over the batch on `hip_stream` (a hipStream_t; NULL = default stream; it must
+ * stay alive until the run has been waited for).  Asynchronous: the first run of a batch takes the order-table arena the
+ * pool holds, and ambi_batch_wait grows it and repeats the run if the tables did not fit. */
 int ambi_batch_run(ambi_batch_t* b, uint32_t flags, void* hip_stream);
 int ambi_batch_wait(ambi_batch_t* b);
 /* Returns as soon as the RECONSTRUCTION results of the enqueued run are complete in HBM (paths, breakpoints, output
@@ -149,6 +153,12 @@ int ambi_batch_wait(ambi_batch_t* b);
 int ambi_batch_wait_results(ambi_batch_t* b);
 /* Copies the result blob to the host (implies wait).  After this the getters below are valid. */
 int ambi_batch_download(ambi_batch_t* b);
+/* What the caller of ONE sample needs -- localhap.cpp:261-289: the path of getBFB, the path after indelBFB, the output
+ * junctions -- on the host with the least traffic (implies ambi_batch_wait_results).  A small batch on the fast path has
+ * had them written into pinned host memory by the reconstruction kernel itself: no copy command at all.  Otherwise the same
+ * as ambi_batch_download.  Afterwards ambi_batch_unit_result (num_orders = -1 when the order count is not part of what
+ * was fetched), ambi_batch_unit_path and ambi_batch_unit_out_juncs are valid; the other getters need ambi_batch_download. */
+int ambi_batch_fetch_paths(ambi_batch_t* b);
 
 /* Device-side view for collectives: the result blob (header [n_units] + per-unit arrays) lives in device memory.  Its
  * layout is the engine's own (csrc/ambi_batch.hpp: UnitOut, unit_layout; path cells are 2-byte LOCAL signed segment ids --

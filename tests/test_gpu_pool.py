@@ -1,0 +1,142 @@
+"""GPU tests of the per-device pool (streams / events / pinned words / device blocks with process lifetime), the result
+mailbox of small batches (ambi_batch_fetch_paths) and the wait_results contract.  Everything goes through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from ambigram_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(workdir, name, n=64, m=128, tier="wide", K=9, seed=1, **kw):
+    s = synth.make_sample(n, m, tier, K, seed=seed, name=name, **kw)
+    return s.write(workdir)
+
+
+def _full(lib, lh, sols, flags=0):
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    for c in range(g.n_chr):
+        b.add_chromosome_sol(g, c, sols[c])
+    b.upload(); b.run(flags); b.download()
+    out = [(b.unit_result(u), b.unit_path(u, 0).tolist(), b.unit_path(u, 1).tolist(), b.unit_out_juncs(u)) for u in range(b.size())]
+    b.close()
+    return out
+
+
+def test_fetch_paths_equals_download(hip_lib, oracle, workdir):
+    """A fresh small batch: upload -> run -> fetch_paths (pinned mailbox, no copy command) gives what download gives, and
+    what the oracle gives; also on the second run of the same batch and with several units."""
+    cases = [_sample(workdir, "mb%d" % i, n=(40, 64, 96, 256)[i % 4], m=(90, 128, 200, 512)[i % 4], tier=("chain", "wide", "mixed")[i % 3], K=(7, 9, 11)[i % 3],
+                     seed=300 + i, imperfect=i % 2, n_del=i % 3, n_dup=(i + 1) % 2) for i in range(8)]
+    for lh, sols in cases:
+        want = _full(hip_lib, lh, sols)
+        g = api.Graph(hip_lib, lh)
+        b = api.Batch(hip_lib)
+        b.add_chromosome_sol(g, 0, sols[0])
+        b.upload()
+        for rep in range(2):
+            b.run(0); b.fetch_paths()
+            r = b.unit_result(0)
+            assert r["status"] == want[0][0]["status"]
+            for k in ("path_len", "path_indel_len", "indel_printed", "n_out_junc", "bias", "first_forward", "path_indel_stored"):
+                assert r[k] == want[0][0][k], (k, rep)
+            assert b.unit_path(0, 0).tolist() == want[0][1] and b.unit_path(0, 1).tolist() == want[0][2]
+            assert b.unit_out_juncs(0) == want[0][3]
+            with pytest.raises(api.AmbiError):
+                b.unit_bkp(0)          # not part of what was fetched
+            b.wait()
+        oc = oracle.run_bfb(lh, sols)["chr"][0]
+        assert b.unit_path(0, 1).tolist() == oc["path_indel"]
+        b.download()
+        assert b.unit_result(0)["num_orders"] == want[0][0]["num_orders"]
+        b.close()
+    # several units in one small batch
+    gs, b = [], api.Batch(hip_lib)
+    for lh, sols in cases:
+        gs.append(api.Graph(hip_lib, lh)); b.add_chromosome_sol(gs[-1], 0, sols[0])
+    b.upload(); b.run(0); b.fetch_paths()
+    for u, (lh, sols) in enumerate(cases):
+        assert b.unit_path(u, 1).tolist() == _full(hip_lib, lh, sols)[0][2]
+    b.close()
+
+
+def test_fetch_paths_reversed_and_all(hip_lib, workdir):
+    lh, sols = _sample(workdir, "mbr", seed=77)
+    for flags in (api.FLAG_REVERSED, api.FLAG_ALL):
+        want = _full(hip_lib, lh, sols, flags)
+        g = api.Graph(hip_lib, lh); b = api.Batch(hip_lib)
+        b.add_chromosome_sol(g, 0, sols[0]); b.upload(); b.run(flags); b.fetch_paths()
+        assert b.unit_path(0, 1).tolist() == want[0][2] and b.unit_result(0)["status"] == want[0][0]["status"]
+        b.close()
+
+
+def test_leases_are_reused_across_batches(hip_lib, oracle, workdir):
+    """Create / run / destroy many batches of alternating sizes in one process: every batch takes its streams, events, pinned
+    words and device blocks from the pool (no per-batch create / destroy), stale contents of a reused block must not leak
+    into the next batch."""
+    small = _sample(workdir, "ls", n=40, m=90, tier="chain", K=7, seed=5, n_del=2, n_dup=1)
+    big = _sample(workdir, "lb", n=256, m=512, tier="wide", K=19, seed=6, n_del=2, n_dup=1)
+    want = {small[0]: _full(hip_lib, *small), big[0]: _full(hip_lib, *big)}
+    for i in range(24):
+        lh, sols = (small, big)[(i // 2) % 2]
+        got = _full(hip_lib, lh, sols, 0)
+        assert got == want[lh], i
+    oc = oracle.run_bfb(*big)["chr"][0]
+    assert want[big[0]][0][2] == oc["path_indel"]
+    # two batches alive at once hold two leases
+    ga, gb = api.Graph(hip_lib, small[0]), api.Graph(hip_lib, big[0])
+    a, b = api.Batch(hip_lib), api.Batch(hip_lib)
+    a.add_chromosome_sol(ga, 0, small[1][0]); b.add_chromosome_sol(gb, 0, big[1][0])
+    a.upload(); b.upload(); a.run(0); b.run(0); a.download(); b.download()
+    assert a.unit_path(0, 1).tolist() == want[small[0]][0][2] and b.unit_path(0, 1).tolist() == want[big[0]][0][2]
+    a.close(); b.close()
+
+
+def test_results_after_wait_results_are_final_under_an_arena_limit(hip_lib, workdir, monkeypatch):
+    """with an arena budget the plan stage refuses units AFTER the express stage has published them; what a
+    caller reads from the device right after wait_results() must already be the final verdict."""
+    import torch
+    lh, sols = _sample(workdir, "cap", n=256, m=512, tier="wide", K=19, seed=9)
+    monkeypatch.setenv("AMBI_ARENA_MAX_BYTES", "65536")     # far below the 48 620 x 20 bytes this unit's table needs
+    g = api.Graph(hip_lib, lh); b = api.Batch(hip_lib)
+    b.add_chromosome_sol(g, 0, sols[0]); b.upload()
+    for rep in range(3):
+        b.run(0); b.wait_results()
+        ptr, nbytes = b.device_results()
+        from ambigram_amd.dist import _DevBytes
+        hdr = torch.as_tensor(_DevBytes(ptr, 80), device="cuda").cpu().numpy().view(np.int32)   # UnitOut of unit 0, as it is in HBM now
+        early_status, early_path_len = int(hdr[0]), int(hdr[4])
+        b.download()
+        r = b.unit_result(0)
+        assert r["status"] == -15 and r["path_len"] == 0
+        assert (early_status, early_path_len) == (r["status"], r["path_len"]), rep
+    b.close()
+    monkeypatch.delenv("AMBI_ARENA_MAX_BYTES")
+    # the same lease, the budget gone: the batch reconstructs
+    assert _full(hip_lib, lh, sols)[0][0]["status"] == 0
+
+
+def test_guard_words_around_direct_path_areas(hip_lib, oracle, workdir, monkeypatch):
+    """AMBI_DEBUG: guard words on both sides of every path area of the direct full-finish launch and around the pinned
+    status words are checked at wait(): a kernel that left its slot would make wait() fail."""
+    monkeypatch.setenv("AMBI_DEBUG", "1")
+    monkeypatch.setenv("AMBI_EXPRESS_UNITS", "0")       # through the ordinary kernel chain: the direct launch does the work
+    gs, b, samples = [], api.Batch(hip_lib), []
+    for i in range(40):
+        lh, sols = _sample(workdir, "gd%d" % i, n=48, m=80 + i, tier=("chain", "wide", "mixed")[i % 3], K=7, seed=900 + i, imperfect=i % 2,
+                           n_del=2 + i % 3, n_dup=1 + i % 2, near_inv=i % 4)
+        gs.append(api.Graph(hip_lib, lh)); b.add_chromosome_sol(gs[-1], 0, sols[0]); samples.append((lh, sols))
+    b.upload()
+    for _ in range(3):
+        b.run(0); b.wait()
+    b.download()
+    edited = 0
+    for u, (lh, sols) in enumerate(samples):
+        oc = oracle.run_bfb(lh, sols)["chr"][0]
+        assert b.unit_path(u, 1).tolist() == oc["path_indel"], u
+        edited += oc["path_indel"] != oc["path"]
+    assert edited >= 5
+    b.close()
