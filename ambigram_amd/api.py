@@ -388,10 +388,18 @@ class Batch:
         return {k: getattr(r, k) for k, _ in UnitResult._fields_}
 
     def unit_path(self, u, which=0):
-        n = self._ck(self.lib.ambi_batch_unit_path(self.h, u, which, None, 0), "unit_path")
-        out = np.zeros(max(n, 1), np.int32)
-        self.lib.ambi_batch_unit_path(self.h, u, which, out.ctypes.data_as(_P(C.c_int32)), n)
-        return out[:n]
+        # one call into a scratch buffer (the function returns the length and copies at most `cap` cells); a second one only
+        # when the path is longer than the scratch
+        buf = getattr(self, "_path_buf", None)
+        if buf is None:
+            buf = self._path_buf = np.empty(1 << 15, np.int32)
+            self._path_ptr = buf.ctypes.data_as(_P(C.c_int32))
+        n = self._ck(self.lib.ambi_batch_unit_path(self.h, u, which, self._path_ptr, len(buf)), "unit_path")
+        if n > len(buf):
+            buf = self._path_buf = np.empty(n + (n >> 2), np.int32)
+            self._path_ptr = buf.ctypes.data_as(_P(C.c_int32))
+            self.lib.ambi_batch_unit_path(self.h, u, which, self._path_ptr, len(buf))
+        return buf[:n].copy()
 
     def unit_bkp(self, u):
         n = self._ck(self.lib.ambi_batch_unit_bkp(self.h, u, None, 0), "unit_bkp")

@@ -180,6 +180,16 @@ struct BatchArgs {
     const int64_t* mail_off;     // [U] byte offset of every unit's slot
     int32_t* plan_seq;           // pinned host int: the plan kernel stores run_seq here once orders_needed / late_flag are final
     int32_t* late_flag;          // pinned host int: != 0 when the lattice or plan stage refused a unit AFTER the express stage published it
+    // small batches: the lattice of every unit is built by a kernel of its own BESIDE the express kernel (stage_lattice_own: it
+    // constructs the DAG a second time instead of waiting for the express kernel's); its outcome is parked here and merged into
+    // the headers by the plan kernel, which runs behind both (nullptr: the lattice stage writes the headers itself)
+    int32_t* lat_seq;            // pinned host int: the last wave of the side lattice kernel stores run_seq here ...
+    int32_t* lat_unsure;         // pinned host int: ... after setting this to 1 unless EVERY unit's lattice is fine and all order tables together
+                                 // (every unit counted, also those the express stage ends without a reconstruction) fit the arena:
+                                 // 0 = nothing behind the express kernel can void what it published
+    int64_t* lat_sum;            // [2] device: {bytes of the order tables so far, waves done} of the side lattice kernel
+    uint64_t* lat_R;             // [U] number of orders
+    int32_t* lat_status;         // [U] ST_OK or the status the DAG / lattice stage ends with
 };
 
 // Mailbox slot of one unit: [UnitOut, 128 bytes] [path: path_cap cells] [path after indelBFB: path_cap cells] [output junctions:

@@ -16,6 +16,7 @@
 //   ambi_pack_*                   optional end-of-batch packing of the paths for an RCCL gather
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -59,6 +60,15 @@ __device__ inline void mail_unit(const BatchArgs& A, int u) {
     if (h->path_ind_stored) copy8(slot + M.path_ind, res + L.path_ind, (int64_t)sizeof(rcell_t) * h->path_indel_len);
     copy8(slot + M.out_junc, res + L.out_junc, (int64_t)sizeof(OutJunc) * h->n_out_junc);
     __threadfence_system();
+}
+// A small batch's input image goes from pinned host memory to HBM and its zero-filled region is cleared by ONE kernel (the
+// threads read host memory over the link): a copy command + a fill command cost two engine hand-overs in front of the
+// first kernel, several times what moving 15 KB takes.
+__global__ __launch_bounds__(256) void ambi_ingest_kernel(const uint4* src, uint4* dst, int64_t n16, uint4* zero, int64_t z16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = i; k < n16; k += stride) dst[k] = src[k];
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (int64_t k = i; k < z16; k += stride) zero[k] = z;
 }
 // guard words on both sides of every path area of the direct full-finish launch (AMBI_DEBUG: does that kernel leave its slot?)
 constexpr int kCellGuardBytes = 64;
@@ -133,9 +143,39 @@ __device__ inline int64_t block_exscan_i64(int64_t v, int64_t* total, int64_t* s
     return base + inc - v;
 }
 
+__global__ __launch_bounds__(64) void ambi_lattice_own_kernel(BatchArgs A) {
+    WaveGroup g;
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.refin_count = 0;   // (as ambi_lattice_kernel)
+    const int u = A.unit_base + (int)blockIdx.x;
+    stage_lattice_own(g, A, u, ambi_lds);
+    // the verdict the host waits for on a fresh batch: no lattice failed and the tables of ALL units fit the arena together
+    // (then every prefix fits, whatever subset the plan kernel ends up placing)
+    if (threadIdx.x == 0 && A.lat_seq) {
+        const bool ok = A.lat_status[u] == ST_OK || A.lat_status[u] == ST_ERR_NO_ELEMENTS;   // (no elements: the express stage reports that itself)
+        const int64_t bytes = A.lat_status[u] == ST_OK ? order_bytes((int64_t)A.lat_R[u], A.units[u].n_elem, A.order_align) : 0;
+        if (!ok) *A.lat_unsure = 1;
+        __threadfence_system();
+        const unsigned long long total = atomicAdd(reinterpret_cast<unsigned long long*>(A.lat_sum), (unsigned long long)bytes) + (unsigned long long)bytes;
+        (void)total;
+        __threadfence();
+        if (atomicAdd(reinterpret_cast<unsigned long long*>(A.lat_sum + 1), 1ull) == (unsigned long long)gridDim.x - 1) {   // last wave
+            const int64_t all = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(A.lat_sum), 0ull);
+            if (all > A.order_arena_bytes) *A.lat_unsure = 1;
+            A.lat_sum[0] = 0; A.lat_sum[1] = 0;
+            __threadfence_system();
+            *(volatile int32_t*)A.lat_seq = A.run_seq;
+        }
+    }
+}
+
 // Parallel form of plan_serial (ambi_stages.hpp): same prefix-sum semantics.
 __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     __shared__ int64_t sh[17];
+    if (A.lat_R) {   // the lattice ran beside the express kernel: its outcome goes into the headers first
+        for (int i = threadIdx.x; i < A.n_units; i += blockDim.x) plan_merge_lattice(A, A.unit_base + i);
+        __threadfence();
+        __syncthreads();
+    }
     // pass 1: rows of the whole batch -> rows per lane of the enumerate kernel
     int64_t my_rows = 0;
     for (int i = threadIdx.x; i < A.n_units; i += blockDim.x) {
@@ -736,7 +776,7 @@ constexpr int kLdsMaxDynamic = 160 * 1024 - 1024;
 // ------------------------------------------------------------------------------------------------
 struct PinnedWords {                    // what kernels write into host memory (BatchArgs::host_pending, host_needed, express_*, plan_seq, late_flag)
     uint32_t guard_lo[16];
-    int32_t npending, express_left, express_seq, plan_seq, late_flag, pad_[11];
+    int32_t npending, express_left, express_seq, plan_seq, late_flag, lat_seq, lat_unsure, pad_[9];
     int64_t needed[16];
     uint32_t guard_hi[16];
 };
@@ -744,12 +784,12 @@ struct TimingEvents { const char* name; hipEvent_t a, b; };
 struct Lease {
     int device = 0;
     hipStream_t side[3][3] = {};        // [back, full, first][default, lowest, highest priority], created on first use
-    hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_back = nullptr, ev_first = nullptr, ev_full = nullptr, ev_plan = nullptr, ev_express = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_back = nullptr, ev_first = nullptr, ev_full = nullptr, ev_plan = nullptr, ev_express = nullptr, ev_lat = nullptr;
     PinnedWords* h_words = nullptr; PinnedWords* dh_words = nullptr;
     uint8_t* d_block = nullptr; int64_t d_block_bytes = 0;      // inputs + working set + result blob of the batch
     uint8_t* d_arena = nullptr; int64_t d_arena_bytes = 0;      // order tables
     uint8_t* d_cells = nullptr; int64_t d_cells_bytes = 0;      // path areas of the direct full-finish launch
-    uint8_t* h_stage = nullptr; int64_t h_stage_bytes = 0;      // pinned image of the inputs (one H2D copy)
+    uint8_t* h_stage = nullptr; uint8_t* dh_stage = nullptr; int64_t h_stage_bytes = 0;   // pinned image of the inputs (one H2D copy, or read by the ingest kernel)
     uint8_t* h_mail = nullptr; uint8_t* dh_mail = nullptr; int64_t h_mail_bytes = 0;   // pinned result mailbox (express path)
     std::vector<TimingEvents> evs;
     std::vector<hipStream_t> slice_streams; std::vector<hipEvent_t> slice_events;     // AMBI_SLICES experiments
@@ -774,7 +814,7 @@ class DevicePool {
         }
         Lease* L = new Lease();
         L->device = dev;
-        hipEvent_t* evs[] = {&L->ev_fork, &L->ev_prep, &L->ev_back, &L->ev_first, &L->ev_full, &L->ev_plan, &L->ev_express};
+        hipEvent_t* evs[] = {&L->ev_fork, &L->ev_prep, &L->ev_back, &L->ev_first, &L->ev_full, &L->ev_plan, &L->ev_express, &L->ev_lat};
         for (hipEvent_t* e : evs) HIP_CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_CK(hipHostMalloc((void**)&L->h_words, sizeof(PinnedWords)));
         memset(L->h_words, 0, sizeof(PinnedWords));
@@ -902,7 +942,9 @@ class HipBackend : public Backend {
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
-    int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0;
+    int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0, lds_lattice_own_ = 0;
+    bool side_lattice_ = false; hipStream_t lattice_stream_ = nullptr;   // env AMBI_SIDE_LATTICE=0: the lattice kernel behind the express kernel (round 2)
+    uint64_t* d_lat_R_ = nullptr; int32_t* d_lat_status_ = nullptr; int64_t* d_lat_sum_ = nullptr;
     bool express_ = false;
     hipEvent_t ev_express_ = nullptr;
     int32_t* h_express_left_ = nullptr; int32_t* dh_express_left_ = nullptr;   // [0] left flag, [1] sequence word (words of the lease)
@@ -928,6 +970,7 @@ class HipBackend : public Backend {
     bool emit_lds_tight_ = true;   // env AMBI_EMIT_LDS_TIGHT=0: the whole 160 KB / k share
     double avg_path_ = 0;
     int enum_threads_ = 256;  // threads per workgroup of the block-emission kernel (env AMBI_ENUM_THREADS: 256 / 512 / 1024)
+    std::chrono::steady_clock::time_point t_run_; double t_launched_ = 0;   // env AMBI_DEBUG_LATENCY
     bool debug_ = false;      // env AMBI_DEBUG: budgets and grids chosen; guard words of the direct path areas checked at wait()
 
     // Everything this batch queued is complete when this returns: the caller's stream (only if a run is still in flight -- the
@@ -972,7 +1015,7 @@ class HipBackend : public Backend {
             if (L->d_block_bytes > kKeepBlock) { (void)hipFree(L->d_block); L->d_block = nullptr; L->d_block_bytes = 0; }
             if (L->d_arena_bytes > kKeepArena) { (void)hipFree(L->d_arena); L->d_arena = nullptr; L->d_arena_bytes = 0; }
             if (L->d_cells_bytes > kKeepCells) { (void)hipFree(L->d_cells); L->d_cells = nullptr; L->d_cells_bytes = 0; }
-            if (L->h_stage_bytes > kKeepStage) { (void)hipHostFree(L->h_stage); L->h_stage = nullptr; L->h_stage_bytes = 0; }
+            if (L->h_stage_bytes > kKeepStage) { (void)hipHostFree(L->h_stage); L->h_stage = nullptr; L->dh_stage = nullptr; L->h_stage_bytes = 0; }
             if (L->h_mail_bytes > kKeepMail) { (void)hipHostFree(L->h_mail); L->h_mail = nullptr; L->dh_mail = nullptr; L->h_mail_bytes = 0; }
             lease_ = nullptr;
             DevicePool::get().release(L);
@@ -1000,14 +1043,14 @@ class HipBackend : public Backend {
         in_bytes_ = c.off;
         zero_off_ = c.off;
         c.take(&d_results_, (size_t)H.result_bytes); c.take(&d_blk_hdr_, U * 8); c.take(&d_fallback_, U);
-        c.take(&d_refin_count_, 1); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1);
+        c.take(&d_refin_count_, 1); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1); c.take(&d_lat_sum_, 2);
         zero_bytes_ = c.off - zero_off_;
         c.take(&d_dags_, U);
         c.take(&d_ikeys_, (size_t)H.ideal_slots); c.take(&d_icnt_, (size_t)H.ideal_slots); c.take(&d_ilink_, (size_t)H.ideal_slots * 4 + 8);
         c.take(&d_ilvl_off_, U * (kMaxNodes + 3)); c.take(&d_icounter_, 2 * U); c.take(&d_ipos_, (size_t)H.ideal_slots);
         c.take(&d_aavail_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_acnt_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_acbase_, (size_t)H.ideal_slots / 2 + U + 1);
         c.take(&d_achild_, (size_t)H.ideal_slots * 4 + 8); c.take(&d_anblk_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_adepth_, (size_t)H.ideal_slots / 2 + 8);
-        c.take(&d_blk_off_, U + kMaxSlices + 1); c.take(&d_rows_, U); c.take(&d_needed_, kMaxSlices);
+        c.take(&d_blk_off_, U + kMaxSlices + 1); c.take(&d_rows_, U); c.take(&d_needed_, kMaxSlices); c.take(&d_lat_R_, U); c.take(&d_lat_status_, U);
         c.take(&d_scratch_, (size_t)H.scratch_ints + 8); c.take(&d_pack_off_, U + 1); c.take(&d_refin_list_, U);
         c.take(&d_first_rows_, U * (size_t)(cfg_.first_budget > 0 ? cfg_.first_budget : 1) * kFirstRowStride);
         const size_t img_stride = (size_t)std::max(block_lds_, ((160 * 1024) / 3) & ~15);   // (the budget per workgroup may be re-chosen after the first run)
@@ -1090,7 +1133,7 @@ class HipBackend : public Backend {
                                      (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel,
                                      (const void*)ambi_enumerate_kernel<0>, (const void*)ambi_enumerate_kernel<1>, (const void*)ambi_enumerate_kernel<2>,
                                      (const void*)ambi_enumerate_blocks_kernel<0>, (const void*)ambi_enumerate_blocks_kernel<1>, (const void*)ambi_enumerate_blocks_kernel<2>,
-                                     (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
+                                     (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_lattice_own_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
                                      (const void*)ambi_all_lanes_kernel, (const void*)ambi_order_paths_kernel};
                 for (const void* f : fns) { hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic); if (e != hipSuccess) err = e; }
             }
@@ -1167,6 +1210,10 @@ class HipBackend : public Backend {
             const char* e9 = getenv("AMBI_EXPRESS_UNITS"); express_units_ = e9 ? atoi(e9) : 32;
             lds_express_ = (int)express_work_bytes(H.max_n, H.max_m, H.max_k, H.max_bkp, finish_path_cells_, H.max_out) + 64;
             lds_lattice_ = (int)(64 * 8 + kPrepLatticeBytes + 64);
+            lds_lattice_own_ = (int)lattice_own_bytes(H.max_k) + 64;
+            const char* e8 = getenv("AMBI_SIDE_LATTICE");
+            side_lattice_ = (e8 ? atoi(e8) != 0 : true) && (int)U <= express_units_ && n_slices_ == 1;
+            if (side_lattice_ && (rc = lease_stream(L, 2, 0, &lattice_stream_))) return rc;
         }
         // result mailbox in pinned host memory: batches that can take the express path, while the slots stay small
         mail_off_.assign(U, 0); mail_bytes_ = 0; mail_on_ = false; mail_valid_ = false;
@@ -1199,7 +1246,7 @@ class HipBackend : public Backend {
         // first run ahead of its kernels) or, for large batches, a plain buffer copied at once
         uint8_t* img;
         const bool pinned = in_bytes_ <= kKeepStage;
-        if (pinned) { if ((rc = lease_pinned_block(&L->h_stage, nullptr, &L->h_stage_bytes, in_bytes_))) return rc; img = L->h_stage; }
+        if (pinned) { if ((rc = lease_pinned_block(&L->h_stage, &L->dh_stage, &L->h_stage_bytes, in_bytes_))) return rc; img = L->h_stage; }
         else { stage_big_.assign((size_t)in_bytes_, 0); img = stage_big_.data(); }
         auto put = [&](const void* dptr, const void* src, size_t bytes) { if (bytes) memcpy(img + (reinterpret_cast<const uint8_t*>(dptr) - L->d_block), src, bytes); };
         put(d_units_, H.units.data(), U * sizeof(UnitIn));
@@ -1226,8 +1273,16 @@ class HipBackend : public Backend {
     int flush_upload(hipStream_t st) {
         if (!upload_pending_) return 0;
         Lease* L = lease_;
-        HIP_CK(hipMemcpyAsync(L->d_block, L->h_stage, (size_t)in_bytes_, hipMemcpyHostToDevice, st));
-        HIP_CK(hipMemsetAsync(L->d_block + zero_off_, 0, (size_t)zero_bytes_, st));
+        if (in_bytes_ + zero_bytes_ <= (8ll << 20) && L->dh_stage && !getenv("AMBI_NO_INGEST")) {   // (every part of the block is 256-byte aligned)
+            const int64_t n16 = in_bytes_ / 16, z16 = zero_bytes_ / 16;
+            int64_t blocks = (std::max(n16, z16) + 255) / 256;
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(ambi_ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)L->dh_stage, (uint4*)L->d_block, n16,
+                               (uint4*)(L->d_block + zero_off_), z16);
+        } else {
+            HIP_CK(hipMemcpyAsync(L->d_block, L->h_stage, (size_t)in_bytes_, hipMemcpyHostToDevice, st));
+            HIP_CK(hipMemsetAsync(L->d_block + zero_off_, 0, (size_t)zero_bytes_, st));
+        }
         if (d_direct_cells_) hipLaunchKernelGGL(ambi_guard_fill_kernel, dim3(direct_slots_), dim3(32), 0, st, d_direct_cells_, direct_stride_, direct_slots_);
         upload_pending_ = false;
         return 0;
@@ -1250,6 +1305,7 @@ class HipBackend : public Backend {
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
         A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
+        A_.lat_R = d_lat_R_; A_.lat_status = d_lat_status_; A_.lat_sum = d_lat_sum_; A_.lat_seq = &lease_->dh_words->lat_seq; A_.lat_unsure = &lease_->dh_words->lat_unsure;
         A_.plan_seq = &lease_->dh_words->plan_seq; A_.late_flag = &lease_->dh_words->late_flag; A_.run_seq = run_seq_;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = getenv("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
     }
@@ -1305,11 +1361,18 @@ class HipBackend : public Backend {
             Ax.express_seq = dh_express_left_ + 1;
             Ax.run_seq = run_seq_;
             h_express_left_[0] = 0;
+            if (side_lattice_) { lease_->h_words->lat_unsure = 0; (void)hipEventRecord(ev_fork_, st); }   // the lattice kernel starts here, not behind the express kernel
             tick("ambi_express_kernel", s, 0, true);
             hipLaunchKernelGGL(ambi_express_kernel, dim3(A.n_units), dim3(256), lds_express_, st, Ax);
             tick("ambi_express_kernel", s, 0, false);
             (void)hipEventRecord(ev_express_, st);
             tick("ambi_plan_kernel", s, 1, true);
+            if (side_lattice_) {   // the lattice beside the express kernel, on a stream of its own; the plan kernel behind both
+                (void)hipStreamWaitEvent(lattice_stream_, ev_fork_, 0);
+                hipLaunchKernelGGL(ambi_lattice_own_kernel, dim3(A.n_units), dim3(64), lds_lattice_own_, lattice_stream_, A);
+                (void)hipEventRecord(lease_->ev_lat, lattice_stream_);
+                (void)hipStreamWaitEvent(st, lease_->ev_lat, 0);
+            } else
             hipLaunchKernelGGL(ambi_lattice_kernel, dim3(A.n_units), dim3(64), lds_lattice_, st, A);
         } else {
             tick("ambi_prepare_kernel", s, 0, true);
@@ -1332,7 +1395,8 @@ class HipBackend : public Backend {
             }
             tick("ambi_plan_kernel", s, 1, true);
         }
-        hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
+        if (express_ && side_lattice_) hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
+        else { BatchArgs Ap = A; Ap.lat_R = nullptr; hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, Ap); }
         tick("ambi_plan_kernel", s, 1, false);
         // (express chain: the lattice kernel reads the status, so the scan of the units the express kernel left stays behind
         // the plan kernel there)
@@ -1446,6 +1510,7 @@ class HipBackend : public Backend {
         if (!uploaded_) return -32;
         if (ran_ && !tuned_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
+        t_run_ = std::chrono::steady_clock::now();
         if (int rc = flush_upload(stream_)) return rc;
         run_seq_ = ++lease_->seq;
         mail_valid_ = false;
@@ -1500,6 +1565,7 @@ class HipBackend : public Backend {
             HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
         }
         ran_ = true; inflight_ = true;
+        t_launched_ = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run_).count();
         if (timing_) timed_runs_++;
         return 0;
     }
@@ -1722,6 +1788,8 @@ class HipBackend : public Backend {
     // kernel's verdict, which reaches it through pinned memory like the express kernel's.  Otherwise the same as wait().
     int wait_results() override {
         if (!ran_) return 0;
+        static const bool lat = getenv("AMBI_DEBUG_LATENCY") != nullptr;   // diagnostics: when the two pinned words arrived, from the start of run()
+        auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run_).count(); };
         if (express_ && !(A_.flags & FLAG_ALL) && ev_express_ && !late_refusal_) {
             // the kernel's last workgroup stores the run's sequence number into pinned host memory: a short spin on it
             // returns microseconds before an event wait would; the event wait is the fallback
@@ -1729,14 +1797,20 @@ class HipBackend : public Backend {
             bool seen = false;
             for (int spin = 0; spin < 400000 && !(seen = (*seq == run_seq_)); spin++) __builtin_ia32_pause();
             if (!seen) HIP_CK(hipEventSynchronize(ev_express_));
+            const double t_express = lat ? since() : 0;
             if (*(volatile int32_t*)h_express_left_ == 0) {
-                if (arena_checked_) { mail_valid_ = mail_on_; return 0; }
-                volatile int32_t* pseq = &lease_->h_words->plan_seq;
+                if (arena_checked_) { mail_valid_ = mail_on_; if (lat) fprintf(stderr, "ambigram latency: run() returned %.1f us, express word %.1f us\n", t_launched_, t_express); return 0; }
+                // fresh batch: the verdict of the side lattice kernel (every lattice fine, all tables together fit the arena), or
+                // else the plan kernel's
+                volatile int32_t* pseq = side_lattice_ ? &lease_->h_words->lat_seq : &lease_->h_words->plan_seq;
                 seen = false;
                 for (int spin = 0; spin < 400000 && !(seen = (*pseq == run_seq_)); spin++) __builtin_ia32_pause();
-                if (seen && *(volatile int32_t*)&lease_->h_words->late_flag == 0 && *(volatile int64_t*)h_needed_ <= slice_bytes_[0]) {
+                const bool fine = side_lattice_ ? *(volatile int32_t*)&lease_->h_words->lat_unsure == 0
+                                                : (*(volatile int32_t*)&lease_->h_words->late_flag == 0 && *(volatile int64_t*)h_needed_ <= slice_bytes_[0]);
+                if (seen && fine) {
                     arena_checked_ = true;     // every table of this batch fits the arena: true for all its runs
                     mail_valid_ = mail_on_;
+                    if (lat) fprintf(stderr, "ambigram latency: run() returned %.1f us, express word %.1f us, plan word %.1f us (fresh batch)\n", t_launched_, t_express, since());
                     return 0;
                 }
             }

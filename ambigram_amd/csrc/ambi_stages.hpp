@@ -285,6 +285,47 @@ AMBI_HD void stage_lattice(const G& g, const BatchArgs& A, int u, uint8_t* work 
     g.sync();
 }
 
+// The lattice stage of a small batch, run BESIDE the express stage instead of behind it: it does not wait for the express
+// stage's DAG but constructs the DAG itself from the solution elements (the same construct_dag_g: the same DAG), builds the
+// lattice / automaton / first rows, and parks R and its status in BatchArgs::lat_R / lat_status.  It does not touch the
+// unit's header (the express stage is writing it); plan_merge_lattice does, behind both.  Units the express stage ends
+// without a reconstruction (shortcut, infeasible) get a lattice nobody reads.
+AMBI_HD int64_t lattice_own_bytes(int K) { return prepare_persistent_bytes(K) + pad8(4 * 64) + pad8(sizeof(Rec3) * 64) + pad8(kPrepLatticeBytes); }
+template <class G>
+AMBI_HD void stage_lattice_own(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    const UnitIn U = A.units[u];
+    const int K = U.n_elem;
+    int64_t o = 0;
+    Dag* dag = reinterpret_cast<Dag*>(work + o); o += pad8(sizeof(Dag));
+    Element* elems = reinterpret_cast<Element*>(work + o); o += pad8(int64_t(sizeof(Element)) * (K > 0 ? K : 1));
+    int32_t* idx = reinterpret_cast<int32_t*>(work + o); o += pad8(4 * 64);
+    Rec3* loops = reinterpret_cast<Rec3*>(work + o); o += pad8(sizeof(Rec3) * 64);
+    uint8_t* lattice_mem = work + o;
+    copy_words(g, reinterpret_cast<uint32_t*>(elems), reinterpret_cast<const uint32_t*>(A.elems + U.elem_off), int64_t(sizeof(Element) / 4) * K);
+    g.sync();
+    int st = ST_ERR_NO_ELEMENTS;
+    uint64_t R = 0;
+    if (K > 0) {
+        DagScratch DS{idx, loops};
+        st = construct_dag_g(g, elems, K, U.seg_base, *dag, DS, nullptr);
+        g.sync();
+        if (st == ST_OK) st = prep_lattice(g, A, u, dag->pred, K, lattice_mem, &R);
+    }
+    if (g.tid() == 0) { A.lat_R[u] = R; A.lat_status[u] = st; }
+    g.sync();
+}
+// the plan stage's first step when the lattice ran beside the express stage: what stage_lattice would have written
+AMBI_HD void plan_merge_lattice(const BatchArgs& A, int u) {
+    UnitOut* out = unit_out(A.results, u);
+    if (out->status != ST_OK) return;
+    out->num_orders = (int64_t)A.lat_R[u];
+    const int st = A.lat_status[u];
+    if (st != ST_OK) {
+        out->status = st; out->order_off = kOrderOffNone;
+        if (A.late_flag) *A.late_flag = 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // plan: order-table offsets + enumerate work blocks (one thread block for the whole batch)
 // ---------------------------------------------------------------------------------------------
