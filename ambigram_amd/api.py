@@ -15,6 +15,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libambigram_hip.so")
 
 FLAG_REVERSED = 1
 FLAG_ALL = 2
+FLAG_LAZY_ORDERS = 4
 
 ST_OK, ST_SHORTCUT, ST_INFEASIBLE, ST_NO_VALID_ORDER = 0, 1, 2, 3
 

@@ -49,6 +49,7 @@ enum Status : int32_t {
 // run flags
 constexpr uint32_t FLAG_REVERSED = 1u;   // --reversed (localhap.cpp:37)
 constexpr uint32_t FLAG_ALL = 2u;        // --all      (localhap.cpp:38)
+constexpr uint32_t FLAG_LAZY_ORDERS = 4u; // the order tables (allTopologicalOrders' by-product) are not written by the run: on demand only
 
 // An element of the ILP solution, 16 bytes ("16K" term of SURVEY.md 8d).
 struct Element {

@@ -168,6 +168,15 @@ __global__ __launch_bounds__(64) void ambi_lattice_own_kernel(BatchArgs A) {
     }
 }
 
+// before the plan kernel is run a SECOND time over the same headers (tables written on demand, or after the arena grew): every
+// unit that has or was refused rows wants rows again
+__global__ void ambi_plan_reset_kernel(BatchArgs A) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= A.n_units) return;
+    UnitOut* out = unit_out(A.results, A.unit_base + i);
+    if (out->order_off >= 0 || out->order_off == kOrderOffNoRoom) out->order_off = kOrderOffWanted;
+}
+
 // Parallel form of plan_serial (ambi_stages.hpp): same prefix-sum semantics.
 __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
     __shared__ int64_t sh[17];
@@ -784,7 +793,7 @@ struct TimingEvents { const char* name; hipEvent_t a, b; };
 struct Lease {
     int device = 0;
     hipStream_t side[3][3] = {};        // [back, full, first][default, lowest, highest priority], created on first use
-    hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_back = nullptr, ev_first = nullptr, ev_full = nullptr, ev_plan = nullptr, ev_express = nullptr, ev_lat = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_back = nullptr, ev_first = nullptr, ev_full = nullptr, ev_plan = nullptr, ev_express = nullptr, ev_lat = nullptr, ev_tail = nullptr;
     PinnedWords* h_words = nullptr; PinnedWords* dh_words = nullptr;
     uint8_t* d_block = nullptr; int64_t d_block_bytes = 0;      // inputs + working set + result blob of the batch
     uint8_t* d_arena = nullptr; int64_t d_arena_bytes = 0;      // order tables
@@ -812,9 +821,19 @@ class DevicePool {
             for (size_t i = 0; i < free_.size(); i++)
                 if (free_[i]->device == dev) { *out = free_[i]; free_.erase(free_.begin() + (long)i); (*out)->uses++; return 0; }
         }
+        {   // the engine's streams want hardware queues of their own: say so when the runtime was started without them
+            static std::once_flag warned;
+            std::call_once(warned, [] {
+                const char* q = getenv("GPU_MAX_HW_QUEUES");
+                if (!q || atoi(q) < 8)
+                    fprintf(stderr, "ambigram_hip: warning: GPU_MAX_HW_QUEUES is %s when the engine creates its streams; with fewer than 8 hardware queues two of "
+                                    "them can share one and the finish kernels then run behind the order-table kernel instead of beside it (measured: 1.55 "
+                                    "instead of 1.10 ms per 4096-sample step).  Set GPU_MAX_HW_QUEUES=8 in the environment before the HIP runtime starts.\n", q ? q : "unset");
+            });
+        }
         Lease* L = new Lease();
         L->device = dev;
-        hipEvent_t* evs[] = {&L->ev_fork, &L->ev_prep, &L->ev_back, &L->ev_first, &L->ev_full, &L->ev_plan, &L->ev_express, &L->ev_lat};
+        hipEvent_t* evs[] = {&L->ev_fork, &L->ev_prep, &L->ev_back, &L->ev_first, &L->ev_full, &L->ev_plan, &L->ev_express, &L->ev_lat, &L->ev_tail};
         for (hipEvent_t* e : evs) HIP_CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_CK(hipHostMalloc((void**)&L->h_words, sizeof(PinnedWords)));
         memset(L->h_words, 0, sizeof(PinnedWords));
@@ -943,7 +962,8 @@ class HipBackend : public Backend {
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
     int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0, lds_lattice_own_ = 0;
-    bool side_lattice_ = false; hipStream_t lattice_stream_ = nullptr;   // env AMBI_SIDE_LATTICE=0: the lattice kernel behind the express kernel (round 2)
+    bool lazy_ = false, tables_written_ = false;   // FLAG_LAZY_ORDERS: the run leaves the order tables out; they are written on demand
+    bool side_lattice_ = false, flushed_ = false; hipStream_t lattice_stream_ = nullptr;   // env AMBI_SIDE_LATTICE=0: the lattice kernel behind the express kernel (round 2)
     uint64_t* d_lat_R_ = nullptr; int32_t* d_lat_status_ = nullptr; int64_t* d_lat_sum_ = nullptr;
     bool express_ = false;
     hipEvent_t ev_express_ = nullptr;
@@ -1361,14 +1381,20 @@ class HipBackend : public Backend {
             Ax.express_seq = dh_express_left_ + 1;
             Ax.run_seq = run_seq_;
             h_express_left_[0] = 0;
-            if (side_lattice_) { lease_->h_words->lat_unsure = 0; (void)hipEventRecord(ev_fork_, st); }   // the lattice kernel starts here, not behind the express kernel
+            // the lattice kernel starts beside the express kernel: behind the input image of a fresh batch, else behind the END of the
+            // previous run (an event recorded then: no marker in front of the express kernel now)
+            const bool side = side_lattice_ && !lazy_;
+            if (side) {
+                lease_->h_words->lat_unsure = 0;
+                if (flushed_) (void)hipEventRecord(ev_fork_, st);
+                (void)hipStreamWaitEvent(lattice_stream_, flushed_ ? ev_fork_ : lease_->ev_tail, 0);
+            }
             tick("ambi_express_kernel", s, 0, true);
             hipLaunchKernelGGL(ambi_express_kernel, dim3(A.n_units), dim3(256), lds_express_, st, Ax);
             tick("ambi_express_kernel", s, 0, false);
             (void)hipEventRecord(ev_express_, st);
             tick("ambi_plan_kernel", s, 1, true);
-            if (side_lattice_) {   // the lattice beside the express kernel, on a stream of its own; the plan kernel behind both
-                (void)hipStreamWaitEvent(lattice_stream_, ev_fork_, 0);
+            if (side) {   // the lattice beside the express kernel, on a stream of its own; the plan kernel behind both
                 hipLaunchKernelGGL(ambi_lattice_own_kernel, dim3(A.n_units), dim3(64), lds_lattice_own_, lattice_stream_, A);
                 (void)hipEventRecord(lease_->ev_lat, lattice_stream_);
                 (void)hipStreamWaitEvent(st, lease_->ev_lat, 0);
@@ -1395,7 +1421,8 @@ class HipBackend : public Backend {
             }
             tick("ambi_plan_kernel", s, 1, true);
         }
-        if (express_ && side_lattice_) hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
+        if (lazy_) {}   // no tables in this run: nothing to plan
+        else if (express_ && side_lattice_) hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, A);
         else { BatchArgs Ap = A; Ap.lat_R = nullptr; hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, st, Ap); }
         tick("ambi_plan_kernel", s, 1, false);
         // (express chain: the lattice kernel reads the status, so the scan of the units the express kernel left stays behind
@@ -1417,7 +1444,7 @@ class HipBackend : public Backend {
     // tables, first run) every unit gets its own workgroup.
     int finish_grid_for(int U) const {
         if (finish_grid_ > 0) return U < finish_grid_ ? U : finish_grid_;          // env AMBI_FINISH_GRID
-        if (!overlap_back_) return U;
+        if (!overlap_back_ || lazy_) return U;   // (no order table being written: nothing to hide behind, every unit its own workgroup)
         const double enum_us = (double)last_needed_ / 5.2e6;                        // order-table bytes of the previous run at an optimistic 5.2 TB/s
         const double unit_us = 4.0 + avg_path_ / 900.0 + hb().max_m / 64.0;          // one unit through the lean finish stage (mean path capacity of the batch)
         if (enum_us < 8.0 * unit_us) return U;
@@ -1454,12 +1481,15 @@ class HipBackend : public Backend {
         if (ahead) { launch_first(); if (first_ahead_ == 1) (void)hipStreamWaitEvent(st, ev_first_, 0); }
         tick("ambi_enumerate_kernel", s, 3, true);
         const int lds_emit = lds_blocks_;
+        if (lazy_) {}   // the tables are written on demand (materialise_tables)
+        else {
         if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
         if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
         if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
         if ((enum_classes_ & 1) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 2) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 4) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
+        }
         tick("ambi_enumerate_kernel", s, 3, false);
         if (!ahead) launch_first();
         // units with deletion / duplication candidates go straight to the full finish stage, on a stream of their own beside
@@ -1508,15 +1538,17 @@ class HipBackend : public Backend {
     // two host round trips in front of every fresh batch).  AMBI_SLICES > 1 (an experiment) keeps the sizing pass.
     int run(uint32_t flags, void* stream) override {
         if (!uploaded_) return -32;
-        if (ran_ && !tuned_) { if (int rc = tune_after_first_run()) return rc; }
+        if (ran_ && !tuned_ && tables_written_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
         t_run_ = std::chrono::steady_clock::now();
+        flushed_ = upload_pending_;
         if (int rc = flush_upload(stream_)) return rc;
         run_seq_ = ++lease_->seq;
         mail_valid_ = false;
         bind(flags);
         all_done_ = false;
         const int U = A_.n_units;
+        lazy_ = (flags & FLAG_LAZY_ORDERS) != 0 && n_slices_ == 1;
         // one slice: no copy commands around the kernels (see BatchArgs::zero_pending)
         const bool direct = n_slices_ == 1 && dh_npending_ && dh_needed_;
         if (!direct) { HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_)); HIP_CK(hipMemsetAsync(d_refin_count_, 0, sizeof(int32_t), stream_)); }
@@ -1553,7 +1585,8 @@ class HipBackend : public Backend {
             if (A.n_units <= 0) continue;
             if (s > 0 && stagger_) (void)hipStreamWaitEvent(slice_stream(s), ev_stage_[s - 1], 0);
             launch_front(s, A);
-            if (!(build_in_emit_ && shared_units_ == 0)) launch_build(s, A);
+            if (lazy_) { tick("ambi_blocks_build_kernel", s, 2, true); tick("ambi_blocks_build_kernel", s, 2, false); }
+            else if (!(build_in_emit_ && shared_units_ == 0)) launch_build(s, A);
             else { tick("ambi_blocks_build_kernel", s, 2, true); tick("ambi_blocks_build_kernel", s, 2, false); }   // nothing to build
             if (s + 1 < n_slices_) (void)hipEventRecord(ev_stage_[s], slice_stream(s));
             launch_back(s, A);
@@ -1564,6 +1597,8 @@ class HipBackend : public Backend {
             HIP_CK(hipMemcpyAsync(h_npending_, d_npending_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
             HIP_CK(hipMemcpyAsync(h_needed_, d_needed_, sizeof(int64_t) * n_slices_, hipMemcpyDeviceToHost, stream_));
         }
+        if (side_lattice_) (void)hipEventRecord(lease_->ev_tail, stream_);   // where the NEXT run's side lattice kernel may start
+        tables_written_ = !lazy_;
         ran_ = true; inflight_ = true;
         t_launched_ = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run_).count();
         if (timing_) timed_runs_++;
@@ -1588,6 +1623,35 @@ class HipBackend : public Backend {
             fprintf(stderr, "ambigram_hip: order-table arena of %lld bytes not available; keeping %lld bytes (units beyond it report ORDERS_CAPACITY)\n",
                     (long long)total, (long long)arena_bytes_);
         return grown;
+    }
+    // FLAG_LAZY_ORDERS: the order tables of the last run, now (plan -> image build -> enumerate on the caller's stream, waited
+    // for; the arena grows first if it must).  Every stream idle.
+    int materialise_tables() {
+        if (tables_written_ || !ran_) return 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            BatchArgs A = slice_args(0);
+            A.zero_pending = 1; A.host_pending = dh_npending_; A.host_needed = dh_needed_; A.lat_R = nullptr; A.plan_seq = nullptr; A.late_flag = nullptr;
+            hipLaunchKernelGGL(ambi_plan_reset_kernel, dim3((A.n_units + 255) / 256), dim3(256), 0, stream_, A);
+            hipLaunchKernelGGL(ambi_plan_kernel, dim3(1), dim3(1024), 0, stream_, A);
+            hipLaunchKernelGGL(ambi_blocks_build_kernel, dim3(A.n_units), dim3(256), lds_build_, stream_, A);
+            const int grid = enum_grid_;
+            if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(enum_threads_), lds_blocks_, stream_, A);
+            if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(enum_threads_), lds_blocks_, stream_, A);
+            if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(enum_threads_), lds_blocks_, stream_, A);
+            if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, stream_, A);
+            if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, stream_, A);
+            if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, stream_, A);
+            HIP_CK(hipGetLastError());
+            HIP_CK(hipStreamSynchronize(stream_));
+            const int64_t need = h_needed_[0];
+            if (need <= slice_bytes_[0] || attempt == 1) break;
+            const int64_t total = (need + (need >> 4) + 4096 + order_align_ - 1) & ~int64_t(order_align_ - 1);
+            if (!grow_arena(total)) break;
+            slice_base_[0] = 0; slice_bytes_[0] = arena_bytes_ & ~int64_t(order_align_ - 1);
+            bind(A_.flags);
+        }
+        tables_written_ = true;
+        return 0;
     }
     // the first complete run of a batch (every stream idle): did its tables fit the arena the lease had?
     int settle_first_run() {
@@ -1735,12 +1799,12 @@ class HipBackend : public Backend {
         if (!ran_) return 0;
         HIP_CK(hipStreamSynchronize(stream_));
         inflight_ = false;
-        if (int rc = settle_first_run()) return rc;
+        if (tables_written_) { if (int rc = settle_first_run()) return rc; }
         if (check_guards("wait")) return -31;
-        last_needed_ = 0;
-        for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s];
+        if (tables_written_) { last_needed_ = 0; for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s]; }
         late_refusal_ = lease_->h_words->late_flag != 0;
         if (*h_npending_ > 0) {
+            if (int rc = materialise_tables()) return rc;   // (FLAG_LAZY_ORDERS: the parallel search reads the tables)
             int rc = slow_path();
             if (rc) return rc;
             *h_npending_ = 0;
@@ -1790,7 +1854,7 @@ class HipBackend : public Backend {
         if (!ran_) return 0;
         static const bool lat = getenv("AMBI_DEBUG_LATENCY") != nullptr;   // diagnostics: when the two pinned words arrived, from the start of run()
         auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run_).count(); };
-        if (express_ && !(A_.flags & FLAG_ALL) && ev_express_ && !late_refusal_) {
+        if (express_ && !(A_.flags & FLAG_ALL) && ev_express_ && !late_refusal_ && (!lazy_ || arena_checked_)) {
             // the kernel's last workgroup stores the run's sequence number into pinned host memory: a short spin on it
             // returns microseconds before an event wait would; the event wait is the fallback
             volatile int32_t* seq = h_express_left_ + 1;
@@ -1877,6 +1941,8 @@ class HipBackend : public Backend {
         return 0;
     }
     int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
+        if (int rc = wait()) return rc;
+        if (int rc = materialise_tables()) return rc;
         UnitOut h;
         HIP_CK(hipMemcpy(&h, d_results_ + sizeof(UnitOut) * (size_t)unit, sizeof(UnitOut), hipMemcpyDeviceToHost));
         if (h.order_off < 0 || first < 0 || first + count > h.num_orders) return ST_ERR_BAD_INPUT;

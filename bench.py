@@ -285,6 +285,26 @@ def main():
                          "parse and the variableIdx map: %.1f /s" % (cnt, B, recon, cnt / whole if whole > 0 else 0),
                "cpu_model": model, "host_cores_available": os.cpu_count(), "compiled": "-O3", "port_at_O0": o0}
 
+    # ---- the step WITHOUT the order tables (AMBI_FLAG_LAZY_ORDERS: tables written on demand only).  The reference materialises
+    # every topological order (LGM.cpp:3380-3409) and so does the headline step; in default mode nothing reads that table
+    # (the scan reads the first orders the lattice stage unranks), so this is what the reconstructions alone cost.
+    lazy = None
+    if world == 1:
+        for _ in range(max(args.warmup, 1)):
+            batch.run(api.FLAG_LAZY_ORDERS, stream)
+        batch.wait(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            batch.run(api.FLAG_LAZY_ORDERS, stream)
+        batch.wait(); torch.cuda.synchronize()
+        dtl = time.perf_counter() - t1
+        batch.download()
+        assert [batch.unit_result(u)["path_indel_len"] for u in range(B)] == [r["path_indel_len"] for r in res]
+        lazy = {"ms_per_step": dtl / args.steps * 1e3, "value": B * args.steps / dtl, "unit": "reconstructions/s",
+                "what": "same batch, same results, AMBI_FLAG_LAZY_ORDERS: prepare (lattice, first 64 orders) -> scan -> finish; no plan / enumerate kernels, "
+                        "the order tables are written only when asked for (ambi_batch_unit_orders) or when a scan runs out of its 64-order budget"}
+        batch.run(0, stream); batch.wait(); batch.download()      # the tables again for the legs below
+
     # ---- two resident batches on two streams (double buffering): the latency-bound prepare / plan kernels of one batch
     # run under the HBM-bound enumerate kernel of the other.  Reported beside the headline value, which stays the plain
     # one-batch-after-the-other measurement; same units, every step a complete pass over one batch.
@@ -450,6 +470,7 @@ def main():
                                   ("%d-th" % args.sv_every) if args.sv_every > 0 else "no", B),
                    "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths (run-length form, expanded on rank 0) at the end of the timed steps", 2: "; one RCCL gather of the paths (run-length form) to rank 0 at the end of every step"}[gather_mode])},
         "roofline": roofline, "cpu_baseline": cpu, "single_sample": single, "pipelined": pipelined,
+        "step_without_table_ms": lazy["ms_per_step"] if lazy else None, "step_without_table": lazy,
         "ilp_assembly": ilp, "all_mode": all_mode,
     }
     print(json.dumps(out))

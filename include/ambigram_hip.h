@@ -23,6 +23,12 @@ extern "C" {
 /* run flags */
 #define AMBI_FLAG_REVERSED 1u /* --reversed (localhap.cpp:37,55) */
 #define AMBI_FLAG_ALL 2u      /* --all      (localhap.cpp:38,56) */
+/* Extension (no counterpart in the reference, which always materialises every topological order, LocalGenomicMap.cpp:3380-3409):
+ * the run does not WRITE the order tables.  Results are identical (the scan for the first valid order reads the first orders the
+ * lattice stage unranks, --all unranks in the kernel); the tables are written on demand -- when a unit's scan runs out of
+ * budget and the parallel search needs them, or when ambi_batch_unit_orders asks for rows.  bench.py reports the step with
+ * and without the tables (91 % of the default step's HBM bytes are this by-product). */
+#define AMBI_FLAG_LAZY_ORDERS 4u
 
 /* per-unit status (ambi_unit_result_t.status); negative values are errors */
 #define AMBI_ST_OK 0

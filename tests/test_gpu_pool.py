@@ -140,3 +140,34 @@ def test_guard_words_around_direct_path_areas(hip_lib, oracle, workdir, monkeypa
         edited += oc["path_indel"] != oc["path"]
     assert edited >= 5
     b.close()
+
+
+def test_lazy_orders_flag(hip_lib, oracle, workdir):
+    """AMBI_FLAG_LAZY_ORDERS: the run writes no order table; results are those of the default run, and the table is written
+    when rows are asked for.  Small batch (express path) and a batch through the ordinary kernel chain."""
+    cases = [_sample(workdir, "lz%d" % i, n=(64, 96)[i % 2], m=(128, 200)[i % 2], tier=("wide", "mixed", "chain")[i % 3], K=(9, 11, 7)[i % 3], seed=500 + i,
+                     n_del=i % 3, n_dup=i % 2) for i in range(40)]
+    for nunits in (3, 40):
+        gs, a, b = [], api.Batch(hip_lib), api.Batch(hip_lib)
+        for lh, sols in cases[:nunits]:
+            gs.append(api.Graph(hip_lib, lh)); a.add_chromosome_sol(gs[-1], 0, sols[0]); b.add_chromosome_sol(gs[-1], 0, sols[0])
+        a.upload(); a.run(0); a.download()
+        b.upload(); b.run(api.FLAG_LAZY_ORDERS); b.download()
+        for u in range(nunits):
+            ra, rb = a.unit_result(u), b.unit_result(u)
+            assert ra == rb, (u, ra, rb)
+            assert a.unit_path(u, 1).tolist() == b.unit_path(u, 1).tolist() and a.unit_bkp(u).tolist() == b.unit_bkp(u).tolist()
+            assert a.unit_out_juncs(u) == b.unit_out_juncs(u)
+        for u in (0, nunits - 1):
+            r = a.unit_result(u)
+            want = a.unit_orders(u, 0, r["num_orders"], r["n_nodes"])
+            got = b.unit_orders(u, 0, r["num_orders"], r["n_nodes"])          # written now
+            assert np.array_equal(want, got)
+        oc = oracle.run_bfb(*cases[0], keep_orders=True)["chr"][0]
+        r = b.unit_result(0)
+        assert b.unit_orders(0, 0, r["num_orders"], r["n_nodes"]).tolist() == oc["orders"]
+        # a lazy run after a default run and the other way round
+        a.run(api.FLAG_LAZY_ORDERS); a.download(); b.run(0); b.download()
+        for u in range(nunits):
+            assert a.unit_path(u, 1).tolist() == b.unit_path(u, 1).tolist()
+        a.close(); b.close()
