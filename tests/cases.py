@@ -12,6 +12,9 @@ def fixed_cases():
     return [
         ("readme6", os.path.join(DATA, "readme6.lh"), [os.path.join(DATA, "readme6.sol")]),
         ("trx_c2", os.path.join(DATA, "trx_c2.lh"), [os.path.join(DATA, "trx_c2_chr0.sol"), os.path.join(DATA, "trx_c2_chr1.sol")]),
+        # inputs reconstructed from the outputs README.md:166 / :146 hold (tests/golden/known_answers.json)
+        ("readme_c2", os.path.join(DATA, "readme_c2.lh"), [os.path.join(DATA, "readme_c2_chr0.sol"), os.path.join(DATA, "readme_c2_chr1.sol")]),
+        ("readme_i2", os.path.join(DATA, "readme_i2.lh"), [os.path.join(DATA, "readme_i2_chr0.sol"), os.path.join(DATA, "readme_i2_chr1.sol")]),
     ]
 
 

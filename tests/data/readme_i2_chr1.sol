@@ -1,0 +1,2 @@
+Optimal - objective value 0.00000000
+      8 x8 1 0

@@ -98,7 +98,7 @@ def test_config2_full_size_properties(hip_lib, oracle, workdir):
 
 
 def test_config3_batch_1024x64(hip_lib, oracle, workdir):
-    """BASELINE config 3: 1024 independent 64-seg samples in one batch; oracle spot-check on a subset."""
+    """BASELINE config 3: 1024 independent 64-seg samples in one batch, every one of them against the oracle."""
     graphs, b, samples = [], api.Batch(hip_lib), []
     for i in range(1024):
         s = synth.config_sample(3, i, tier=("chain", "wide", "mixed")[i % 3], K=(9, 9, 7)[i % 3])
@@ -115,10 +115,14 @@ def test_config3_batch_1024x64(hip_lib, oracle, workdir):
         d = np.abs(np.abs(p[1:]) - np.abs(p[:-1]))
         same = (p[1:] > 0) == (p[:-1] > 0)
         assert len(p) > 64 and ((d == 1) & same | (d <= 2) & ~same).all(), i   # adjacency or fold-back (<= 2 apart)
-    for i in range(0, 1024, 37):
-        oc = oracle.run_bfb(*samples[i])["chr"][0]
+    for i in range(1024):      # every sample against the oracle (it does a few hundred of these per second)
+        o = oracle.run_bfb(*samples[i])
+        oc = o["chr"][0]
         assert b.unit_path(i, 0).tolist() == oc["path"] and b.unit_path(i, 1).tolist() == oc["path_indel"], i
-        assert b.unit_out_juncs(i) == [tuple(x) for x in oracle.run_bfb(*samples[i])["out_juncs"]], i
+        assert b.unit_bkp(i).tolist() == oc["bkp"], i
+        assert b.unit_out_juncs(i) == [tuple(x) for x in o["out_juncs"]], i
+        r = b.unit_result(i)
+        assert (r["num_orders"], r["first_valid"], r["bias"]) == (oc["num_orders"], oc["first_valid"], oc["bias"]), i
 
 
 def test_config4_multichr_1024(hip_lib, oracle, workdir):

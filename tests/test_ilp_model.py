@@ -185,11 +185,19 @@ def test_row_descriptor_form_equals_loop_generator(hostsim_lib, workdir):
 
 
 @pytest.mark.gpu
-def test_ilp_entries_written_on_the_device(hip_lib, workdir):
-    """ambi_ilp_fill_kernel: bit-identical to the host generator, incl. config 2 (n = 256:
-    230 015 rows, 56.5 M non-zeros = 0.68 GB written)."""
+def test_ilp_entries_written_on_the_device(hip_lib, oracle, workdir):
+    """ambi_ilp_fill_kernel: bit-identical to the ORACLE's restatement of BFB_ILP -- its LITERAL form
+    (string-keyed map, the O(numPat^2) coefficient loop, LGM.cpp:4397-4752) wherever that finishes in seconds, its closed form
+    beyond -- and to the library's own host generator, incl. config 2 (n = 256: 230 015 rows, 56.5 M non-zeros = 0.68 GB written)."""
     for lh, c, juncs, ji in _row_form_cases(workdir):
-        _same_models(_model_from_engine(hip_lib, lh, c, juncs, ji, hip_lib, device=True), _model_from_engine(hip_lib, lh, c, juncs, ji, hip_lib))
+        d = _model_from_engine(hip_lib, lh, c, juncs, ji, hip_lib, device=True)
+        _same_models(d, _model_from_engine(hip_lib, lh, c, juncs, ji, hip_lib))
+        n = api.Graph(hip_lib, lh).chromosome(c)
+        _same(d, oracle.ilp(lh, c, juncs=juncs, junc_info=ji, literal=(n[1] - n[0] + 1) <= 17))
+    for n, seed in [(9, 1), (17, 2), (33, 3)]:          # the cases of test_synthetic_ilp_equality, entries written by the kernel
+        s = synth.make_sample(n, 2 * n + 4, "chain", 4, seed, imperfect=1, n_del=1, n_dup=1)
+        lh, _ = s.write(workdir, "ilpd%d" % n)
+        _same(_model_from_engine(hip_lib, lh, 0, "", False, hip_lib, device=True), oracle.ilp(lh, 0, literal=(n <= 17)))
     s = synth.make_sample(256, 512, "wide", 19, seed=2000)
     lh, _ = s.write(workdir, "ilp256")
     d = _model_from_engine(hip_lib, lh, 0, "", False, hip_lib, device=True)

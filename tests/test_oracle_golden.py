@@ -13,12 +13,14 @@ def _paths(log):
     return [l for l in log if l and (l[0].isdigit() or l.startswith("BFB"))]
 
 
-@pytest.mark.parametrize("case", ["readme6", "trx_c2"])
+@pytest.mark.parametrize("case", ["readme6", "trx_c2", "readme_c2", "readme_i2"])
 def test_known_answer_forward(oracle, case):
     k = KA[case]
     r = oracle.run_bfb(os.path.join(ROOT, k["lh"]), [os.path.join(ROOT, s) for s in k["sols"]])
     assert r["ok"], r["err"]
     assert _paths(r["log"]) == k["forward"]
+    if "reference_held_last_line" in k:   # README.md:146 / :166 -- what the reference itself holds for these two
+        assert r["log"][-1] == k["reference_held_last_line"]
 
 
 def test_known_answer_reversed(oracle):
