@@ -76,6 +76,7 @@ def _declare(L):
         "ambi_batch_wait_results": (C.c_int, [vp]),
         "ambi_batch_download": (C.c_int, [vp]),
         "ambi_batch_fetch_paths": (C.c_int, [vp]),
+        "ambi_batch_run_sharded": (C.c_int, [vp, u32, pi32, i32]),
         "ambi_batch_device_results": (C.c_int, [vp, _P(vp), pi64]),
         "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
         "ambi_batch_pack_runs": (C.c_int, [vp, i32, vp, vp, vp, vp, i64, vp, vp]),
@@ -362,6 +363,16 @@ class Batch:
 
     def download(self):
         self._ck(self.lib.ambi_batch_download(self.h), "download")
+
+    def run_sharded(self, flags=0, devices=None, n_devices=0):
+        """Upload + run + download with the units dealt round-robin over several devices, one host thread per device
+        (ambi_batch_run_sharded).  devices: list of device ordinals (an ordinal may repeat) or None for the first n_devices
+        visible devices (all if n_devices <= 0)."""
+        if devices is None:
+            self._ck(self.lib.ambi_batch_run_sharded(self.h, flags, None, n_devices), "run_sharded")
+        else:
+            d, pd = _arr(devices, np.int32)
+            self._ck(self.lib.ambi_batch_run_sharded(self.h, flags, pd, len(d)), "run_sharded")
 
     def fetch_paths(self):
         """Headers, final paths and output junctions on the host (small batches: read from the pinned mailbox the

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/ambigram_hip.h"
@@ -15,10 +17,28 @@ using namespace ambi;
 
 struct ambi_graph { LhGraph g; };
 
+// one device's share of a batch (ambi_batch_run_sharded): its own packed inputs, backend and result blob
+struct Shard {
+    HostBatch hb;
+    std::unique_ptr<Backend> be;
+    std::vector<uint8_t> blob;
+    std::vector<int> units;     // local unit -> unit of the batch
+    int device = 0, rc = 0;
+    bool uploaded = false;
+};
+
 struct ambi_batch {
     HostBatch hb;
     EngineConfig cfg;
     std::unique_ptr<Backend> be;
+    std::vector<std::unique_ptr<Shard>> shards;        // empty unless ambi_batch_run_sharded built them
+    std::vector<std::pair<int, int>> where;             // unit -> (shard, local unit)
+    // the backend that holds a unit's device-side state (DAG, order table, --all bitmaps) and the unit's index there
+    Backend* owner(int unit, int* local) const {
+        if (shards.empty()) { *local = unit; return be.get(); }
+        *local = where[unit].second;
+        return shards[where[unit].first]->be.get();
+    }
     std::vector<uint8_t> blob;
     bool uploaded = false, downloaded = false;
     bool mail_view = false;   // header / final paths / output junctions are read from the backend's pinned mailbox (ambi_batch_fetch_paths)
@@ -261,7 +281,7 @@ int ambi_batch_debug_inject_validity(ambi_batch_t* b, int32_t unit, const int8_t
 }
 int ambi_batch_upload(ambi_batch_t* b) {
     if (!b) return AMBI_ERR_ARG;
-    if (b->hb.units.empty()) return AMBI_ERR_STATE;
+    if (b->hb.units.empty() || !b->shards.empty()) return AMBI_ERR_STATE;
     b->hb.finalize();
     int rc = b->be->upload(b->hb, b->cfg);
     if (rc == 0) b->uploaded = true;
@@ -290,6 +310,71 @@ int ambi_batch_fetch_paths(ambi_batch_t* b) {
     if (b->downloaded) return 0;
     if (b->be->mail_slot(0)) { b->mail_view = true; return 0; }
     return ambi_batch_download(b);
+}
+// Multi-GPU below Python (`ambi_bfb_reconstruct_batch(..., device_or_minus1_for_all)`; the units are the iterations
+// of the loop localhap.cpp:111-265 and do not depend on each other): one host thread per device, the units dealt round-robin,
+// every shard through its own backend (upload -> run -> download), the result blobs merged into the batch's on the host.
+int ambi_batch_run_sharded(ambi_batch_t* b, uint32_t flags, const int32_t* devices, int32_t n_devices) {
+    if (!b) return AMBI_ERR_ARG;
+    if (b->hb.units.empty() || b->uploaded) return AMBI_ERR_STATE;   // (a batch is either uploaded to one device or sharded)
+    std::vector<int> devs;
+    if (n_devices > 0 && devices) devs.assign(devices, devices + n_devices);
+    else {
+        int n = 0;
+        b->be->device_count(&n);
+        if (n_devices > 0 && n_devices < n) n = n_devices;
+        if (n <= 0) return AMBI_ERR_NO_DEVICE;
+        for (int d = 0; d < n; d++) devs.push_back(d);
+    }
+    const int N = (int)devs.size(), U = (int)b->hb.units.size();
+    bool same = (int)b->shards.size() == N;
+    for (int k = 0; same && k < N; k++) same = b->shards[k]->device == devs[k];
+    if (!same) {
+        b->shards.clear(); b->where.assign(U, {0, 0});
+        for (int k = 0; k < N; k++) {
+            std::unique_ptr<Shard> s(new Shard());
+            s->device = devs[k];
+            s->hb.ideal_cap = b->hb.ideal_cap;
+            s->be.reset(make_backend());
+            b->shards.push_back(std::move(s));
+        }
+        for (int u = 0; u < U; u++) {
+            Shard& s = *b->shards[u % N];
+            int l = s.hb.add_unit_from(b->hb, u);
+            if (l < 0) return l;
+            s.units.push_back(u);
+            b->where[u] = {u % N, l};
+        }
+        for (auto& s : b->shards) s->hb.finalize();
+    }
+    b->hb.finalize();
+    b->downloaded = false; b->mail_view = false;
+    auto work = [&](Shard* s) {
+        s->rc = 0;
+        if (s->units.empty()) return;
+        if ((s->rc = s->be->set_device(s->device))) return;
+        if (!s->uploaded) { if ((s->rc = s->be->upload(s->hb, b->cfg))) return; s->uploaded = true; }
+        if ((s->rc = s->be->run(flags, nullptr))) return;
+        s->rc = s->be->download(s->blob);
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < N; k++) threads.emplace_back(work, b->shards[k].get());
+    work(b->shards[0].get());
+    for (auto& t : threads) t.join();
+    for (auto& s : b->shards) if (s->rc) return s->rc;
+    // merge: the header and the variable part of every unit go where a single-device download would have put them
+    b->blob.assign((size_t)b->hb.result_bytes, 0);
+    for (int u = 0; u < U; u++) {
+        const Shard& s = *b->shards[b->where[u].first];
+        const int l = b->where[u].second;
+        const UnitIn& P = b->hb.units[u];
+        const UnitIn& Q = s.hb.units[l];
+        memcpy(b->blob.data() + sizeof(UnitOut) * (size_t)u, s.blob.data() + sizeof(UnitOut) * (size_t)l, sizeof(UnitOut));
+        const UnitLayout L = unit_layout(P.n_seg, P.bkp_cap, P.path_cap, P.out_cap);
+        memcpy(b->blob.data() + P.res_off, s.blob.data() + Q.res_off, (size_t)L.total);
+    }
+    b->downloaded = true;
+    return 0;
 }
 int ambi_batch_device_results(ambi_batch_t* b, void** dev_ptr, int64_t* bytes) {
     if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
@@ -393,7 +478,9 @@ int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, 
     const UnitOut* h = header(b, unit);
     if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     Dag D;
-    int rc = b->be->copy_dag(unit, &D);
+    int local = unit;
+    Backend* be = b->owner(unit, &local);
+    int rc = be->copy_dag(local, &D);
     if (rc) return rc;
     const int base = b->hb.units[unit].seg_base;
     for (int i = 0; i < h->K; i++) {
@@ -418,21 +505,29 @@ int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, i
     return h->n_out_junc;
 }
 int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out) {
-    if (!b || !b->uploaded || !out) return AMBI_ERR_ARG;
-    return b->be->copy_orders(unit, first, count, out);
+    if (!b || !(b->uploaded || !b->shards.empty()) || !out || unit < 0 || unit >= (int)b->hb.units.size()) return AMBI_ERR_ARG;
+    int local = unit;
+    Backend* be = b->owner(unit, &local);
+    return be->copy_orders(local, first, count, out);
 }
 int ambi_batch_all_count(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t* count) {
-    if (!b || !b->uploaded || !count) return AMBI_ERR_ARG;
-    return b->be->all_count(unit, pass, count);
+    if (!b || !(b->uploaded || !b->shards.empty()) || !count || unit < 0 || unit >= (int)b->hb.units.size()) return AMBI_ERR_ARG;
+    int local = unit;
+    Backend* be = b->owner(unit, &local);
+    return be->all_count(local, pass, count);
 }
 int ambi_batch_all_orders(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int64_t* order_idx) {
-    if (!b || !b->uploaded || (!order_idx && count > 0)) return AMBI_ERR_ARG;
-    return b->be->all_orders(unit, pass, first, count, order_idx);
+    if (!b || !(b->uploaded || !b->shards.empty()) || (!order_idx && count > 0) || unit < 0 || unit >= (int)b->hb.units.size()) return AMBI_ERR_ARG;
+    int local = unit;
+    Backend* be = b->owner(unit, &local);
+    return be->all_orders(local, pass, first, count, order_idx);
 }
 int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells,
                          int64_t stride) {
-    if (!b || !b->uploaded || !lengths || !cells) return AMBI_ERR_ARG;
-    return b->be->all_paths(unit, pass, first, count, lengths, cells, stride);
+    if (!b || !(b->uploaded || !b->shards.empty()) || !lengths || !cells || unit < 0 || unit >= (int)b->hb.units.size()) return AMBI_ERR_ARG;
+    int local = unit;
+    Backend* be = b->owner(unit, &local);
+    return be->all_paths(local, pass, first, count, lengths, cells, stride);
 }
 int ambi_batch_all_set_shard(ambi_batch_t* b, int32_t rank, int32_t world) { return b ? b->be->set_shard(rank, world) : AMBI_ERR_ARG; }
 int ambi_batch_all_device(ambi_batch_t* b, void** ptr, int64_t* bytes) { return (b && b->uploaded) ? b->be->all_device(ptr, bytes) : AMBI_ERR_ARG; }

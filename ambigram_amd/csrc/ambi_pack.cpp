@@ -115,6 +115,33 @@ int HostBatch::add_graph_chr(const LhGraph& g, int chr, const SolFile* sol, int 
     return u;
 }
 
+int HostBatch::add_unit_from(const HostBatch& src, int u) {
+    if (u < 0 || u >= (int)src.units.size()) return ST_ERR_BAD_INPUT;
+    UnitIn U = src.units[u];
+    const UnitIn& S = src.units[u];
+    U.seg_off = (int64_t)seg_cn.size();
+    seg_cn.insert(seg_cn.end(), src.seg_cn.begin() + S.seg_off, src.seg_cn.begin() + S.seg_off + S.n_seg + 1);
+    U.junc_off = (int64_t)juncs.size();
+    juncs.insert(juncs.end(), src.juncs.begin() + S.junc_off, src.juncs.begin() + S.junc_off + S.n_junc);
+    junc_ends.insert(junc_ends.end(), src.junc_ends.begin() + S.junc_off, src.junc_ends.begin() + S.junc_off + S.n_junc);
+    U.elem_off = (int64_t)elems.size();
+    elems.insert(elems.end(), src.elems.begin() + S.elem_off, src.elems.begin() + S.elem_off + S.n_elem);
+    U.ideal_cap = ideal_cap;
+    units.push_back(U);
+    junc_global.push_back(src.junc_global[u]);
+    if ((size_t)u < src.inject_unit.size() && !src.inject_unit[u].empty()) { inject_unit.resize(units.size()); inject_unit.back() = src.inject_unit[u]; }
+    for (int j = 0; j < S.n_junc; j++) {   // (any_sv as add_unit derives it)
+        const Junction& J = src.juncs[S.junc_off + j];
+        const bool same = J.sdir == J.tdir;
+        const bool normal = same && ((J.sdir > 0 && J.tgt - J.src == 1) || (J.sdir <= 0 && J.src - J.tgt == 1));
+        const bool fbi = !same && std::abs(J.src - J.tgt) <= 2;
+        if (!normal && !fbi) any_sv = true;
+    }
+    max_n = std::max(max_n, U.n_seg); max_m = std::max(max_m, U.n_junc); max_k = std::max(max_k, U.n_elem);
+    max_bkp = std::max(max_bkp, U.bkp_cap); max_path = std::max(max_path, U.path_cap); max_out = std::max(max_out, U.out_cap);
+    return (int)units.size() - 1;
+}
+
 void HostBatch::finalize() {
     int64_t off = header_bytes();
     off = (off + 15) & ~int64_t(15);

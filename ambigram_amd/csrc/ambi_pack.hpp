@@ -40,6 +40,9 @@ struct HostBatch {
     // [block*numComp, (block+1)*numComp) of a joint .sol; such a unit never takes the no-fold-back shortcut (that decision
     // is the caller's, from the first graph alone, localhap.cpp:505-512).
     int add_graph_chr(const LhGraph& g, int chr, const SolFile* sol, int block = 0, int n_blocks = 0);
+    // Appends a copy of unit `u` of another batch (its packed inputs, capacities, junction map, injected verdicts): how a batch
+    // is dealt over several devices (ambi_batch_run_sharded).  Returns the new unit's index.
+    int add_unit_from(const HostBatch& src, int u);
     void finalize();                          // computes result/ideal/scratch offsets
     int64_t header_bytes() const { return int64_t(sizeof(UnitOut)) * (int64_t)units.size(); }
 };

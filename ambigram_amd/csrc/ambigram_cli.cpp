@@ -237,6 +237,230 @@ int run_sc_bfb(Args& A) {
     return 0;
 }
 
+
+// `--op bfb` (localhap.cpp:49-388).  One sample = the reference's behaviour, line for line.  Extensions (no counterpart in the
+// reference, whose --in_lh names one file for this op): --in_lh may be a comma-separated LIST of samples -- every sample goes
+// through its own ILP / solver stage in turn, then the chromosomes of ALL samples are reconstructed as ONE batch -- and
+// --devices N|all deals that batch over several GPUs (ambi_batch_run_sharded: one host thread per device, round-robin).
+// Every sample's stdout lines and side-file rows are what a run on that sample alone prints, in sample order.
+struct Sample {
+    std::string lh;
+    ambi_graph_t* g = nullptr;
+    int32_t n_seg = 0, n_junc = 0, n_chr = 0, ins_mode = 0, con_mode = 0;
+    char main_chr[256] = {0};
+    std::vector<double> cn_all;
+    std::vector<int32_t> seg_start, seg_end;
+    std::vector<std::string> head;       // lines the reference prints before a chromosome's path lines
+    std::vector<int> unit;               // chromosome -> unit of the reconstruct batch
+    int num_inv = 0;
+    std::chrono::steady_clock::time_point t_begin;
+};
+
+int run_bfb(Args& A) {
+    const std::string prefix = A.kv["lp_prefix"], juncs = A.kv.count("juncdb") ? A.kv["juncdb"] : "";
+    const bool junc_info = truthy(A.kv["junc_info"]), reversed = truthy(A.kv["reversed"]), all = truthy(A.kv["all"]);
+    const double solver_timeout = A.kv.count("solver_timeout") ? atof(A.kv["solver_timeout"].c_str()) : 0;   // extension: seconds, 0 = none
+    int n_devices = 0;                   // 0: one device, the classic path; > 0: that many; -1: all visible
+    std::vector<int32_t> device_list;    // or an explicit list of ordinals "0,1,1" (an ordinal may repeat: several shares on one device)
+    if (A.kv.count("devices")) {
+        const std::string d = A.kv["devices"];
+        if (d.find(',') != std::string::npos) {
+            std::stringstream ss(d);
+            std::string t;
+            while (std::getline(ss, t, ',')) if (!t.empty()) device_list.push_back(atoi(t.c_str()));
+            n_devices = (int)device_list.size();
+        } else n_devices = (d == "all") ? -1 : atoi(d.c_str());
+    }
+    std::vector<std::string> files;
+    {
+        std::stringstream ss(A.kv["in_lh"]);
+        std::string f;
+        while (std::getline(ss, f, ',')) if (!f.empty()) files.push_back(f);
+        if (files.empty()) files.push_back(A.kv["in_lh"]);
+    }
+    int rc;
+    std::vector<Sample> samples(files.size());
+    ambi_batch_t* b; ambi_batch_create(&b);
+    int n_units = 0;
+    for (size_t si = 0; si < files.size(); si++) {
+        Sample& S = samples[si];
+        S.lh = files[si];
+        S.t_begin = std::chrono::steady_clock::now();
+        rc = ambi_graph_read_lh(S.lh.c_str(), &S.g);
+        if (rc == AMBI_ERR_OPEN) return die("Cannot open file " + S.lh);            // Graph.cpp:111-114
+        if (rc != 0) return die(std::string("input error: ") + ambi_error_string(rc));
+        ambi_graph_t* g = S.g;
+        size_t printed = 0;
+        print_log(g, &printed);
+        if (!juncs.empty()) { if ((rc = ambi_graph_read_juncs(g, juncs.c_str())) != 0) return die(ambi_error_string(rc)); print_log(g, &printed); }
+        ambi_graph_sizes(g, &S.n_seg, &S.n_junc, &S.n_chr);
+        ambi_graph_props(g, &S.ins_mode, &S.con_mode, S.main_chr, sizeof(S.main_chr));
+        S.cn_all.resize(S.n_seg); S.seg_start.resize(S.n_seg); S.seg_end.resize(S.n_seg);
+        ambi_graph_segments(g, nullptr, nullptr, S.seg_start.data(), S.seg_end.data(), nullptr, S.cn_all.data());
+        S.head.assign(S.n_chr, ""); S.unit.assign(S.n_chr, -1);
+        // Two batches, every chromosome a unit:
+        //   probe batch   -- localhap.cpp:136-170 for all chromosomes of the sample at once: junction CNs, bias, getIndelBias, shortcut;
+        //   solve         -- per chromosome, in order: ILP model -> <prefix>.lp/.mps -> `cbc` -> <prefix>.sol (the reference
+        //                    reuses the same file names for every chromosome, so each .sol is taken in right after its solve);
+        //   reconstruct batch -- localhap.cpp:222-262 for all chromosomes (of all samples) at once.
+        // This program's own stdout lines come out in the reference's order (per chromosome: the three ILP progress lines, then
+        // the path lines); they are held back until the reconstruct batch is done, so only the solver's own chatter, which
+        // the reference interleaves between them, moves to the front.  Both batches take their streams, events, pinned words and
+        // device blocks from the engine's per-device pool: one resident context serves them in turn.
+        ambi_batch_t* probe; ambi_batch_create(&probe);
+        for (int c = 0; c < S.n_chr; c++)
+            if ((rc = ambi_batch_add_chromosome(probe, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
+        if ((rc = ambi_batch_upload(probe)) != 0 || (rc = ambi_batch_run(probe, 0, nullptr)) != 0 || (rc = ambi_batch_download(probe)) != 0)
+            return die(std::string("engine: ") + ambi_error_string(rc));
+        for (int c = 0; c < S.n_chr; c++) {
+            int32_t s, e;
+            ambi_graph_chromosome(g, c, &s, &e);
+            const int n = e - s + 1;
+            ambi_unit_result_t pr; ambi_batch_unit_result(probe, c, &pr);
+            std::vector<double> junc_cn(2 * (n + 1)), seg_cn(n + 1);
+            std::vector<int32_t> inv(n + 1);
+            ambi_batch_unit_prepare(probe, c, junc_cn.data(), seg_cn.data(), nullptr, inv.data());
+            // getIndelBias of chromosome c has edited its segment CNs (localhap.cpp:147); the ILP of chromosome c sees the
+            // edits of chromosomes <= c only (its loop bound is the CN sum over ALL segments, LGM.cpp:4708-4711)
+            for (int i = 1; i <= n; i++) { S.cn_all[s - 1 + i - 1] = seg_cn[i]; if (inv[i] >= 0) S.num_inv++; }
+            if (pr.status == AMBI_ST_SHORTCUT) {
+                if ((rc = ambi_batch_add_chromosome(b, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
+                S.unit[c] = rc; n_units++;
+                continue;
+            }
+            double max_cn = 0;
+            for (double v : S.cn_all) max_cn += v;
+            ambi_ilp_t* ilp = nullptr;
+            // BFB_ILP (LGM.cpp:4397-4752): the rows are listed on the host, the non-zeros (56.5 M at 256 segments) written by
+            // ambi_ilp_fill_kernel on the device; small chromosomes are not worth the launch and take the host generator
+            if (n >= 32) rc = ambi_ilp_build_device(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, nullptr, &ilp);
+            else rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp);
+            if (rc != 0) return die(ambi_error_string(rc));
+            S.head[c] = "Declare done\nILP formula done\nVariable constrains done\n";
+            ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());   // LGM.cpp:4749-4750: both side files
+            ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
+            ambi_ilp_destroy(ilp);
+            (void)remove(("./" + prefix + ".sol").c_str());        // a stale .sol of an earlier chromosome or run must not pass for this solve
+            std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181
+            if (solver_timeout > 0) { char t[64]; snprintf(t, sizeof(t), "timeout -k 5 %.0f ", solver_timeout); cmd = t + cmd; }
+            std::cout.flush();
+            const int solver_rc = system(cmd.c_str());
+            // the reference ignores the exit status (a missing .sol is what it notices, localhap.cpp:187-190); say what happened
+            if (solver_rc != 0) {
+                const int code = WIFEXITED(solver_rc) ? WEXITSTATUS(solver_rc) : -1;
+                if (solver_timeout > 0 && code == 124) std::cerr << "ILP error: cbc did not finish within " << solver_timeout << " s (chromosome " << c << ")" << std::endl;
+                else std::cerr << "ILP warning: `" << cmd << "` ended with status " << code << std::endl;
+            }
+            rc = ambi_batch_add_chromosome_sol(b, g, c, ("./" + prefix + ".sol").c_str());
+            if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:187-190
+            if (rc < 0) return die(ambi_error_string(rc));
+            S.unit[c] = rc; n_units++;
+        }
+        ambi_batch_destroy(probe);
+    }
+    const uint32_t flags = (reversed ? AMBI_FLAG_REVERSED : 0u) | (all ? AMBI_FLAG_ALL : 0u);
+    if (n_devices != 0) rc = ambi_batch_run_sharded(b, flags, device_list.empty() ? nullptr : device_list.data(), n_devices);
+    else if ((rc = ambi_batch_upload(b)) == 0 && (rc = ambi_batch_run(b, flags, nullptr)) == 0) rc = ambi_batch_download(b);
+    if (rc != 0) return die(std::string("engine: ") + ambi_error_string(rc));
+    int refused_total = 0;
+    for (Sample& S : samples) {
+        ambi_graph_t* g = S.g;
+        std::vector<std::vector<int32_t>> paths(S.n_chr);
+        std::vector<OutJ> out_acc;
+        int refused = 0;
+        for (int c = 0; c < S.n_chr; c++) {
+            const int u = S.unit[c];
+            std::cout << S.head[c];
+            ambi_unit_result_t r; ambi_batch_unit_result(b, u, &r);
+            if (r.status < 0 || r.status == AMBI_ST_NO_VALID_ORDER) {
+                // where the reference would print this chromosome's path.  AMBI_ERR_REF_UB: the reference itself reads past the
+                // end of its breakpoint vector on this input (LGM.cpp:3436-3442) -- whatever it prints there is not defined by
+                // its source, so nothing is printed here; the other chromosomes follow, the exit status is 1.
+                std::cout.flush();
+                std::cerr << "bfb: chromosome " << c << ": " << ambi_error_string(r.status) << std::endl;
+                refused++;
+                continue;
+            }
+            std::vector<int32_t> p(r.path_len), q(r.path_indel_len);
+            ambi_batch_unit_path(b, u, 0, p.data(), r.path_len);
+            ambi_batch_unit_path(b, u, 1, q.data(), r.path_indel_len);
+            if (all && r.status == AMBI_ST_OK) {
+                // --all: one line per valid order; the flipped orientation only if the last order was invalid (LGM.cpp:3672-3695)
+                const int64_t stride = 2ll * r.path_len + 64;
+                for (int pass = 0; pass < 2; pass++) {
+                    int64_t nv = 0;
+                    ambi_batch_all_count(b, u, pass, &nv);
+                    for (int64_t lo = 0; lo < nv; lo += 64) {
+                        const int64_t cnt = nv - lo < 64 ? nv - lo : 64;
+                        std::vector<int32_t> len((size_t)cnt), cells((size_t)(cnt * stride));
+                        if ((rc = ambi_batch_all_paths(b, u, pass, lo, cnt, len.data(), cells.data(), stride)) != 0)
+                            return die(std::string("bfb --all: ") + ambi_error_string(rc));
+                        for (int64_t j = 0; j < cnt; j++) {
+                            if (len[j] < 0) return die(std::string("bfb --all: ") + ambi_error_string(len[j]));
+                            std::vector<int32_t> pj(cells.begin() + j * stride, cells.begin() + j * stride + len[j]);
+                            std::cout << path_text(g, pj) << std::endl;
+                        }
+                    }
+                }
+            } else
+                std::cout << path_text(g, p) << std::endl;                               // printBFB (LGM.cpp:3411-3429)
+            if (r.status == AMBI_ST_INFEASIBLE) std::cout << "ILP is unsolvable.\n";    // localhap.cpp:217
+            else if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(g, q) << std::endl;
+            paths[c] = q;
+            std::vector<int32_t> ju(r.n_out_junc), jv(r.n_out_junc), jc(r.n_out_junc);
+            ambi_batch_unit_out_juncs(b, u, ju.data(), jv.data(), jc.data(), r.n_out_junc);
+            for (int k = 0; k < r.n_out_junc; k++) merge_steps(out_acc, ju[k], jv[k], jc[k], true);   // localhap.cpp:267-289
+        }
+        if (refused) { refused_total += refused; continue; }     // (this sample has no translocation stage and leaves no side-file rows)
+        int path_len = 0, cn_sum = 0, max_cn_i = 0;
+        for (auto& p : paths) path_len += (int)p.size();
+        for (double v : S.cn_all) { cn_sum += v; max_cn_i = (max_cn_i > v) ? max_cn_i : v; }   // localhap.cpp:290-293 (int fed with doubles)
+        if (S.ins_mode == 2 || S.con_mode == 2) {   // localhap.cpp:295-316
+            if (!S.main_chr[0]) return die("BFB-TRX needs PROP M:<chr>");
+            std::cout << "BFB with translocation:\n";
+            std::vector<int64_t> offs(S.n_chr + 1, 0);
+            for (int c = 0; c < S.n_chr; c++) offs[c + 1] = offs[c] + (int64_t)paths[c].size();
+            std::vector<int32_t> flat((size_t)offs[S.n_chr] + 1), out((size_t)offs[S.n_chr] * 2 + 16);
+            for (int c = 0; c < S.n_chr; c++) std::copy(paths[c].begin(), paths[c].end(), flat.begin() + offs[c]);
+            int len = ambi_translocation_bfb(g, flat.data(), offs.data(), S.n_chr, out.data(), (int32_t)out.size());
+            if (len < 0) return die(ambi_error_string(len));
+            out.resize(len);
+            std::cout << path_text(g, out) << std::endl;
+            for (int i = 0; i + 1 < len; i++) {
+                int u = out[i], v = out[i + 1];
+                if (!(std::abs(std::abs(u) - std::abs(v)) == 1 && (u > 0) == (v > 0))) merge_steps(out_acc, u, v, 1, false);
+            }
+        }
+        // side files (localhap.cpp:326-337, 382-388)
+        {
+            int32_t n_seg = S.n_seg, n_junc = S.n_junc, n_chr = S.n_chr;
+            ambi_graph_sizes(g, &n_seg, &n_junc, &n_chr);
+            std::vector<int32_t> js(n_junc), jt(n_junc); std::vector<int8_t> jsd(n_junc), jtd(n_junc); std::vector<double> jcn(n_junc);
+            ambi_graph_junctions(g, js.data(), jsd.data(), jt.data(), jtd.data(), nullptr, jcn.data(), nullptr, nullptr);
+            auto chrom = [&](int id) { char nm[256]; ambi_graph_chrom_name(g, id, nm, sizeof(nm)); return std::string(nm); };
+            auto vend = [&](int id, int dir) { return dir > 0 ? S.seg_end[id - 1] : S.seg_start[id - 1]; };      // Vertex::getEnd
+            auto vstart = [&](int id, int dir) { return dir > 0 ? S.seg_start[id - 1] : S.seg_end[id - 1]; };    // Vertex::getStart
+            std::ofstream sv("simulation_sv.txt", std::ios_base::app);
+            for (int j = 0; j < n_junc; j++)
+                sv << S.lh << "\t" << juncs << "\t" << chrom(js[j]) << "\t" << vend(js[j], jsd[j]) << "\t" << (jsd[j] > 0 ? '+' : '-') << "\t"
+                   << chrom(jt[j]) << "\t" << vstart(jt[j], jtd[j]) << "\t" << (jtd[j] > 0 ? '+' : '-') << "\t" << jcn[j] << "\tinput\n";
+            for (auto& j : out_acc) {
+                int a = std::abs(j.u), bb = std::abs(j.v), ad = j.u > 0 ? 1 : -1, bd = j.v > 0 ? 1 : -1;
+                sv << S.lh << "\t" << juncs << "\t" << chrom(a) << "\t" << vend(a, ad) << "\t" << (ad > 0 ? '+' : '-') << "\t"
+                   << chrom(bb) << "\t" << vstart(bb, bd) << "\t" << (bd > 0 ? '+' : '-') << "\t" << j.cn << "\toutput\n";
+            }
+            auto t_end = std::chrono::steady_clock::now();
+            std::ofstream tf("time.csv", std::ios_base::app);
+            tf << S.lh.substr(0, S.lh.find(".")) << "," << n_seg << "," << S.num_inv << "," << n_junc - S.num_inv << "," << cn_sum << "," << path_len << ","
+               << max_cn_i << "," << std::chrono::duration_cast<std::chrono::microseconds>(t_end - S.t_begin).count() / 1000000.0 << "\n";
+        }
+    }
+    ambi_batch_destroy(b);
+    for (Sample& S : samples) ambi_graph_destroy(S.g);
+    if (refused_total) return die("bfb: " + std::to_string(refused_total) + " chromosome(s) without a path");
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -244,185 +468,13 @@ int main(int argc, char** argv) {
     Args A = parse(argc, argv);
     if (A.help) {
         std::cout << "Local Haplotype constructer\nUsage:\n  Ambigram --op bfb|sc_bfb --in_lh <file[,file...]> --lp_prefix <name> [--juncdb <file> --junc_info true] "
-                     "[--reversed true] [--all true] [--solver_timeout <seconds>]\n";
+                     "[--reversed true] [--all true] [--solver_timeout <seconds>] [--devices N|all|<ordinal,ordinal,...>]\n"
+                     "  --op bfb: --in_lh may list several samples; their chromosomes are reconstructed as one batch, over the devices named by --devices\n";
         return 0;
     }
     const std::string op = A.kv.count("op") ? A.kv["op"] : "";
     std::cout << op << std::endl;   // localhap.cpp:47
     if (op == "sc_bfb") return run_sc_bfb(A);
     if (op != "bfb") return 0;   // the reference does nothing for any other op (localhap.cpp:49, :390)
-    auto t_begin = std::chrono::steady_clock::now();
-    const std::string lh = A.kv["in_lh"], prefix = A.kv["lp_prefix"], juncs = A.kv.count("juncdb") ? A.kv["juncdb"] : "";
-    const bool junc_info = truthy(A.kv["junc_info"]), reversed = truthy(A.kv["reversed"]), all = truthy(A.kv["all"]);
-
-    ambi_graph_t* g = nullptr;
-    int rc = ambi_graph_read_lh(lh.c_str(), &g);
-    if (rc == AMBI_ERR_OPEN) return die("Cannot open file " + lh);            // Graph.cpp:111-114
-    if (rc != 0) return die(std::string("input error: ") + ambi_error_string(rc));
-    size_t printed = 0;
-    print_log(g, &printed);
-    if (!juncs.empty()) { if ((rc = ambi_graph_read_juncs(g, juncs.c_str())) != 0) return die(ambi_error_string(rc)); print_log(g, &printed); }
-    int32_t n_seg, n_junc, n_chr, ins_mode, con_mode;
-    char main_chr[256];
-    ambi_graph_sizes(g, &n_seg, &n_junc, &n_chr);
-    ambi_graph_props(g, &ins_mode, &con_mode, main_chr, sizeof(main_chr));
-    std::vector<double> cn_all(n_seg);
-    std::vector<int32_t> seg_start(n_seg), seg_end(n_seg);
-    ambi_graph_segments(g, nullptr, nullptr, seg_start.data(), seg_end.data(), nullptr, cn_all.data());
-
-    std::vector<std::vector<int32_t>> paths(n_chr);
-    std::vector<OutJ> out_acc;
-    int num_inv = 0;
-    // Two batches for the whole sample, every chromosome a unit:
-    //   probe batch   -- localhap.cpp:136-170 for all chromosomes at once: junction CNs, bias, getIndelBias, shortcut;
-    //   solve         -- per chromosome, in order: ILP model -> <prefix>.lp/.mps -> `cbc` -> <prefix>.sol (the reference
-    //                    reuses the same file names for every chromosome, so each .sol is taken in right after its solve);
-    //   reconstruct batch -- localhap.cpp:222-262 for all chromosomes at once.
-    // This program's own stdout lines come out in the reference's order (per chromosome: the three ILP progress lines, then
-    // the path lines); they are held back until the reconstruct batch is done, so only the solver's own chatter, which
-    // the reference interleaves between them, moves to the front.
-    ambi_batch_t* probe; ambi_batch_create(&probe);
-    for (int c = 0; c < n_chr; c++)
-        if ((rc = ambi_batch_add_chromosome(probe, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
-    if ((rc = ambi_batch_upload(probe)) != 0 || (rc = ambi_batch_run(probe, 0, nullptr)) != 0 || (rc = ambi_batch_download(probe)) != 0)
-        return die(std::string("engine: ") + ambi_error_string(rc));
-    ambi_batch_t* b; ambi_batch_create(&b);
-    std::vector<std::string> head(n_chr);   // lines the reference prints before a chromosome's path lines
-    const double solver_timeout = A.kv.count("solver_timeout") ? atof(A.kv["solver_timeout"].c_str()) : 0;   // extension: seconds, 0 = none
-    for (int c = 0; c < n_chr; c++) {
-        int32_t s, e;
-        ambi_graph_chromosome(g, c, &s, &e);
-        const int n = e - s + 1;
-        ambi_unit_result_t pr; ambi_batch_unit_result(probe, c, &pr);
-        std::vector<double> junc_cn(2 * (n + 1)), seg_cn(n + 1);
-        std::vector<int32_t> inv(n + 1);
-        ambi_batch_unit_prepare(probe, c, junc_cn.data(), seg_cn.data(), nullptr, inv.data());
-        // getIndelBias of chromosome c has edited its segment CNs (localhap.cpp:147); the ILP of chromosome c sees the
-        // edits of chromosomes <= c only (its loop bound is the CN sum over ALL segments, LGM.cpp:4708-4711)
-        for (int i = 1; i <= n; i++) { cn_all[s - 1 + i - 1] = seg_cn[i]; if (inv[i] >= 0) num_inv++; }
-        if (pr.status == AMBI_ST_SHORTCUT) {
-            if ((rc = ambi_batch_add_chromosome(b, g, c, 0, nullptr, nullptr, 0)) < 0) return die(ambi_error_string(rc));
-            continue;
-        }
-        double max_cn = 0;
-        for (double v : cn_all) max_cn += v;
-        ambi_ilp_t* ilp = nullptr;
-        // BFB_ILP (LGM.cpp:4397-4752): the rows are listed on the host, the non-zeros (56.5 M at 256 segments) written by
-        // ambi_ilp_fill_kernel on the device; small chromosomes are not worth the launch and take the host generator
-        if (n >= 32) rc = ambi_ilp_build_device(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, nullptr, &ilp);
-        else rc = ambi_ilp_build(g, c, seg_cn.data(), junc_cn.data(), pr.bias, max_cn, junc_info ? 1 : 0, &ilp);
-        if (rc != 0) return die(ambi_error_string(rc));
-        head[c] = "Declare done\nILP formula done\nVariable constrains done\n";
-        ambi_ilp_write_mps(ilp, (prefix + ".mps").c_str());   // LGM.cpp:4749-4750: both side files
-        ambi_ilp_write_lp(ilp, (prefix + ".lp").c_str());
-        ambi_ilp_destroy(ilp);
-        (void)remove(("./" + prefix + ".sol").c_str());        // a stale .sol of an earlier chromosome or run must not pass for this solve
-        std::string cmd = "cbc " + prefix + ".lp solve solu " + prefix + ".sol";   // localhap.cpp:179-181
-        if (solver_timeout > 0) { char t[64]; snprintf(t, sizeof(t), "timeout -k 5 %.0f ", solver_timeout); cmd = t + cmd; }
-        std::cout.flush();
-        const int solver_rc = system(cmd.c_str());
-        // the reference ignores the exit status (a missing .sol is what it notices, localhap.cpp:187-190); say what happened
-        if (solver_rc != 0) {
-            const int code = WIFEXITED(solver_rc) ? WEXITSTATUS(solver_rc) : -1;
-            if (solver_timeout > 0 && code == 124) std::cerr << "ILP error: cbc did not finish within " << solver_timeout << " s (chromosome " << c << ")" << std::endl;
-            else std::cerr << "ILP warning: `" << cmd << "` ended with status " << code << std::endl;
-        }
-        rc = ambi_batch_add_chromosome_sol(b, g, c, ("./" + prefix + ".sol").c_str());
-        if (rc == AMBI_ERR_SOL_OPEN) return die("ILP error: cannot open file ./" + prefix + ".sol");   // localhap.cpp:187-190
-        if (rc < 0) return die(ambi_error_string(rc));
-    }
-    ambi_batch_destroy(probe);
-    if ((rc = ambi_batch_upload(b)) != 0 ||
-        (rc = ambi_batch_run(b, (reversed ? AMBI_FLAG_REVERSED : 0u) | (all ? AMBI_FLAG_ALL : 0u), nullptr)) != 0 ||
-        (rc = ambi_batch_download(b)) != 0)
-        return die(std::string("engine: ") + ambi_error_string(rc));
-    int refused = 0;
-    for (int c = 0; c < n_chr; c++) {
-        std::cout << head[c];
-        ambi_unit_result_t r; ambi_batch_unit_result(b, c, &r);
-        if (r.status < 0 || r.status == AMBI_ST_NO_VALID_ORDER) {
-            // where the reference would print this chromosome's path.  AMBI_ERR_REF_UB: the reference itself reads past the
-            // end of its breakpoint vector on this input (LGM.cpp:3436-3442) -- whatever it prints there is not defined by
-            // its source, so nothing is printed here; the other chromosomes follow, the exit status is 1.
-            std::cout.flush();
-            std::cerr << "bfb: chromosome " << c << ": " << ambi_error_string(r.status) << std::endl;
-            refused++;
-            continue;
-        }
-        std::vector<int32_t> p(r.path_len), q(r.path_indel_len);
-        ambi_batch_unit_path(b, c, 0, p.data(), r.path_len);
-        ambi_batch_unit_path(b, c, 1, q.data(), r.path_indel_len);
-        if (all && r.status == AMBI_ST_OK) {
-            // --all: one line per valid order; the flipped orientation only if the last order was invalid (LGM.cpp:3672-3695)
-            const int64_t stride = 2ll * r.path_len + 64;
-            for (int pass = 0; pass < 2; pass++) {
-                int64_t nv = 0;
-                ambi_batch_all_count(b, c, pass, &nv);
-                for (int64_t lo = 0; lo < nv; lo += 64) {
-                    const int64_t cnt = nv - lo < 64 ? nv - lo : 64;
-                    std::vector<int32_t> len((size_t)cnt), cells((size_t)(cnt * stride));
-                    if ((rc = ambi_batch_all_paths(b, c, pass, lo, cnt, len.data(), cells.data(), stride)) != 0)
-                        return die(std::string("bfb --all: ") + ambi_error_string(rc));
-                    for (int64_t j = 0; j < cnt; j++) {
-                        if (len[j] < 0) return die(std::string("bfb --all: ") + ambi_error_string(len[j]));
-                        std::vector<int32_t> pj(cells.begin() + j * stride, cells.begin() + j * stride + len[j]);
-                        std::cout << path_text(g, pj) << std::endl;
-                    }
-                }
-            }
-        } else
-            std::cout << path_text(g, p) << std::endl;                               // printBFB (LGM.cpp:3411-3429)
-        if (r.status == AMBI_ST_INFEASIBLE) std::cout << "ILP is unsolvable.\n";    // localhap.cpp:217
-        else if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(g, q) << std::endl;
-        paths[c] = q;
-        std::vector<int32_t> ju(r.n_out_junc), jv(r.n_out_junc), jc(r.n_out_junc);
-        ambi_batch_unit_out_juncs(b, c, ju.data(), jv.data(), jc.data(), r.n_out_junc);
-        for (int k = 0; k < r.n_out_junc; k++) merge_steps(out_acc, ju[k], jv[k], jc[k], true);   // localhap.cpp:267-289
-    }
-    ambi_batch_destroy(b);
-    if (refused) return die("bfb: " + std::to_string(refused) + " chromosome(s) without a path");
-    int path_len = 0, cn_sum = 0, max_cn_i = 0;
-    for (auto& p : paths) path_len += (int)p.size();
-    for (double v : cn_all) { cn_sum += v; max_cn_i = (max_cn_i > v) ? max_cn_i : v; }   // localhap.cpp:290-293 (int fed with doubles)
-    if (ins_mode == 2 || con_mode == 2) {   // localhap.cpp:295-316
-        if (!main_chr[0]) return die("BFB-TRX needs PROP M:<chr>");
-        std::cout << "BFB with translocation:\n";
-        std::vector<int64_t> offs(n_chr + 1, 0);
-        for (int c = 0; c < n_chr; c++) offs[c + 1] = offs[c] + (int64_t)paths[c].size();
-        std::vector<int32_t> flat((size_t)offs[n_chr] + 1), out((size_t)offs[n_chr] * 2 + 16);
-        for (int c = 0; c < n_chr; c++) std::copy(paths[c].begin(), paths[c].end(), flat.begin() + offs[c]);
-        int len = ambi_translocation_bfb(g, flat.data(), offs.data(), n_chr, out.data(), (int32_t)out.size());
-        if (len < 0) return die(ambi_error_string(len));
-        out.resize(len);
-        std::cout << path_text(g, out) << std::endl;
-        for (int i = 0; i + 1 < len; i++) {
-            int u = out[i], v = out[i + 1];
-            if (!(std::abs(std::abs(u) - std::abs(v)) == 1 && (u > 0) == (v > 0))) merge_steps(out_acc, u, v, 1, false);
-        }
-    }
-    // side files (localhap.cpp:326-337, 382-388)
-    {
-        std::vector<int32_t> js(n_junc), jt(n_junc); std::vector<int8_t> jsd(n_junc), jtd(n_junc); std::vector<double> jcn(n_junc);
-        ambi_graph_sizes(g, &n_seg, &n_junc, &n_chr);
-        js.resize(n_junc); jt.resize(n_junc); jsd.resize(n_junc); jtd.resize(n_junc); jcn.resize(n_junc);
-        ambi_graph_junctions(g, js.data(), jsd.data(), jt.data(), jtd.data(), nullptr, jcn.data(), nullptr, nullptr);
-        auto chrom = [&](int id) { char b[256]; ambi_graph_chrom_name(g, id, b, sizeof(b)); return std::string(b); };
-        auto vend = [&](int id, int dir) { return dir > 0 ? seg_end[id - 1] : seg_start[id - 1]; };      // Vertex::getEnd
-        auto vstart = [&](int id, int dir) { return dir > 0 ? seg_start[id - 1] : seg_end[id - 1]; };    // Vertex::getStart
-        std::ofstream sv("simulation_sv.txt", std::ios_base::app);
-        for (int j = 0; j < n_junc; j++)
-            sv << lh << "\t" << juncs << "\t" << chrom(js[j]) << "\t" << vend(js[j], jsd[j]) << "\t" << (jsd[j] > 0 ? '+' : '-') << "\t"
-               << chrom(jt[j]) << "\t" << vstart(jt[j], jtd[j]) << "\t" << (jtd[j] > 0 ? '+' : '-') << "\t" << jcn[j] << "\tinput\n";
-        for (auto& j : out_acc) {
-            int a = std::abs(j.u), b = std::abs(j.v), ad = j.u > 0 ? 1 : -1, bd = j.v > 0 ? 1 : -1;
-            sv << lh << "\t" << juncs << "\t" << chrom(a) << "\t" << vend(a, ad) << "\t" << (ad > 0 ? '+' : '-') << "\t"
-               << chrom(b) << "\t" << vstart(b, bd) << "\t" << (bd > 0 ? '+' : '-') << "\t" << j.cn << "\toutput\n";
-        }
-        auto t_end = std::chrono::steady_clock::now();
-        std::ofstream tf("time.csv", std::ios_base::app);
-        tf << lh.substr(0, lh.find(".")) << "," << n_seg << "," << num_inv << "," << n_junc - num_inv << "," << cn_sum << "," << path_len << ","
-           << max_cn_i << "," << std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_begin).count() / 1000000.0 << "\n";
-    }
-    ambi_graph_destroy(g);
-    return 0;
+    return run_bfb(A);
 }

@@ -166,6 +166,16 @@ int ambi_batch_download(ambi_batch_t* b);
  * was fetched), ambi_batch_unit_path and ambi_batch_unit_out_juncs are valid; the other getters need ambi_batch_download. */
 int ambi_batch_fetch_paths(ambi_batch_t* b);
 
+/* Several GPUs from C (`ambi_bfb_reconstruct_batch(..., device_or_minus1_for_all)`; north star: "independent .lh
+ * samples shard embarrassingly across the 8 GPUs of one node").  The units of a batch are the iterations of the loop
+ * localhap.cpp:111-265 and do not depend on each other: this call deals them round-robin over the devices, runs every share
+ * on its device from a host thread of its own (upload -> run(flags) -> download) and merges the results on the host.  Takes
+ * the place of ambi_batch_upload + _run + _download: all getters are valid afterwards (the per-unit device-side ones -- DAG,
+ * order rows, --all lists -- are answered by the device that holds the unit).  devices: n_devices device ordinals (an ordinal
+ * may repeat: several shares on one device), or NULL for the first n_devices visible devices (all of them if n_devices <= 0).
+ * May be called again (the shares stay resident).  A batch is either uploaded to one device or sharded, not both. */
+int ambi_batch_run_sharded(ambi_batch_t* b, uint32_t flags, const int32_t* devices, int32_t n_devices);
+
 /* Device-side view for collectives: the result blob (header [n_units] + per-unit arrays) lives in device memory.  Its
  * layout is the engine's own (csrc/ambi_batch.hpp: UnitOut, unit_layout; path cells are 2-byte LOCAL signed segment ids --
  * absolute id = id +- the chromosome's first segment id - 1); portable consumers use ambi_batch_pack_paths / _pack_runs, which

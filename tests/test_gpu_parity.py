@@ -163,6 +163,10 @@ def test_cli_on_gpu(hip_lib, oracle, tmp_path):
     t.check_errors(exe, str(d3))
     t.test_cli_many_chromosomes_one_batch(exe, oracle, d4)       # 8 chromosomes: one probe batch + one reconstruct batch
     t.test_cli_with_a_solver_that_reads_the_lp(exe, d5)          # the written .lp solved for real (HiGHS stand-in for cbc)
+    d6, d7 = tmp_path / "f", tmp_path / "g"
+    d6.mkdir(); d7.mkdir()
+    t.check_sample_list_over_devices(exe, str(d6), oracle, "0,0,0")   # several samples, one batch, three shares on the one GPU
+    t.check_sample_list_over_devices(exe, str(d7), oracle, "all")     # ... and over every visible device
 
 
 def test_large_lattice(hip_lib, oracle, workdir):
