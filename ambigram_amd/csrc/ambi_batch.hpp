@@ -183,8 +183,6 @@ struct BatchArgs {
     // small batches: the lattice of every unit is built by a kernel of its own BESIDE the express kernel (stage_lattice_own: it
     // constructs the DAG a second time instead of waiting for the express kernel's); its outcome is parked here and merged into
     // the headers by the plan kernel, which runs behind both (nullptr: the lattice stage writes the headers itself)
-    int32_t* persist_cursor;     // [4] device: next unit of the persistent order-table kernel per row-width class, [3] = units it could not take
-    int32_t* persist_miss;       // pinned host int: set when the persistent kernel could not take a unit (the host falls back to the other form)
     int32_t* lat_seq;            // pinned host int: the last wave of the side lattice kernel stores run_seq here ...
     int32_t* lat_unsure;         // pinned host int: ... after setting this to 1 unless EVERY unit's lattice is fine and all order tables together
                                  // (every unit counted, also those the express stage ends without a reconstruction) fit the arena:

@@ -88,10 +88,7 @@ __global__ void ambi_guard_check_kernel(const uint8_t* cells, int64_t stride, in
 
 __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
-    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) {   // nothing counts pending / handed-over units before the scan
-        *A.n_pending = 0; *A.refin_count = 0;
-        if (A.persist_cursor) { A.persist_cursor[0] = 0; A.persist_cursor[1] = 0; A.persist_cursor[2] = 0; }
-    }
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { *A.n_pending = 0; *A.refin_count = 0; }   // nothing counts pending / handed-over units before the scan
     stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
@@ -421,7 +418,6 @@ __global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A
                     int32_t* hdr = A.block_hdr + 8 * (int64_t)u;
                     hdr[0] = fits ? (dfs ? 2 : 1) : 0;
                     hdr[3] = (int32_t)(scr + (fits ? H.image_bytes : 0) + (dfs ? kDfsStateBytes : 0));
-                    hdr[4] = (int32_t)scr; hdr[5] = fits ? H.image_bytes : 0;   // (the two parts, for the persistent form's buffers)
                 }
             } else {
                 const BlockImageHeader* hdr = reinterpret_cast<const BlockImageHeader*>(A.block_hdr + 8 * (int64_t)u);
@@ -467,85 +463,6 @@ __global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A
                 emit_blocks_dispatch<CLS>(image, nB, K, (uint32_t)wlo, (uint32_t)whi,
                                           A.order_arena + out->order_off, lane, lane + 1);
         }
-    }
-}
-
-// The order-table kernel in its PERSISTENT form (round 3).  One workgroup of eight wavefronts per CU stays resident and takes
-// units from a cursor; wavefronts 0-3 emit the table of unit i from its image in group memory while wavefronts 4-7 build the
-// image of unit i+1 in a second buffer -- the 31 us in which a workgroup of the one-unit-per-workgroup kernel above stores
-// nothing (and for which it wants a fourth workgroup per CU, 4 x 39 KB = all of a CU's group memory) are hidden, four storing
-// wavefronts per CU already saturate the memory side (profiles/tools/hbm_write_pat6.hip: 5.9 TB/s, the same as 4 x 4), and the
-// rest of the CU's group memory stays free for the scan / finish workgroups that run beside this kernel.
-// Group memory: [build tables, scr_bytes][image 0, img_bytes][image 1, img_bytes].  Only for batches whose units are all
-// "simple" (one work block, an image with a directory, or no image at all: R <= first_budget) -- the host decides after the
-// first run; a unit the kernel cannot take after all is counted in persist_cursor[3] and the host falls back for good.
-struct Lanes256 {   // the emitting half as a strided-loop group (no barrier needed by what it runs)
-    __device__ inline int tid() const { return (int)threadIdx.x; }
-    __device__ inline int size() const { return 256; }
-};
-template <int CLS>
-__global__ __launch_bounds__(512) void ambi_enumerate_persist_kernel(BatchArgs A, int scr_bytes, int img_bytes) {
-    __shared__ int part_scratch[44];
-    __shared__ int unit_of[2], kind_of[2], nb_of[2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool builder = wave >= 4;
-    if (threadIdx.x < 44) part_scratch[threadIdx.x] = 0;
-    __syncthreads();
-    PartGroup gb(part_scratch, 256, 256);
-    uint8_t* scr = ambi_lds;
-    uint8_t* img[2] = {ambi_lds + scr_bytes, ambi_lds + scr_bytes + img_bytes};
-    // next unit of this class that wants rows (thread 256 only)
-    auto fetch = [&]() -> int {
-        while (true) {
-            const int i = atomicAdd(A.persist_cursor + CLS, 1);
-            if (i >= A.n_units) return -1;
-            const UnitOut* o = unit_out(A.results, A.unit_base + i);
-            if (o->order_off >= 0 && o->num_orders > 0 && enum_class_of(o->K) == CLS) return A.unit_base + i;
-        }
-    };
-    auto build = [&](int u, int b) {   // builders only
-        const UnitOut* out = unit_out(A.results, u);
-        const int K = out->K;
-        const int64_t R = out->num_orders;
-        int kind = 0, nB = 0;
-        if (A.first_rows && R <= A.first_budget) kind = 2;   // the table is among the rows unranked for the scan: a copy, no image
-        else {
-            const IdealTable tbl = unit_ideal_table(A, u);
-            BuildTables dummy;
-            BlockImageHeader H;
-            if (carve_build_tables(scr, tbl.counter[0], tbl.counter[1], dummy) <= scr_bytes &&
-                build_block_image(gb, tbl, K, row_stride(K) / 4, R, A.block_max, scr, scr_bytes, img[b], img_bytes, H)) { kind = 1; nB = H.nB; }
-        }
-        if (gb.tid() == 0) {
-            kind_of[b] = kind; nb_of[b] = nB;
-            if (kind == 0) { A.unit_fallback[u] = 1; atomicAdd(A.persist_cursor + 3, 1); if (A.persist_miss) *A.persist_miss = 1; }
-        }
-    };
-    if (builder) {
-        if (gb.tid() == 0) unit_of[0] = fetch();
-        gb.sync();
-        if (unit_of[0] >= 0) build(unit_of[0], 0);
-    }
-    __syncthreads();
-    int cur = 0;
-    while (true) {
-        const int u = unit_of[cur];
-        if (u < 0) break;
-        if (builder) {
-            if (gb.tid() == 0) unit_of[cur ^ 1] = fetch();
-            gb.sync();
-            const int un = unit_of[cur ^ 1];
-            if (un >= 0) build(un, cur ^ 1);
-        } else {
-            const UnitOut* out = unit_out(A.results, u);
-            const int K = out->K;
-            const int64_t R = out->num_orders;
-            uint8_t* rows = A.order_arena + out->order_off;
-            if (kind_of[cur] == 2) copy_first_rows(Lanes256{}, A.first_rows + (int64_t)u * A.first_budget * kFirstRowStride, K, R, rows);
-            else if (kind_of[cur] == 1) emit_blocks_dispatch<CLS>(reinterpret_cast<const uint32_t*>(img[cur]), nb_of[cur], K, 0u, (uint32_t)R, rows, lane, lane + 1, wave, 4);
-        }
-        __syncthreads();
-        cur ^= 1;
     }
 }
 
@@ -868,7 +785,7 @@ constexpr int kLdsMaxDynamic = 160 * 1024 - 1024;
 // ------------------------------------------------------------------------------------------------
 struct PinnedWords {                    // what kernels write into host memory (BatchArgs::host_pending, host_needed, express_*, plan_seq, late_flag)
     uint32_t guard_lo[16];
-    int32_t npending, express_left, express_seq, plan_seq, late_flag, lat_seq, lat_unsure, persist_miss, pad_[8];
+    int32_t npending, express_left, express_seq, plan_seq, late_flag, lat_seq, lat_unsure, pad_[9];
     int64_t needed[16];
     uint32_t guard_hi[16];
 };
@@ -1045,8 +962,6 @@ class HipBackend : public Backend {
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
     int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0, lds_lattice_own_ = 0;
-    // persistent form of the order-table kernel (env AMBI_PERSIST=0: never): eligible batches only, decided after the first run
-    bool persist_ok_ = false; int persist_scr_ = 0, persist_img_ = 0, persist_per_cu_ = 1, n_cus_ = 256; int32_t* d_persist_cursor_ = nullptr;
     bool lazy_ = false, tables_written_ = false;   // FLAG_LAZY_ORDERS: the run leaves the order tables out; they are written on demand
     bool side_lattice_ = false, flushed_ = false; hipStream_t lattice_stream_ = nullptr;   // env AMBI_SIDE_LATTICE=0: the lattice kernel behind the express kernel (round 2)
     uint64_t* d_lat_R_ = nullptr; int32_t* d_lat_status_ = nullptr; int64_t* d_lat_sum_ = nullptr;
@@ -1148,7 +1063,7 @@ class HipBackend : public Backend {
         in_bytes_ = c.off;
         zero_off_ = c.off;
         c.take(&d_results_, (size_t)H.result_bytes); c.take(&d_blk_hdr_, U * 8); c.take(&d_fallback_, U);
-        c.take(&d_refin_count_, 1); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1); c.take(&d_lat_sum_, 2); c.take(&d_persist_cursor_, 4);
+        c.take(&d_refin_count_, 1); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1); c.take(&d_lat_sum_, 2);
         zero_bytes_ = c.off - zero_off_;
         c.take(&d_dags_, U);
         c.take(&d_ikeys_, (size_t)H.ideal_slots); c.take(&d_icnt_, (size_t)H.ideal_slots); c.take(&d_ilink_, (size_t)H.ideal_slots * 4 + 8);
@@ -1184,7 +1099,7 @@ class HipBackend : public Backend {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
         if (uploaded_) { free_all(); uploaded_ = false; }   // a second upload replaces the first (every stream idle first)
-        ran_ = false; general_path_ = -1; timed_runs_ = 0; tuned_ = false; late_refusal_ = false; last_needed_ = 0; persist_ok_ = false;
+        ran_ = false; general_path_ = -1; timed_runs_ = 0; tuned_ = false; late_refusal_ = false; last_needed_ = 0;
         express_ = false;
         shared_units_ = -1;
         hbp_ = &hb_in; cfg_ = cfg;
@@ -1197,7 +1112,7 @@ class HipBackend : public Backend {
         h_npending_ = &L->h_words->npending; h_needed_ = L->h_words->needed;
         dh_npending_ = &L->dh_words->npending; dh_needed_ = L->dh_words->needed;
         h_express_left_ = &L->h_words->express_left; dh_express_left_ = &L->dh_words->express_left;
-        L->h_words->npending = 0; L->h_words->express_left = 1; L->h_words->late_flag = 0; L->h_words->persist_miss = 0;
+        L->h_words->npending = 0; L->h_words->express_left = 1; L->h_words->late_flag = 0;
         ev_fork_ = L->ev_fork; ev_prep_ = L->ev_prep; ev_back_ = L->ev_back; ev_first_ = L->ev_first; ev_full_ = L->ev_full; ev_plan_ = L->ev_plan; ev_express_ = L->ev_express;
         if (getenv("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
         { const char* e9 = getenv("AMBI_ORDER_ALIGN"); order_align_ = e9 ? atoi(e9) : 4096; if (order_align_ < 16 || (order_align_ & (order_align_ - 1))) order_align_ = 4096; }
@@ -1238,7 +1153,6 @@ class HipBackend : public Backend {
                                      (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel,
                                      (const void*)ambi_enumerate_kernel<0>, (const void*)ambi_enumerate_kernel<1>, (const void*)ambi_enumerate_kernel<2>,
                                      (const void*)ambi_enumerate_blocks_kernel<0>, (const void*)ambi_enumerate_blocks_kernel<1>, (const void*)ambi_enumerate_blocks_kernel<2>,
-                                     (const void*)ambi_enumerate_persist_kernel<0>, (const void*)ambi_enumerate_persist_kernel<1>, (const void*)ambi_enumerate_persist_kernel<2>,
                                      (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_lattice_own_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
                                      (const void*)ambi_all_lanes_kernel, (const void*)ambi_order_paths_kernel};
                 for (const void* f : fns) { hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic); if (e != hipSuccess) err = e; }
@@ -1411,7 +1325,6 @@ class HipBackend : public Backend {
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
         A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
-        A_.persist_cursor = d_persist_cursor_; A_.persist_miss = &lease_->dh_words->persist_miss;
         A_.lat_R = d_lat_R_; A_.lat_status = d_lat_status_; A_.lat_sum = d_lat_sum_; A_.lat_seq = &lease_->dh_words->lat_seq; A_.lat_unsure = &lease_->dh_words->lat_unsure;
         A_.plan_seq = &lease_->dh_words->plan_seq; A_.late_flag = &lease_->dh_words->late_flag; A_.run_seq = run_seq_;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = getenv("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
@@ -1569,14 +1482,7 @@ class HipBackend : public Backend {
         tick("ambi_enumerate_kernel", s, 3, true);
         const int lds_emit = lds_blocks_;
         if (lazy_) {}   // the tables are written on demand (materialise_tables)
-        else if (persist_ok_ && !express_) {
-            const int pl = persist_scr_ + 2 * persist_img_;
-            int pg = n_cus_ * persist_per_cu_;
-            if (pg > U) pg = U;
-            if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_persist_kernel<0>, dim3(pg), dim3(512), pl, st, A, persist_scr_, persist_img_);
-            if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_persist_kernel<1>, dim3(pg), dim3(512), pl, st, A, persist_scr_, persist_img_);
-            if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_persist_kernel<2>, dim3(pg), dim3(512), pl, st, A, persist_scr_, persist_img_);
-        } else {
+        else {
         if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<0>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
         if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<1>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
         if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_blocks_kernel<2>, dim3(grid), dim3(enum_threads_), lds_emit, st, A);
@@ -1832,27 +1738,6 @@ class HipBackend : public Backend {
                         if (emit_lds_tight_ && tight < block_lds_) block_lds_ = tight;
                         lds_blocks_ = block_lds_;
                     }
-                    // The persistent form: every unit that has rows is one work block and either has an image with a directory
-                    // that this run built in its workgroup (header kind 1) or is a copy of its first rows; two image buffers
-                    // and the build tables must leave at least a third of the CU's group memory to the kernels beside it.
-                    {
-                        const char* e = getenv("AMBI_PERSIST"); const bool want = e ? atoi(e) != 0 : true;
-                        const char* e2 = getenv("AMBI_PERSIST_PER_CU"); persist_per_cu_ = e2 ? atoi(e2) : 1; if (persist_per_cu_ < 1) persist_per_cu_ = 1;
-                        std::vector<UnitOut> hdr(hb().units.size());
-                        HIP_CK(hipMemcpy(hdr.data(), d_results_, hdr.size() * sizeof(UnitOut), hipMemcpyDeviceToHost));
-                        bool ok = want && shared_units_ == 0 && build_in_emit_ && (int)hb().units.size() >= 2 * ncu;
-                        int scr = 0, im = 0;
-                        for (size_t u2 = 0; ok && u2 < hb().units.size(); u2++) {
-                            if (hdr[u2].order_off < 0 || hdr[u2].num_orders <= 0) continue;
-                            if (hdr[u2].num_orders <= cfg_.first_budget) continue;
-                            if (hd[8 * u2] != 1) { ok = false; break; }
-                            scr = std::max(scr, hd[8 * u2 + 4]); im = std::max(im, hd[8 * u2 + 5]);
-                        }
-                        scr = (scr + 15) & ~15; im = (im + 15) & ~15;
-                        if (ok && scr + 2 * im + 1024 > (persist_per_cu_ > 1 ? 150 * 1024 / persist_per_cu_ : 108 * 1024)) ok = false;
-                        persist_ok_ = ok; persist_scr_ = scr; persist_img_ = im > 16 ? im : 16; n_cus_ = ncu;
-                        if (debug_) fprintf(stderr, "ambigram_hip: persistent order-table kernel %s (build tables %d B, image %d B, %d workgroup(s) per CU)\n", ok ? "on" : "off", scr, im, persist_per_cu_);
-                    }
                 }
             }
         }
@@ -1916,19 +1801,6 @@ class HipBackend : public Backend {
         inflight_ = false;
         if (tables_written_) { if (int rc = settle_first_run()) return rc; }
         if (check_guards("wait")) return -31;
-        if (persist_ok_ && tables_written_ && !express_) {   // a unit the persistent kernel could not take (never expected: the batch is immutable): back to the other form, now
-            if (*(volatile int32_t*)&lease_->h_words->persist_miss) {
-                fprintf(stderr, "ambigram_hip: the persistent order-table kernel could not take every unit; falling back to the one-unit-per-workgroup form\n");
-                persist_ok_ = false;
-                lease_->h_words->persist_miss = 0;
-                const bool t = timing_; timing_ = false;
-                int rc = run(A_.flags, (void*)stream_);
-                timing_ = t;
-                if (rc) return rc;
-                HIP_CK(hipStreamSynchronize(stream_));
-                inflight_ = false;
-            }
-        }
         if (tables_written_) { last_needed_ = 0; for (int s = 0; s < n_slices_; s++) last_needed_ += h_needed_[s]; }
         late_refusal_ = lease_->h_words->late_flag != 0;
         if (*h_npending_ > 0) {

@@ -194,68 +194,6 @@ struct BlockGroup {
     __device__ inline int first_flag(bool q) const { const int m = min_i32(q ? (int)threadIdx.x : 0x7fffffff); return m == 0x7fffffff ? -1 : m; }
 };
 
-// A PART of a workgroup: `count` consecutive threads from thread `first` (whole wavefronts), e.g. the four wavefronts that build
-// the next unit's image while the other four emit the current one (ambi_enumerate_persist_kernel).  Its barrier cannot be
-// s_barrier (that one counts every wavefront of the workgroup): the wavefronts of the part meet at a counter in group memory
-// (`scratch[40]` arrivals, `scratch[41]` generation; all wavefronts of a resident workgroup are resident, so the wait is bounded
-// by the slowest of them).  Every wavefront of the part must call sync() the same number of times.
-struct PartGroup {
-    static constexpr bool kLaneArrays = false;
-    int* scratch;        // >= 42 ints of group memory, [40] and [41] zero before first use
-    int first, count;
-    __device__ inline PartGroup(int* s, int f, int c) : scratch(s), first(f), count(c) {}
-    __device__ inline int tid() const { return (int)threadIdx.x - first; }
-    __device__ inline int size() const { return count; }
-    __device__ inline int nwaves() const { return count >> 6; }
-    __device__ inline void sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((threadIdx.x & 63u) == 0) {
-            volatile int* gen = scratch + 41;
-            const int g = *gen;
-            if (atomicAdd(scratch + 40, 1) == nwaves() - 1) {
-                scratch[40] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                atomicAdd(scratch + 41, 1);
-            } else {
-                while (*gen == g) __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    template <class Op> __device__ inline int combine(int wave_value, Op op, int identity) const {
-        sync();   // protect scratch against the previous reduction's readers
-        if ((threadIdx.x & 63u) == 0) scratch[tid() >> 6] = wave_value;
-        sync();
-        int r = identity;
-        const int nw = nwaves();
-        for (int i = 0; i < nw; i++) r = op(r, scratch[i]);
-        return r;
-    }
-    __device__ inline int min_i32(int v) const { WaveGroup w; return combine(w.min_i32(v), [](int a, int b) { return a < b ? a : b; }, 0x7fffffff); }
-    __device__ inline int max_i32(int v) const { WaveGroup w; return combine(w.max_i32(v), [](int a, int b) { return a > b ? a : b; }, (int)0x80000000); }
-    __device__ inline int sum_i32(int v) const { WaveGroup w; return combine(w.sum_i32(v), [](int a, int b) { return a + b; }, 0); }
-    __device__ inline bool any(bool p) const { return combine(__ballot(p) != 0ull ? 1 : 0, [](int a, int b) { return a | b; }, 0) != 0; }
-    __device__ inline int bcast_i32(int v, int src) const {
-        sync();
-        if (tid() == src) scratch[32] = v;
-        sync();
-        return scratch[32];
-    }
-    __device__ inline int exscan_i32(int v, int* total) const {
-        WaveGroup w;
-        int wt;
-        int x = w.exscan_i32(v, &wt);
-        sync();
-        if ((threadIdx.x & 63u) == 63u) scratch[tid() >> 6] = wt;
-        sync();
-        int base = 0, tot = 0, nw = nwaves(), me = tid() >> 6;
-        for (int i = 0; i < nw; i++) { int s = scratch[i]; if (i < me) base += s; tot += s; }
-        *total = tot;
-        return base + x;
-    }
-};
-
 #endif  // __HIPCC__
 
 }  // namespace ambi
