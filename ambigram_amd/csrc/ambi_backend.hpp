@@ -43,6 +43,8 @@ class Backend {
                            void* stream) = 0;
     virtual int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) = 0;
     virtual int copy_dag(int unit, Dag* out) = 0;
+    // the same for a wide unit (64..127 nodes): node records [K][3] each, successor sets as [K][2] 64-bit words
+    virtual int copy_dag_wide(int unit, int32_t* pat, int32_t* loop, uint64_t* succ2) { (void)unit; (void)pat; (void)loop; (void)succ2; return ST_ERR_BAD_INPUT; }
     virtual void set_timing(bool on) = 0;
     virtual void set_timing_mask(uint32_t mask) { set_timing(mask != 0); }
     virtual const std::vector<KernelTime>& kernel_times() = 0;

@@ -15,6 +15,8 @@
 
 namespace ambi {
 
+struct WideUnit;
+
 struct UnitIn {
     int32_t n_seg;        // n: local segments 1..n
     int32_t seg_base;     // absolute id = local + seg_base
@@ -176,6 +178,9 @@ struct BatchArgs {
     // small batches (express path): what a caller of ONE sample wants on the host -- header, final path(s), output junctions --
     // is mirrored by the express kernel into a pinned host "mailbox" (one slot per unit, MailLayout), so that no copy command
     // follows the kernel; and the two late verdicts that can still void an express result reach the host through pinned words
+    // wide units (64..127 DAG nodes, ambi_wide.hpp): their DAG / lattice working sets, and which unit has which
+    WideUnit* wide;       // [number of wide units]
+    const int32_t* wide_index;   // [U] index into `wide`, -1 for ordinary units (nullptr: the batch has no wide unit)
     uint8_t* mail;               // device address of the pinned mailbox (nullptr: none)
     const int64_t* mail_off;     // [U] byte offset of every unit's slot
     int32_t* plan_seq;           // pinned host int: the plan kernel stores run_seq here once orders_needed / late_flag are final

@@ -11,6 +11,7 @@
 #include "../../include/ambigram_hip.h"
 #include "ambi_backend.hpp"
 #include "ambi_pack.hpp"
+#include "ambi_wide.hpp"
 #include "lh_graph.hpp"
 
 using namespace ambi;
@@ -61,7 +62,7 @@ const char* ambi_error_string(int code) {
         case AMBI_ST_SHORTCUT: return "no fold-back inversion (reference path)";
         case AMBI_ST_INFEASIBLE: return "ILP is unsolvable";
         case AMBI_ST_NO_VALID_ORDER: return "no valid BFB order";
-        case AMBI_ERR_TOO_MANY_NODES: return "more than 63 selected patterns/loops in one chromosome";
+        case AMBI_ERR_TOO_MANY_NODES: return "more than 127 selected patterns/loops in one chromosome";
         case AMBI_ERR_NO_ELEMENTS: return "ILP solution selects no pattern or loop";
         case AMBI_ERR_REF_UB: return "reference behaviour undefined on this input (out-of-bounds read)";
         case AMBI_ERR_BKP_CAPACITY: return "breakpoint path capacity exceeded";
@@ -477,12 +478,26 @@ int ambi_batch_unit_prepare(const ambi_batch_t* b, int32_t unit, double* junc_cn
 int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, int32_t* node2loop, uint64_t* succ) {
     const UnitOut* h = header(b, unit);
     if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
-    Dag D;
     int local = unit;
     Backend* be = b->owner(unit, &local);
+    const int base = b->hb.units[unit].seg_base;
+    if (h->K > kMaxNodes) {   // a wide unit (64..127 nodes): succ[] gets the LOW word of every successor set (ambi_batch_unit_dag_words has both)
+        std::vector<int32_t> p(128 * 3), l(128 * 3);
+        std::vector<uint64_t> s2(256);
+        int rc = be->copy_dag_wide(local, p.data(), l.data(), s2.data());
+        if (rc) return rc;
+        for (int i = 0; i < h->K; i++) {
+            for (int c = 0; c < 3; c++) {
+                if (node2pat) node2pat[3 * i + c] = p[3 * i + c] + ((c < 2 && p[3 * i] != 0) ? base : 0);
+                if (node2loop) node2loop[3 * i + c] = l[3 * i + c] + ((c < 2 && l[3 * i] != 0) ? base : 0);
+            }
+            if (succ) succ[i] = s2[2 * i];
+        }
+        return h->K;
+    }
+    Dag D;
     int rc = be->copy_dag(local, &D);
     if (rc) return rc;
-    const int base = b->hb.units[unit].seg_base;
     for (int i = 0; i < h->K; i++) {
         for (int c = 0; c < 3; c++) {
             if (node2pat) node2pat[3 * i + c] = D.pat[i][c] + ((c < 2 && D.pat[i][0] != 0) ? base : 0);
@@ -490,6 +505,25 @@ int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, 
         }
         if (succ) succ[i] = D.succ[i];
     }
+    return h->K;
+}
+int ambi_batch_unit_dag_words(const ambi_batch_t* b, int32_t unit, uint64_t* succ2) {
+    const UnitOut* h = header(b, unit);
+    if (!h || !succ2) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    int local = unit;
+    Backend* be = b->owner(unit, &local);
+    if (h->K > kMaxNodes) {
+        std::vector<int32_t> p(128 * 3), l(128 * 3);
+        std::vector<uint64_t> s2(256);
+        int rc = be->copy_dag_wide(local, p.data(), l.data(), s2.data());
+        if (rc) return rc;
+        for (int i = 0; i < 2 * h->K; i++) succ2[i] = s2[i];
+        return h->K;
+    }
+    Dag D;
+    int rc = be->copy_dag(local, &D);
+    if (rc) return rc;
+    for (int i = 0; i < h->K; i++) { succ2[2 * i] = D.succ[i]; succ2[2 * i + 1] = 0; }
     return h->K;
 }
 int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap) {

@@ -466,6 +466,28 @@ __global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A
     }
 }
 
+// Order tables of the wide units (64..127 nodes, row class 3): 64 workgroups per wide unit, one thread per row -- the row is
+// unranked from the unit's completion counts (unrank_wide) and written as 128 bytes (nodes, then 0xFF).  Rare units, at most
+// kWideMaxOrders rows each: written for correctness, not for the roofline.
+__global__ __launch_bounds__(256) void ambi_enumerate_wide_kernel(BatchArgs A, const int32_t* wide_units, int n_wide) {
+    const int w = blockIdx.y;
+    if (w >= n_wide) return;
+    const int u = wide_units[w];
+    const UnitOut* out = unit_out(A.results, u);
+    if (out->order_off < 0 || out->num_orders <= 0) return;
+    const WideUnit& X = A.wide[A.wide_index[u]];
+    const int K = out->K, stride = row_stride(K);
+    uint8_t* rows = A.order_arena + out->order_off;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < out->num_orders; r += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t row[128];
+        unrank_wide(X, (uint64_t)r, row);
+        for (int d = K; d < stride; d++) row[d] = 0xFF;
+        uint4* dst = reinterpret_cast<uint4*>(rows + r * stride);
+        const uint4* src = reinterpret_cast<const uint4*>(row);
+        for (int q = 0; q < stride / 16; q++) dst[q] = src[q];
+    }
+}
+
 __global__ __launch_bounds__(64) void ambi_first_kernel(BatchArgs A) {
     WaveGroup g;
     stage_first(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
@@ -492,7 +514,7 @@ __global__ __launch_bounds__(256) void ambi_search_kernel(BatchArgs A, SearchArg
         if (unit_out(A.results, u)->status != ST_PENDING) continue;   // resolved by the previous pass
         const int64_t first = (c - S.chunk_off[p]) * S.chunk;
         if (first >= search_limit(load_now_i64(&S.slots[p].found), load_now_i64(&S.slots[p].err_key))) continue;   // an earlier hit is already known
-        FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+        FirstWork W = carve_first(work, U.n_seg, U.bkp_cap, U.n_elem > kMaxNodes);
         load_first_work(g, A, u, W);
         stage_search_chunk(g, A, u, W, first, S.chunk, S.forward != 0, &S.slots[p]);
     }
@@ -529,7 +551,7 @@ __global__ __launch_bounds__(256) void ambi_all_lanes_kernel(BatchArgs A, int pa
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.all_off[mid] <= 2 * c) lo = mid; else hi = mid; }
         const int u = lo;
         const UnitIn& U = A.units[u];
-        if (U.bkp_cap > lane_cap) continue;
+        if (U.bkp_cap > lane_cap || U.n_elem > kMaxNodes) continue;   // (long breakpoint paths and wide units: ambi_all_kernel)
         const int64_t R = unit_out(A.results, u)->num_orders;
         if (!all_chunk_is_mine(A, c, c - A.all_off[u] / 2, R)) continue;   // another rank's chunk
         if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;
@@ -575,10 +597,11 @@ __global__ __launch_bounds__(256) void ambi_all_kernel(BatchArgs A, int pass, in
         const int64_t R = unit_out(A.results, u)->num_orders;
         if (pass == 1 && all_pass0_last_valid(A, u, R)) continue;   // no orientation flip for this unit (LGM.cpp:3691-3695)
         const UnitIn& U = A.units[u];
-        if (U.bkp_cap <= lane_cap) continue;                         // taken by ambi_all_lanes_kernel
+        const bool wide = U.n_elem > kMaxNodes;
+        if (U.bkp_cap <= lane_cap && !wide) continue;                // taken by ambi_all_lanes_kernel
         if (!all_chunk_is_mine(A, c, c - A.all_off[u] / 2, R)) continue;   // another rank's chunk
-        FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
-        uint8_t* rows = work + first_work_bytes(U.n_seg, U.bkp_cap);
+        FirstWork W = carve_first(work, U.n_seg, U.bkp_cap, wide);
+        uint8_t* rows = work + first_work_bytes(U.n_seg, U.bkp_cap, wide);
         g.sync();
         load_first_work(g, A, u, W);
         stage_all_chunk(g, A, u, W, rows, c - A.all_off[u] / 2, pass);
@@ -595,8 +618,9 @@ __global__ __launch_bounds__(64) void ambi_order_paths_kernel(BatchArgs A, int u
     WaveGroup g;
     const UnitIn& U = A.units[u];
     const int j = blockIdx.x;
-    FirstWork W = carve_first(ambi_lds, U.n_seg, U.bkp_cap);
-    int32_t* offs = reinterpret_cast<int32_t*>(ambi_lds + first_work_bytes(U.n_seg, U.bkp_cap));
+    const bool wide = U.n_elem > kMaxNodes;
+    FirstWork W = carve_first(ambi_lds, U.n_seg, U.bkp_cap, wide);
+    int32_t* offs = reinterpret_cast<int32_t*>(ambi_lds + first_work_bytes(U.n_seg, U.bkp_cap, wide));
     load_first_work(g, A, u, W);
     int L = 0;
     const int v = eval_indexed(g, A, u, W, order_idx[j], forward != 0, &L);
@@ -921,6 +945,7 @@ class HipBackend : public Backend {
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
     int64_t* d_mail_off_ = nullptr; int32_t* d_guard_bad_ = nullptr;
+    WideUnit* d_wide_ = nullptr; int32_t* d_wide_index_ = nullptr; int32_t* d_wide_units_ = nullptr; int n_wide_ = 0;   // units with 64..127 nodes (ambi_wide.hpp)
     int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned (words of the lease)
     int32_t* dh_npending_ = nullptr; int64_t* dh_needed_ = nullptr; // the same two, as the device addresses them
     int64_t in_bytes_ = 0, zero_off_ = 0, zero_bytes_ = 0;          // input image / zero-filled region of the block
@@ -1059,6 +1084,7 @@ class HipBackend : public Backend {
         Carver c{base};
         c.take(&d_units_, U); c.take(&d_seg_cn_, H.seg_cn.size()); c.take(&d_juncs_, H.juncs.size()); c.take(&d_junc_ends_, H.junc_ends.size());
         c.take(&d_elems_, H.elems.size()); c.take(&d_scratch_off_, U); c.take(&d_direct_list_, direct_list.size()); c.take(&d_mail_off_, U);
+        c.take(&d_wide_index_, U); c.take(&d_wide_units_, (size_t)H.n_wide);
         c.take(&d_inject_, H.inject.size()); c.take(&d_inject_off_, H.inject.empty() ? 0 : 2 * U);
         in_bytes_ = c.off;
         zero_off_ = c.off;
@@ -1075,6 +1101,7 @@ class HipBackend : public Backend {
         c.take(&d_first_rows_, U * (size_t)(cfg_.first_budget > 0 ? cfg_.first_budget : 1) * kFirstRowStride);
         const size_t img_stride = (size_t)std::max(block_lds_, ((160 * 1024) / 3) & ~15);   // (the budget per workgroup may be re-chosen after the first run)
         c.take(&d_blk_img_, U * img_stride);
+        c.take(&d_wide_, (size_t)H.n_wide);
         return c.off;
     }
 
@@ -1118,7 +1145,8 @@ class HipBackend : public Backend {
         { const char* e9 = getenv("AMBI_ORDER_ALIGN"); order_align_ = e9 ? atoi(e9) : 4096; if (order_align_ < 16 || (order_align_ & (order_align_ - 1))) order_align_ = 4096; }
         // LDS budgets (dynamic shared memory), sized for the largest unit of the batch
         lds_prepare_ = (int)prepare_work_bytes(H.max_n, H.max_m, H.max_k);
-        lds_first_ = (int)first_work_bytes(H.max_n, H.max_bkp);
+        n_wide_ = H.n_wide;
+        lds_first_ = (int)first_work_bytes(H.max_n, H.max_bkp, n_wide_ > 0);
         // the full finish stage keeps the path cells in LDS: as many as fit beside its other arrays (longer paths are
         // served by the lean stage alone)
         finish_path_cells_ = H.max_path < kPathLdsCells ? H.max_path : kPathLdsCells;
@@ -1277,6 +1305,12 @@ class HipBackend : public Backend {
         put(d_scratch_off_, H.scratch_off.data(), U * sizeof(int64_t));
         if (!dl.empty()) put(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t));
         put(d_mail_off_, mail_off_.data(), U * sizeof(int64_t));
+        put(d_wide_index_, H.wide_index.data(), U * sizeof(int32_t));
+        {
+            std::vector<int32_t> wu;
+            for (size_t u2 = 0; u2 < U; u2++) if (H.wide_index[u2] >= 0) wu.push_back((int32_t)u2);
+            if (!wu.empty()) put(d_wide_units_, wu.data(), wu.size() * sizeof(int32_t));
+        }
         if (!H.inject.empty()) { put(d_inject_, H.inject.data(), H.inject.size()); put(d_inject_off_, H.inject_off.data(), 2 * U * sizeof(int64_t)); }
         if (pinned) upload_pending_ = true;
         else {
@@ -1324,6 +1358,7 @@ class HipBackend : public Backend {
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
+        A_.wide = n_wide_ > 0 ? d_wide_ : nullptr; A_.wide_index = n_wide_ > 0 ? d_wide_index_ : nullptr;
         A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
         A_.lat_R = d_lat_R_; A_.lat_status = d_lat_status_; A_.lat_sum = d_lat_sum_; A_.lat_seq = &lease_->dh_words->lat_seq; A_.lat_unsure = &lease_->dh_words->lat_unsure;
         A_.plan_seq = &lease_->dh_words->plan_seq; A_.late_flag = &lease_->dh_words->late_flag; A_.run_seq = run_seq_;
@@ -1489,6 +1524,7 @@ class HipBackend : public Backend {
         if ((enum_classes_ & 1) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 2) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, st, A);
         if ((enum_classes_ & 4) && general_path_ != 0) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, st, A);
+        if (n_wide_ > 0) hipLaunchKernelGGL(ambi_enumerate_wide_kernel, dim3(64, n_wide_), dim3(256), 0, st, A, (const int32_t*)d_wide_units_, n_wide_);
         }
         tick("ambi_enumerate_kernel", s, 3, false);
         if (!ahead) launch_first();
@@ -1574,7 +1610,7 @@ class HipBackend : public Backend {
         }
         overlap_back_ = want_overlap_ && back_stream_ != nullptr && n_slices_ == 1;
         A_.direct_full_on = (overlap_back_ && direct_n_ > 0 && full_stream_ != nullptr) ? 1 : 0;
-        express_ = n_slices_ == 1 && U <= express_units_ && lds_express_ <= kLdsMaxDynamic && dh_express_left_ != nullptr && direct;
+        express_ = n_slices_ == 1 && U <= express_units_ && lds_express_ <= kLdsMaxDynamic && dh_express_left_ != nullptr && direct && n_wide_ == 0;
         if (direct) { A_.zero_pending = 1; A_.host_pending = dh_npending_; A_.host_needed = dh_needed_; }
         // Software pipeline over the slices: slice s starts its latency-bound front (prepare, plan, image build) when
         // slice s-1 has finished its own and moves on to the HBM-bound enumerate kernel, so the two kinds of work
@@ -1641,6 +1677,7 @@ class HipBackend : public Backend {
             if (enum_classes_ & 1) hipLaunchKernelGGL(ambi_enumerate_kernel<0>, dim3(grid), dim3(256), lds_enum_, stream_, A);
             if (enum_classes_ & 2) hipLaunchKernelGGL(ambi_enumerate_kernel<1>, dim3(grid), dim3(256), lds_enum_, stream_, A);
             if (enum_classes_ & 4) hipLaunchKernelGGL(ambi_enumerate_kernel<2>, dim3(grid), dim3(256), lds_enum_, stream_, A);
+            if (n_wide_ > 0) hipLaunchKernelGGL(ambi_enumerate_wide_kernel, dim3(64, n_wide_), dim3(256), 0, stream_, A, (const int32_t*)d_wide_units_, n_wide_);
             HIP_CK(hipGetLastError());
             HIP_CK(hipStreamSynchronize(stream_));
             const int64_t need = h_needed_[0];
@@ -1957,6 +1994,15 @@ class HipBackend : public Backend {
         HIP_CK(hipMemcpy(out, d_dags_ + unit, sizeof(Dag), hipMemcpyDeviceToHost));
         return 0;
     }
+    int copy_dag_wide(int unit, int32_t* pat, int32_t* loop, uint64_t* succ2) override {
+        if (unit < 0 || unit >= (int)hb().units.size() || hb().wide_index[unit] < 0) return ST_ERR_BAD_INPUT;
+        const WideUnit* X = d_wide_ + hb().wide_index[unit];
+        const uint8_t* base = reinterpret_cast<const uint8_t*>(X);
+        HIP_CK(hipMemcpy(pat, base + offsetof(WideUnit, dag) + offsetof(WideDag, pat), sizeof(int32_t) * 128 * 3, hipMemcpyDeviceToHost));
+        HIP_CK(hipMemcpy(loop, base + offsetof(WideUnit, dag) + offsetof(WideDag, loop), sizeof(int32_t) * 128 * 3, hipMemcpyDeviceToHost));
+        HIP_CK(hipMemcpy(succ2, base + offsetof(WideUnit, succ), sizeof(U128) * 128, hipMemcpyDeviceToHost));
+        return 0;
+    }
     void set_timing(bool on) override { timing_ = on; timing_mask_ = ~0u; timed_runs_ = 0; }
     void set_timing_mask(uint32_t mask) override { timing_ = mask != 0; timing_mask_ = mask; timed_runs_ = 0; }
     const std::vector<KernelTime>& kernel_times() override { return times_; }
@@ -2009,9 +2055,10 @@ class HipBackend : public Backend {
             // units with a short breakpoint path (the rule): one thread per order; the others: one wavefront per order
             int lane_cap = 0, lanes_units = 0, wave_units = 0;
             { const char* e = getenv("AMBI_ALL_LANES"); lane_cap = (e && atoi(e) == 0) ? 0 : kAllLaneMaxCells; }
-            for (int u = 0; u < U; u++) if (all_off_[u + 1] > all_off_[u]) { if (hb().units[u].bkp_cap <= lane_cap) lanes_units++; else wave_units++; }
+            auto lane_unit = [&](int u) { return hb().units[u].bkp_cap <= lane_cap && hb().units[u].n_elem <= kMaxNodes; };
+            for (int u = 0; u < U; u++) if (all_off_[u + 1] > all_off_[u]) { if (lane_unit(u)) lanes_units++; else wave_units++; }
             int max_lane_cells = 8;
-            for (int u = 0; u < U; u++) if (hb().units[u].bkp_cap <= lane_cap && hb().units[u].bkp_cap > max_lane_cells) max_lane_cells = hb().units[u].bkp_cap;
+            for (int u = 0; u < U; u++) if (lane_unit(u) && hb().units[u].bkp_cap > max_lane_cells) max_lane_cells = hb().units[u].bkp_cap;
             const int head_bytes = (int)((first_work_bytes(hb().max_n, 8) + 15) & ~15);
             // group memory for a staged copy of the unit's automaton (env AMBI_ALL_AUTO_LDS): 0 = the lanes unrank through L2.
             // Measured (4096 bench units): 0 / 4096 / 8192 bytes = 561 / 489 / 390 M orders/s -- the kernel lives on the number
@@ -2106,7 +2153,7 @@ class HipBackend : public Backend {
         HIP_CK(b_cells.alloc((size_t)count * (size_t)stride * sizeof(int32_t)));
         int64_t* d_idx = b_idx.as<int64_t>(); int32_t* d_len = b_len.as<int32_t>(); int32_t* d_cells = b_cells.as<int32_t>();
         HIP_CK(hipMemcpy(d_idx, v.data() + first, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice));
-        const int lds = (int)(first_work_bytes(Uin.n_seg, Uin.bkp_cap) + 4ll * (Uin.bkp_cap / 2 + 2) + 16);
+        const int lds = (int)(first_work_bytes(Uin.n_seg, Uin.bkp_cap, Uin.n_elem > kMaxNodes) + 4ll * (Uin.bkp_cap / 2 + 2) + 16);
         hipLaunchKernelGGL(ambi_order_paths_kernel, dim3((unsigned)count), dim3(64), lds, stream_, A_, unit, fwd ? 1 : 0, (const int64_t*)d_idx, d_len,
                            d_cells, stride);
         HIP_CK(hipGetLastError());

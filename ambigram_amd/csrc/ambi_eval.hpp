@@ -175,8 +175,9 @@ AMBI_HD int eval_finish(const G& g, int placed, int K, cell_t* bkp, int L, const
 
 // Placement part of the evaluation of one order (LGM.cpp:3519-3646): seeds and places the elements; needs the DAG only.
 // Returns the number of elements placed (== K: all) or a negative Status; *L_out = bkp length.
-template <class G>
-AMBI_HD int eval_place(const G& g, const Dag& D, const uint8_t* ord, bool forward, cell_t* bkp, int cap, int* L_out) {
+// DAG: anything with K, pat[][3], loop[][3] -- Dag (up to 63 nodes) or WideDag (ambi_wide.hpp, up to 127).
+template <class G, class DAG>
+AMBI_HD int eval_place(const G& g, const DAG& D, const uint8_t* ord, bool forward, cell_t* bkp, int cap, int* L_out) {
     const int K = D.K;
     int L = 0;
     int x = ord[0];
@@ -253,8 +254,8 @@ AMBI_HD int eval_place(const G& g, const Dag& D, const uint8_t* ord, bool forwar
 }
 
 // Evaluate one order.  Returns 1 valid / 0 invalid / negative Status on error.  *L_out = bkp length.
-template <class G>
-AMBI_HD int eval_order(const G& g, const Dag& D, const uint8_t* ord, bool forward, const InvMap& inv,
+template <class G, class DAG>
+AMBI_HD int eval_order(const G& g, const DAG& D, const uint8_t* ord, bool forward, const InvMap& inv,
                        cell_t* bkp, int cap, int* L_out, int64_t* clk = nullptr) {
     const int K = D.K;
     int L = 0;

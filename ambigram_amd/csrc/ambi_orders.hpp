@@ -27,7 +27,7 @@ constexpr int kFirstRowStride = 64;       // bytes between the pre-unranked firs
 
 // Kpad: bytes per row of the order table (a multiple of 4; coarser buckets above 32 nodes keep the number of
 // enumerate-kernel instantiations small)
-AMBI_HD int row_stride(int K) { return K <= 32 ? ((K + 3) & ~3) : (K <= 48 ? 48 : 64); }
+AMBI_HD int row_stride(int K) { return K <= 32 ? ((K + 3) & ~3) : (K <= 48 ? 48 : (K <= 63 ? 64 : 128)); }   // (64..127 nodes: wide units, ambi_wide.hpp)
 
 // ---- atomics usable from both builds ----
 AMBI_HD uint64_t atomic_cas_u64(uint64_t* p, uint64_t expected, uint64_t desired) {

@@ -24,6 +24,8 @@ struct HostBatch {
     int64_t result_bytes = 0, ideal_slots = 0, scratch_ints = 0;
     int max_n = 0, max_m = 0, max_k = 0, max_bkp = 0, max_path = 0, max_out = 0;
     int ideal_cap = kDefaultIdealCap;
+    int n_wide = 0;                         // units with 64..127 DAG nodes (ambi_wide.hpp)
+    std::vector<int32_t> wide_index;        // [U] index among the wide units or -1; filled by finalize()
     bool any_sv = false;                    // some unit has a junction indelBFB would look at (neither adjacency nor fold-back): the full finish stage may be needed
     // diagnostics hook (ambi_batch_debug_inject_validity): verdict overrides per unit, see BatchArgs::inject_valid
     std::vector<int8_t> inject;

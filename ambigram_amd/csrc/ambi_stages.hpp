@@ -17,6 +17,7 @@
 #include "ambi_finish.hpp"
 #include "ambi_orders.hpp"
 #include "ambi_prepare.hpp"
+#include "ambi_wide.hpp"
 
 namespace ambi {
 
@@ -233,10 +234,48 @@ AMBI_HD void prep_header(UnitOut* out, int status, int bias, int K, uint64_t R, 
     out->inv_cn_sum = inv_sum;
 }
 
+AMBI_HD bool unit_is_wide(const BatchArgs& A, int u) { return A.wide_index != nullptr && A.wide_index[u] >= 0; }
+
+// The prepare stage of a WIDE unit (64..127 nodes, ambi_wide.hpp): the junction side as for every unit, then the DAG, the
+// order ideals and the counts in their plain two-word form in the unit's HBM working set.  No first rows are unranked: the
+// scan for the first valid order of such a unit is the parallel search over its order table (stage_first hands it over).
+template <class G>
+AMBI_HD void stage_prepare_wide(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
+    PrepareWork W = carve_prepare(work, n, m, K);
+    UnitOut* out = unit_out(A.results, u);
+    int bias = 1;
+    bool no_fbi = false;
+    double inv_sum = 0;
+    prep_junctions(g, A, u, U, W, &bias, &no_fbi, &inv_sum);
+    int status = prep_status(U, no_fbi, ST_OK);
+    bool have_target = false;
+    WideUnit& X = A.wide[A.wide_index[u]];
+    if (status == ST_OK) {
+        const Element* el = A.elems + U.elem_off;
+        target_cn_g(g, el, K, n, W.slot_cnt, W.slot_cnt);            // localhap.cpp:222-232
+        have_target = true;
+        g.sync();
+        status = construct_dag_wide(g, el, K, U.seg_base, X);        // :236
+    }
+    g.sync();
+    prep_copy_out(g, A, u, U, W, W.slot_cnt, have_target, ST_SHORTCUT /* (no 64-node DAG record to copy) */);
+    g.sync();
+    uint64_t R = 0;
+    if (status == ST_OK) {
+        status = lattice_wide(g, X, &R);
+        if (status == ST_OK && (R >= kCountSat || R > (uint64_t)kWideMaxOrders)) status = ST_ERR_ORDERS_CAPACITY;
+    }
+    if (g.tid() == 0) prep_header(out, status, bias, K, R, inv_sum);
+    g.sync();
+}
+
 template <class G>
 AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     const UnitIn U = A.units[u];
     const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
+    if (K > kMaxNodes) { stage_prepare_wide(g, A, u, work); return; }
     PrepareWork W = carve_prepare(work, n, m, K);
     UnitOut* out = unit_out(A.results, u);
     AMBI_MARK(A, g, u, 0);
@@ -437,7 +476,7 @@ constexpr int kDfsStateBytes = 16 * kDfsWaveStride;   // up to sixteen waves per
 
 // Row-width classes of the enumerate kernel (one kernel instantiation each, so that the register budget of the wide
 // rows does not throttle the occupancy of the narrow ones): 0: K <= 20, 1: K <= 32, 2: K <= 63.
-AMBI_HD int enum_class_of(int K) { return K <= 20 ? 0 : (K <= 32 ? 1 : 2); }
+AMBI_HD int enum_class_of(int K) { return K <= 20 ? 0 : (K <= 32 ? 1 : (K <= kMaxNodes ? 2 : 3)); }   // 3: wide units (their own table kernel)
 
 // dispatch on K: NW = Kpad/4 dwords per row; 32-bit masks while K <= 32.  CLS < 0: all classes (host simulation).
 template <int CLS, class AUTO32, class AUTO64>
@@ -475,21 +514,31 @@ struct FirstWork {
     cell_t* bkp;        // [bkp_cap]
     int16_t* inv_src;   // [n+1]
     int16_t* inv_tgt;   // [n+1]
-    Dag* dag;
-    uint8_t* ord;       // [64]
+    Dag* dag;           // node records of an ordinary unit ...
+    WideDag* wdag;      // ... or of a wide one (the same bytes; nullptr for ordinary units)
+    uint8_t* ord;       // [64], [128] for a wide unit
 };
-AMBI_HD int64_t first_work_bytes(int n, int bkp_cap) {
-    return pad8(2ll * bkp_cap) + 2 * pad8(2ll * (n + 1)) + pad8(sizeof(Dag)) + 64;
+// wide: the area is laid out for a unit with 64..127 nodes (larger node records, 128-byte order row)
+AMBI_HD int64_t first_work_bytes(int n, int bkp_cap, bool wide = false) {
+    return pad8(2ll * bkp_cap) + 2 * pad8(2ll * (n + 1)) + pad8(wide ? sizeof(WideDag) : sizeof(Dag)) + (wide ? 128 : 64);
 }
-AMBI_HD FirstWork carve_first(uint8_t* base, int n, int bkp_cap) {
+AMBI_HD FirstWork carve_first(uint8_t* base, int n, int bkp_cap, bool wide = false) {
     FirstWork W;
     int64_t o = 0;
     W.bkp = reinterpret_cast<cell_t*>(base + o); o += pad8(2ll * bkp_cap);
     W.inv_src = reinterpret_cast<int16_t*>(base + o); o += pad8(2ll * (n + 1));
     W.inv_tgt = reinterpret_cast<int16_t*>(base + o); o += pad8(2ll * (n + 1));
-    W.dag = reinterpret_cast<Dag*>(base + o); o += pad8(sizeof(Dag));
+    W.dag = reinterpret_cast<Dag*>(base + o);
+    W.wdag = wide ? reinterpret_cast<WideDag*>(base + o) : nullptr;
+    o += pad8(wide ? sizeof(WideDag) : sizeof(Dag));
     W.ord = base + o;
     return W;
+}
+// one order through the evaluation, with the node records the work area holds
+template <class G>
+AMBI_HD int eval_order_w(const G& g, const FirstWork& W, const uint8_t* ord, bool forward, const InvMap& inv, cell_t* bkp, int cap, int* L_out,
+                         int64_t* clk = nullptr) {
+    return W.wdag ? eval_order(g, *W.wdag, ord, forward, inv, bkp, cap, L_out, clk) : eval_order(g, *W.dag, ord, forward, inv, bkp, cap, L_out, clk);
 }
 
 template <class G>
@@ -497,6 +546,8 @@ AMBI_HD void load_first_work(const G& g, const BatchArgs& A, int u, const FirstW
     const UnitIn& U = A.units[u];
     const UnitLayout Lay = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
     uint8_t* res = A.results + U.res_off;
+    if (W.wdag) copy_words(g, reinterpret_cast<uint32_t*>(W.wdag), reinterpret_cast<const uint32_t*>(&A.wide[A.wide_index[u]].dag), int64_t(sizeof(WideDag) / 4));
+    else
     copy_words(g, reinterpret_cast<uint32_t*>(W.dag), reinterpret_cast<const uint32_t*>(A.dags + u), int64_t(sizeof(Dag) / 4));
     copy_words(g, W.inv_src, reinterpret_cast<const int16_t*>(res + Lay.inv_src), int64_t(U.n_seg + 1));
     copy_words(g, W.inv_tgt, reinterpret_cast<const int16_t*>(res + Lay.inv_tgt), int64_t(U.n_seg + 1));
@@ -518,6 +569,11 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     UnitOut* out = unit_out(A.results, u);
     if (out->status != ST_OK || out->reserved) return;   // (reserved: reconstructed by the express stage already)
     const UnitIn U = A.units[u];
+    if (U.n_elem > kMaxNodes) {   // a wide unit has no pre-unranked first rows: the parallel search over its order table takes it from order 0
+        if (g.tid() == 0) { out->status = ST_PENDING; out->evaluated = 0; atomic_add_i32(A.n_pending, 1); }
+        g.sync();
+        return;
+    }
     FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
     AMBI_MARK(A, g, u, 9);
     load_first_work(g, A, u, W);
@@ -583,7 +639,7 @@ AMBI_HD int eval_indexed(const G& g, const BatchArgs& A, int u, const FirstWork&
     for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * row_stride(K) + d];
     g.sync();
     InvMap inv{W.inv_src, W.inv_tgt};
-    const int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);
+    const int v = eval_order_w(g, W, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);
     return injected_verdict(A, u, out->num_orders, nidx, forwardDir, v);
 }
 
@@ -644,7 +700,7 @@ AMBI_HD void stage_resolve(const G& g, const BatchArgs& A, int u, uint8_t* work,
         if (pass == 1 && g.tid() == 0) { out->status = ST_NO_VALID_ORDER; out->evaluated = (int32_t)(2 * R); }
         return;
     }
-    FirstWork W = carve_first(work, U.n_seg, U.bkp_cap);
+    FirstWork W = carve_first(work, U.n_seg, U.bkp_cap, U.n_elem > kMaxNodes);
     load_first_work(g, A, u, W);
     int L = 0;
     const int v = eval_indexed(g, A, u, W, f, forward, &L);   // materialise the winner's breakpoints
@@ -677,17 +733,27 @@ AMBI_HD void stage_all_chunk(const G& g, const BatchArgs& A, int u, const FirstW
     const int K = out->K;
     const int64_t R = out->num_orders;
     const bool fwd0 = !(A.flags & FLAG_REVERSED), forward = pass == 0 ? fwd0 : !fwd0;
-    const AutoView V = auto_view(unit_ideal_table(A, u));
     const int64_t first = c * 64;
     const int cnt = (int)(R - first < 64 ? R - first : 64);
-    for (int i = g.tid(); i < cnt; i += g.size()) (void)order_unrank(V, K, (uint64_t)(first + i), rows + (int64_t)i * kFirstRowStride);
+    const bool wide = W.wdag != nullptr;    // a wide unit's orders are read from its (small) order table, one at a time
+    if (!wide) {
+        const AutoView V = auto_view(unit_ideal_table(A, u));
+        for (int i = g.tid(); i < cnt; i += g.size()) (void)order_unrank(V, K, (uint64_t)(first + i), rows + (int64_t)i * kFirstRowStride);
+    }
     g.sync();
     const InvMap inv{W.inv_src, W.inv_tgt};
     uint64_t word = 0;
     int undefined = 0;
     for (int i = 0; i < cnt; i++) {
         int L = 0;
-        int v = eval_order(g, *W.dag, rows + (int64_t)i * kFirstRowStride, forward, inv, W.bkp, U.bkp_cap, &L);
+        const uint8_t* ord = rows + (int64_t)i * kFirstRowStride;
+        if (wide) {
+            const uint8_t* trow = A.order_arena + out->order_off + (first + i) * row_stride(K);
+            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = trow[d];
+            g.sync();
+            ord = W.ord;
+        }
+        int v = eval_order_w(g, W, ord, forward, inv, W.bkp, U.bkp_cap, &L);
         v = injected_verdict(A, u, R, first + i, forward, v);
         if (v == 1) word |= 1ull << i;
         else if (v < 0) undefined = 1;

@@ -346,7 +346,8 @@ def check_mixed_batch(lib, oracle, workdir, big=False):
 
 
 def check_max_sizes(lib, oracle, workdir):
-    """The engine's documented limits (DESIGN.md section 8): 63 DAG nodes per unit work, 64 are refused when the unit is added;
+    """The engine's documented limits: 63 DAG nodes per unit on the fast path, 64..127 on the wide path
+    (tests/test_wide_units.py), 128 are refused when the unit is added;
     a path longer than the 65 536 cells the full finish stage can hold in group memory is served by the lean stage (runs
     only); if its SVs edit the path, by the direct full-stage launch with the cells in device memory -- ST_ERR_PATH_CAPACITY
     only where the group-memory form runs."""
@@ -365,13 +366,24 @@ def check_max_sizes(lib, oracle, workdir):
         assert r["status"] == 0 and r["n_nodes"] == K and r["num_orders"] == o["num_orders"], r
         assert b.unit_path(0, 0).tolist() == o["path"] and b.unit_path(0, 1).tolist() == o["path_indel"]
         b.close(); g.close()
-    s = synth.make_sample(512, 1024, "chain", 64, seed=4242)
-    lh, sols = s.write(workdir, "max_chain64")
+    s = synth.make_sample(512, 1024, "chain", 128, seed=4242)
+    lh, sols = s.write(workdir, "max_chain128")
     g = api.Graph(lib, lh)
     with pytest.raises(api.AmbiError) as e:
         api.Batch(lib).add_chromosome_sol(g, 0, sols[0])
     assert e.value.code == -10
     g.close()
+    s = synth.make_sample(512, 1024, "chain", 64, seed=4242)            # one node more than the fast path takes: the wide path, same long path
+    lh, sols = s.write(workdir, "max_chain64")
+    o = oracle.run_bfb(lh, sols)["chr"][0]
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sols[0])
+    b.upload(); b.run(0); b.download()
+    r = b.unit_result(0)
+    assert r["status"] == 0 and r["n_nodes"] == 64 and r["num_orders"] == o["num_orders"], r
+    assert b.unit_path(0, 0).tolist() == o["path"] and b.unit_path(0, 1).tolist() == o["path_indel"]
+    b.close(); g.close()
     s = synth.make_sample(512, 1024, "chain", 63, seed=4242, n_del=2)      # long path AND an SV that edits it
     lh, sols = s.write(workdir, "max_chain63_del")
     o = oracle.run_bfb(lh, sols)["chr"][0]

@@ -31,6 +31,7 @@ class HostSimBackend : public Backend {
     std::vector<int32_t> refin_list_;
     int64_t orders_needed_ = 0;
     std::vector<KernelTime> times_;
+    std::vector<WideUnit> wide_;          // working sets of the units with 64..127 nodes (ambi_wide.hpp)
     BatchArgs A_{};
 
   public:
@@ -57,6 +58,7 @@ class HostSimBackend : public Backend {
         if (!getenv("AMBI_HOSTSIM_TABLE_SCAN")) first_rows_.assign(U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride, 0);
         else first_rows_.clear();
         arena_.assign((size_t)(cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : 0), 0);
+        wide_.assign((size_t)hb.n_wide, WideUnit{});
         return 0;
     }
 
@@ -78,6 +80,7 @@ class HostSimBackend : public Backend {
         A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
         refin_list_.assign(units_.size() + 1, 0); refin_count_ = 0;
         A_.refin_list = refin_list_.data(); A_.refin_count = &refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
+        A_.wide = wide_.empty() ? nullptr : wide_.data(); A_.wide_index = wide_.empty() ? nullptr : hb_.wide_index.data();
         A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
         A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
     }
@@ -107,6 +110,19 @@ class HostSimBackend : public Backend {
             IdealTable tbl = unit_ideal_table(A_, u);
             AutoView V = auto_view(tbl);
             uint8_t* rows = A_.order_arena + out->order_off;
+            if (K > kMaxNodes) {   // ambi_enumerate_wide_kernel: every row unranked from the wide unit's counts (once per unit)
+                if (b == blk_off_[u]) {
+                    const WideUnit& X = A_.wide[A_.wide_index[u]];
+                    const int stride = row_stride(K);
+                    for (int64_t r = 0; r < R; r++) {
+                        uint8_t row[128];
+                        unrank_wide(X, (uint64_t)r, row);
+                        for (int d = K; d < stride; d++) row[d] = 0xFF;
+                        memcpy(rows + r * stride, row, (size_t)stride);
+                    }
+                }
+                continue;
+            }
             if (A_.first_rows && R <= A_.first_budget) {   // as ambi_enumerate_blocks_kernel: the table is a copy of the first rows
                 copy_first_rows(g, A_.first_rows + (int64_t)u * A_.first_budget * kFirstRowStride, K, R, rows);
                 continue;
@@ -160,8 +176,9 @@ class HostSimBackend : public Backend {
             if (out->status != ST_PENDING) continue;
             if (out->order_off < 0) continue;   // no table to search (the plan stage had no room): the finish stage behind turns this into ORDERS_CAPACITY, as on the device, where the finish kernels run before the search
             const UnitIn& U = units_[u];
-            std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
-            FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+            const bool wide = U.n_elem > kMaxNodes;
+            std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap, wide));
+            FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap, wide);
             load_first_work(g, A_, (int)u, W);
             const int64_t R = out->num_orders, nchunks = (R + chunk - 1) / chunk;
             std::vector<int64_t> order((size_t)nchunks);
@@ -174,7 +191,7 @@ class HostSimBackend : public Backend {
                     if (c * chunk >= search_limit(slot.found, slot.err_key)) continue;   // as ambi_search_kernel
                     stage_search_chunk(g, A_, (int)u, W, c * chunk, chunk, fwd, &slot);
                 }
-                std::vector<uint8_t> work2((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
+                std::vector<uint8_t> work2((size_t)first_work_bytes(U.n_seg, U.bkp_cap, wide));
                 stage_resolve(g, A_, (int)u, work2.data(), &slot, fwd, pass);
                 fwd = !fwd;
             }
@@ -190,7 +207,7 @@ class HostSimBackend : public Backend {
         // stage behind it, as the HIP backend launches them (env AMBI_EXPRESS_UNITS, default 32; 0 = never)
         const char* ex = getenv("AMBI_EXPRESS_UNITS");
         const int express_units = ex ? atoi(ex) : 32;
-        const bool express = Un <= express_units;
+        const bool express = Un <= express_units && hb_.n_wide == 0;   // (as HipBackend::run)
         if (express)
             for (int u = 0; u < Un; u++) {
                 const UnitIn& U = units_[u];
@@ -286,12 +303,13 @@ class HostSimBackend : public Backend {
                 const UnitIn& U = units_[u];
                 const int64_t R = unit_out(A_.results, u)->num_orders;
                 if (pass == 1 && all_pass0_last_valid(A_, u, R)) continue;
-                std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap)), rows(64 * kFirstRowStride);
-                FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+                const bool wide = U.n_elem > kMaxNodes;
+                std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap, wide)), rows(64 * kFirstRowStride);
+                FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap, wide);
                 load_first_work(g, A_, u, W);
                 // as the HIP backend: one thread per order for units with a short breakpoint path, the wavefront form otherwise
                 const char* el = getenv("AMBI_ALL_LANES");
-                const bool lanes = !(el && atoi(el) == 0) && U.bkp_cap <= kAllLaneMaxCells;
+                const bool lanes = !(el && atoi(el) == 0) && U.bkp_cap <= kAllLaneMaxCells && !wide;
                 std::vector<cell_t> cells(lanes ? (size_t)U.bkp_cap * 64 : 1);
                 for (int64_t c = 0; c < all_words(R); c++) {
                     if (!all_chunk_is_mine(A_, all_off_[u] / 2 + c, c, R)) continue;   // another rank's chunk
@@ -334,9 +352,10 @@ class HostSimBackend : public Backend {
         if (first < 0 || count < 0 || first + count > (int64_t)v.size() || stride <= 0) return ST_ERR_BAD_INPUT;
         HostGroup g;
         const UnitIn& U = units_[unit];
-        std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap));
+        const bool wide = U.n_elem > kMaxNodes;
+        std::vector<uint8_t> work((size_t)first_work_bytes(U.n_seg, U.bkp_cap, wide));
         std::vector<int32_t> offs((size_t)U.bkp_cap / 2 + 2);
-        FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap);
+        FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap, wide);
         load_first_work(g, A_, unit, W);
         const bool fwd0 = !(A_.flags & FLAG_REVERSED), fwd = pass == 0 ? fwd0 : !fwd0;
         for (int64_t j = 0; j < count; j++) {
@@ -400,6 +419,12 @@ class HostSimBackend : public Backend {
         return 0;
     }
     int copy_dag(int unit, Dag* out) override { *out = dags_[unit]; return 0; }
+    int copy_dag_wide(int unit, int32_t* pat, int32_t* loop, uint64_t* succ2) override {
+        if (unit < 0 || unit >= (int)units_.size() || hb_.wide_index[unit] < 0) return ST_ERR_BAD_INPUT;
+        const WideUnit& X = wide_[(size_t)hb_.wide_index[unit]];
+        memcpy(pat, X.dag.pat, sizeof(X.dag.pat)); memcpy(loop, X.dag.loop, sizeof(X.dag.loop)); memcpy(succ2, X.succ, sizeof(X.succ));
+        return 0;
+    }
     void set_timing(bool) override {}
     const std::vector<KernelTime>& kernel_times() override { return times_; }
     int64_t order_bytes_written() const override { return orders_needed_; }
