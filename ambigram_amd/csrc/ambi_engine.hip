@@ -663,9 +663,16 @@ __global__ __launch_bounds__(1024) void ambi_finish_ext_kernel(BatchArgs A, cons
 
 // Lean finish (ambi_stages.hpp: stage_finish_lean): every unit of the slice; units it cannot take are counted in
 // n_pending with status ST_REFINISH.  The last workgroup to finish reports n_pending to the host.
-__global__ __launch_bounds__(256) void ambi_finish_lean_kernel(BatchArgs A) {
+__global__ __launch_bounds__(256) void ambi_finish_lean_kernel(BatchArgs A, const int32_t* unit_list = nullptr, int list_count = 0) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
+    if (unit_list) {   // the listed units only (the units the parallel search has just resolved)
+        for (int i = (int)blockIdx.x; i < list_count; i += (int)gridDim.x) {
+            stage_finish_lean(g, A, unit_list[i], ambi_lds);
+            __syncthreads();
+        }
+        return;
+    }
     // a workgroup takes every gridDim.x-th unit: the grid is sized to the number of workgroups that should be resident
     // at a time (one per CU fits beside the enumerate workgroups), not to the batch
     for (int i = (int)blockIdx.x; i < A.n_units; i += (int)gridDim.x) {
@@ -1553,7 +1560,7 @@ class HipBackend : public Backend {
         const int fgrid = finish_grid_for(U);
         if (debug_) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d\n", fgrid, block_lds_);
         if (lean_finish_) {
-            hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A);
+            hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A, (const int32_t*)nullptr, 0);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
             // device (an empty list costs one launch of workgroups that exit at once)
             if (hb().any_sv) {
@@ -1826,7 +1833,26 @@ class HipBackend : public Backend {
             HIP_CK(hipGetLastError());
             fwd = !fwd;
         }
-        hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin), dim3(256), lds_finish_, stream_, A_, (const int32_t*)d_pend, (const int32_t*)nullptr, -1);
+        // finish: the units the search resolved go through the lean stage first (any path length) and through the full stage only
+        // when their SVs chain or edit the path (the list the lean kernel leaves on the device); the units the main chain's lean
+        // stage had handed over already go straight to the full stage
+        if (np > 0) {
+            BatchArgs Al = A_;
+            Al.host_pending = nullptr; Al.direct_full_on = 0;
+            HIP_CK(hipMemsetAsync(d_refin_count_, 0, sizeof(int32_t), stream_));
+            hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(np < 1024 ? np : 1024), dim3(256), lds_finish_lean_, stream_, Al, (const int32_t*)d_pend, np);
+            // ... with the path cells in device memory where the batch has such areas (units with deletion / duplication candidates:
+            // any path length), else in group memory (up to kPathLdsCells cells)
+            int32_t handed = 0;
+            HIP_CK(hipMemcpyAsync(&handed, d_refin_count_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+            HIP_CK(hipStreamSynchronize(stream_));
+            if (handed > 0 && d_direct_cells_ && direct_slots_ > 0)
+                hipLaunchKernelGGL(ambi_finish_ext_kernel, dim3(handed < direct_slots_ ? handed : direct_slots_), dim3(full_threads_), lds_finish_ext_, stream_, Al,
+                                   (const int32_t*)d_refin_list_, (int)handed, d_direct_cells_, direct_stride_);
+            else if (handed > 0)
+                hipLaunchKernelGGL(ambi_finish_kernel, dim3(handed < 256 ? handed : 256), dim3(256), lds_finish_, stream_, Al, (const int32_t*)d_refin_list_, (const int32_t*)d_refin_count_, -1);
+        }
+        if (nfin > np) hipLaunchKernelGGL(ambi_finish_kernel, dim3(nfin - np), dim3(256), lds_finish_, stream_, A_, (const int32_t*)(d_pend + np), (const int32_t*)nullptr, -1);
         HIP_CK(hipGetLastError());
         HIP_CK(hipStreamSynchronize(stream_));
         return 0;

@@ -104,10 +104,30 @@ def test_wide_and_ordinary_units_in_one_batch(hostsim_lib, oracle, workdir):
     check_mixed_batch(hostsim_lib, oracle, workdir, "wms", sharded=[0, 0])
 
 
+def test_wide_units_all_mode_on_the_host_simulation(hostsim_lib, oracle, workdir):
+    check_wide_all_mode(hostsim_lib, oracle, workdir, "wha", 100, 220)
+
+
 def check_wide_all_mode(lib, oracle, workdir, tag, n=140, m=300):
-    s = synth.make_sample(n, m, "mixed", 65, seed=1, name="%s_all65" % tag)
-    lh, sols = s.write(workdir)
-    assert parity.compare(lib, oracle, lh, sols, all_=True, keep_orders=False) == []
+    seen = set()
+    for tier, K, seed in (("mixed", 65, 1), ("chain", 70, 2), ("skew", 65, 3)):
+        s = synth.make_sample(n, m, tier, K, seed=seed, name="%s_all%s%d" % (tag, tier, K))
+        lh, sols = s.write(workdir)
+        o = oracle.run_bfb(lh, sols, all_=True, keep_orders=False)
+        if o["chr"][0]["ub_valid"]:     # the reference's own behaviour is undefined on one of the orders --all evaluates: refused, by both
+            e = api.reconstruct_sample(lib, lh, sols, all_=True)
+            assert not e["ok"] and e["chr"][0]["status"] == -12
+            seen.add("refused")
+            continue
+        if o["chr"][0]["first_valid"] < 0:   # no order assembles in either orientation (e.g. a cyclic relation: R = 0)
+            e = api.reconstruct_sample(lib, lh, sols, all_=True)
+            assert not e["ok"] and e["chr"][0]["status"] == api.ST_NO_VALID_ORDER and e["chr"][0]["num_orders"] == o["chr"][0]["num_orders"]
+            seen.add("none")
+            continue
+        assert parity.compare(lib, oracle, lh, sols, all_=True, keep_orders=False) == []
+        assert len(o["chr"][0]["all_paths"]) >= 1
+        seen.add("ok")
+    assert "ok" in seen
 
 
 @pytest.mark.gpu
