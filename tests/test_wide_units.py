@@ -105,12 +105,12 @@ def test_wide_and_ordinary_units_in_one_batch(hostsim_lib, oracle, workdir):
 
 
 def test_wide_units_all_mode_on_the_host_simulation(hostsim_lib, oracle, workdir):
-    check_wide_all_mode(hostsim_lib, oracle, workdir, "wha", 100, 220)
+    check_wide_all_mode(hostsim_lib, oracle, workdir, "wha", 80, 170)
 
 
 def check_wide_all_mode(lib, oracle, workdir, tag, n=140, m=300):
     seen = set()
-    for tier, K, seed in (("mixed", 65, 1), ("chain", 70, 2), ("skew", 65, 3)):
+    for tier, K, seed in (("mixed", 65, 1), ("chain", 70, 2)):      # (few thousand orders at most: --all prints every valid one)
         s = synth.make_sample(n, m, tier, K, seed=seed, name="%s_all%s%d" % (tag, tier, K))
         lh, sols = s.write(workdir)
         o = oracle.run_bfb(lh, sols, all_=True, keep_orders=False)
