@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
     ap.add_argument("--single-reps", type=int, default=200, help="repetitions of the single-sample latency leg (0 disables it)")
     ap.add_argument("--pipelined", type=int, default=1, help="1: also report the throughput with two resident batches on two streams (N = 1 only)")
+    ap.add_argument("--lazy", type=int, default=1, help="1: also report the step without the order tables (AMBI_FLAG_LAZY_ORDERS); 0: skip that leg")
     ap.add_argument("--target-lanes", type=int, default=0)
     ap.add_argument("--slices", type=int, default=0, help="unit ranges run on separate HIP streams (0: engine default)")
     ap.add_argument("--gather", type=int, default=-1, help="1: the timed region ends with the packing of the paths + ONE RCCL gather to "
@@ -223,10 +224,10 @@ def main():
     dom_bytes = per_kernel.get(dom, 0) / slices
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
     # HBM traffic by the PMC counters (rocprofv3 --pmc passes of this very command, corrected as MI355X_MICROARCH.md
-    # prescribes; profiles/traffic_r02.json, written by profiles/tools/collect.sh + summarize): per launch of the dominant
+    # prescribes; profiles/traffic_r03.json, written by profiles/tools/collect.sh + summarize): per launch of the dominant
     # kernel, and summed over every kernel of a step
     traffic, step_traffic = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -289,7 +290,7 @@ def main():
     # every topological order (LGM.cpp:3380-3409) and so does the headline step; in default mode nothing reads that table
     # (the scan reads the first orders the lattice stage unranks), so this is what the reconstructions alone cost.
     lazy = None
-    if world == 1:
+    if world == 1 and args.lazy:
         for _ in range(max(args.warmup, 1)):
             batch.run(api.FLAG_LAZY_ORDERS, stream)
         batch.wait(); torch.cuda.synchronize()
