@@ -243,8 +243,14 @@ class Graph:
 
     def components(self):
         """Components collected by read_juncs (readComponents, LGM.cpp:5096-5156)."""
-        ids, offs = np.zeros(1 << 16, np.int32), np.zeros(1 << 12, np.int32)
-        n = self.lib.ambi_graph_components(self.h, ids.ctypes.data_as(_P(C.c_int32)), len(ids), offs.ctypes.data_as(_P(C.c_int32)), len(offs))
+        # sizes first (null buffers: the call returns the component count, the last offset is the id count), then exact buffers
+        n = self.lib.ambi_graph_components(self.h, None, 0, None, 0)
+        if n <= 0:
+            return []
+        offs = np.zeros(n + 1, np.int32)
+        self.lib.ambi_graph_components(self.h, None, 0, offs.ctypes.data_as(_P(C.c_int32)), n + 1)
+        ids = np.zeros(max(int(offs[n]), 1), np.int32)
+        self.lib.ambi_graph_components(self.h, ids.ctypes.data_as(_P(C.c_int32)), len(ids), offs.ctypes.data_as(_P(C.c_int32)), n + 1)
         return [ids[offs[c]:offs[c + 1]].tolist() for c in range(n)]
 
     def chrom_name(self, seg_id):
