@@ -393,9 +393,24 @@ def main():
             fresh.close()
         new_ms = span / reps3 * 1e3
         assert p_new.tolist() == batch.unit_path(0, 1).tolist()
+        # (f) (c) as a C caller of the ABI sees it: ambigram_amd/bin/e2e_probe (csrc/e2e_probe.cpp) runs the same four calls natively
+        #     in a process of its own, on the same sample
+        c_probe = None
+        try:
+            import subprocess
+            exe = os.path.join(ROOT, "ambigram_amd", "bin", "e2e_probe")
+            if os.path.exists(exe):
+                one.wait(); torch.cuda.synchronize()
+                pr = subprocess.run([exe, files[0][0], files[0][1][0], str(args.single_reps)], capture_output=True, text=True, timeout=120)
+                if pr.returncode == 0:
+                    c_probe = json.loads(pr.stdout.strip().splitlines()[-1])
+                    assert c_probe["path_len"] == len(p_e2e)
+        except Exception as e:      # the probe is optional
+            c_probe = {"error": str(e)}
         single = {"gpu_ms": gpu_ms, "gpu_ms_order_table_included": gpu_all_ms, "e2e_ms": e2e_ms, "gpu_ms_with_upload_and_download": e2e_ms,
+                  "e2e_ms_c_caller": (c_probe["e2e_us_mean"] / 1e3) if c_probe and "e2e_us_mean" in c_probe else None, "c_caller": c_probe,
                   "e2e_ms_blob_download_and_table": pcie_ms, "e2e_ms_new_batch_object_incl_sol_parse": new_ms, "reps": args.single_reps,
-                  "what": "e2e_ms: packed unit on the host -> final path on the host (upload, run, fetch_paths, unit_path; SURVEY 8d's region; the order table "
+                  "what": "e2e_ms: packed unit on the host -> final path on the host (upload, run, fetch_paths, unit_path through ctypes; e2e_ms_c_caller: the same four calls from C; SURVEY 8d's region; the order table "
                           "of the sample is written behind it); gpu_ms: launch -> reconstruction results complete, inputs resident in HBM (ambi_batch_wait_results)",
                   "sample": "sample 0 of the batch (1 unit, R = %d orders)" % res[0]["num_orders"]}
         if cpu is not None:
@@ -407,6 +422,8 @@ def main():
             single["speedup"] = best * 1e3 / e2e_ms
             single["e2e_speedup"] = best * 1e3 / e2e_ms
             single["speedup_inputs_resident"] = best * 1e3 / gpu_ms
+            if single.get("e2e_ms_c_caller"):
+                single["e2e_speedup_c_caller"] = best * 1e3 / single["e2e_ms_c_caller"]
             single["cpu_kind"] = "port (oracle, 1 core, best of 5)"
 
     # ---- the step WITH the ILP assembly ("reported twice").  BFB_ILP (LGM.cpp:4397-4752) is where the
