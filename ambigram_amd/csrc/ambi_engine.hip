@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
 // Small batches: the whole reconstruction of a unit whose first order assembles, one workgroup per unit (ambi_stages.hpp:
 // stage_express) -- junction side and DAG side on two wavefronts at once, then imperfectFBI, then the finish stage on the
 // workgroup.  The lattice / order table follow in the kernels behind (ambi_lattice_kernel, plan, enumerate).
-__global__ __launch_bounds__(256) void ambi_express_kernel(BatchArgs A) {
+__global__ __launch_bounds__(1024) void ambi_express_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup gb(scratch);
     WaveGroup gw;
@@ -993,6 +993,7 @@ class HipBackend : public Backend {
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
+    int express_threads_ = 512;   // env AMBI_EXPRESS_THREADS (256 / 512 / 1024): the serial stages use three wavefronts, the finish stage and the mailbox copy all of them
     int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0, lds_lattice_own_ = 0;
     bool lazy_ = false, tables_written_ = false;   // FLAG_LAZY_ORDERS: the run leaves the order tables out; they are written on demand
     bool side_lattice_ = false, flushed_ = false; hipStream_t lattice_stream_ = nullptr;   // env AMBI_SIDE_LATTICE=0: the lattice kernel behind the express kernel (round 2)
@@ -1263,6 +1264,7 @@ class HipBackend : public Backend {
         }
         {   // express path: small batches only, and only if a unit's whole working set fits one workgroup's group memory
             const char* e9 = getenv("AMBI_EXPRESS_UNITS"); express_units_ = e9 ? atoi(e9) : 32;
+            { const char* et = getenv("AMBI_EXPRESS_THREADS"); express_threads_ = et ? atoi(et) : 512; if (express_threads_ != 256 && express_threads_ != 1024) express_threads_ = 512; }   // (measured, one 256-segment sample: 256 / 512 / 1024 threads = 79.7 / 76.8 / 79.2 us run -> results)
             lds_express_ = (int)express_work_bytes(H.max_n, H.max_m, H.max_k, H.max_bkp, finish_path_cells_, H.max_out) + 64;
             lds_lattice_ = (int)(64 * 8 + kPrepLatticeBytes + 64);
             lds_lattice_own_ = (int)lattice_own_bytes(H.max_k) + 64;
@@ -1432,7 +1434,7 @@ class HipBackend : public Backend {
                 (void)hipStreamWaitEvent(lattice_stream_, flushed_ ? ev_fork_ : lease_->ev_tail, 0);
             }
             tick("ambi_express_kernel", s, 0, true);
-            hipLaunchKernelGGL(ambi_express_kernel, dim3(A.n_units), dim3(256), lds_express_, st, Ax);
+            hipLaunchKernelGGL(ambi_express_kernel, dim3(A.n_units), dim3(express_threads_), lds_express_, st, Ax);
             tick("ambi_express_kernel", s, 0, false);
             (void)hipEventRecord(ev_express_, st);
             tick("ambi_plan_kernel", s, 1, true);
