@@ -1973,7 +1973,9 @@ class HipBackend : public Backend {
             if (s == base) continue;
             double sum = 0; size_t cnt = 0;
             for (size_t u = 0; u < U; u++) {
-                const int64_t a = clk[u * kStageSlots + base], b = clk[u * kStageSlots + s];
+                int64_t a = clk[u * kStageSlots + base];
+                const int64_t b = clk[u * kStageSlots + s];
+                if (!a && base == 0) a = clk[u * kStageSlots + 9];   // express kernel: the marks of the prepare pieces count from its own first mark
                 if (a && b && b >= a) { sum += (double)(b - a); cnt++; }
             }
             if (cnt) fprintf(stderr, " [%d]=%.0f", s, sum / cnt);

@@ -253,6 +253,136 @@ AMBI_HD int eval_place(const G& g, const DAG& D, const uint8_t* ord, bool forwar
     return i;
 }
 
+// The placement part for ONE wavefront with the breakpoint cells in REGISTERS (device code): cell i lives in lane i & 63,
+// register i >> 6 -- up to kRegCells cells.  A placement of the group-memory form above costs ~2 700 cycles on a lone wavefront
+// (a strided scan, a max-reduction, a chunked shift through group memory with two barriers per round, the writes: ~25 dependent
+// round trips); here the candidate test is a compare per lane with its neighbours fetched by lane shuffles, the last candidate a
+// wave-wide maximum, and the insert's shift one lane rotation per register.  Same cells, same return values; kRegsGiveUp when the
+// path outgrows the registers (the caller then runs eval_place).  Writes the cells to `bkp` (group memory) at the end.
+constexpr int kRegCells = 256;
+constexpr int kRegsGiveUp = -1000;
+#if defined(__HIP_DEVICE_COMPILE__)
+// NR registers per lane hold 64 * NR cells; everything that loops over the registers is unrolled at compile time
+template <int NR>
+struct RegCells {
+    int c[NR];
+    // cell i, i uniform over the wavefront
+    __device__ inline int get_u(int i) const {
+        int v = c[0];
+#pragma unroll
+        for (int r = 1; r < NR; r++) v = (i >> 6) == r ? c[r] : v;
+        return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i & 63));
+    }
+    __device__ inline void set_u(int i, int v, int lane) {
+        const bool me = lane == (i & 63);
+#pragma unroll
+        for (int r = 0; r < NR; r++) c[r] = (me && (i >> 6) == r) ? v : c[r];
+    }
+};
+template <int NR, class DAG>
+__device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool forward, cell_t* bkp, int cap, int* L_out) {
+    constexpr int kCells = 64 * NR;
+    const int lane = (int)(threadIdx.x & 63u);
+    WaveGroup g;
+    const int K = D.K;
+    int L = 0;
+    int x = ord[0];
+    const bool isPat = D.pat[x][0] != 0, isLoop = D.loop[x][0] != 0;
+    if (!isPat && !isLoop) { *L_out = 0; return ST_ERR_REF_UB; }
+    RegCells<NR> R;
+    {
+        const int s = isPat ? D.pat[x][0] : D.loop[x][0], e = isPat ? D.pat[x][1] : D.loop[x][1];
+        int q0, q1, q2, q3;
+        if (forward) { q0 = s; q1 = e; q2 = -e; q3 = -s; } else { q0 = -e; q1 = -s; q2 = s; q3 = e; }
+        const int len = isPat ? 2 : 4 * D.loop[x][2];
+        if (len > cap) { *L_out = 0; return ST_ERR_BKP_CAPACITY; }
+        if (len > kCells) return kRegsGiveUp;
+        const int w = lane & 3, v = w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3;      // (64 is a multiple of 4: the pattern is the same in every register)
+#pragma unroll
+        for (int r = 0; r < NR; r++) R.c[r] = 64 * r + lane < len ? v : 0;
+        L = len;
+    }
+    int i;
+    for (i = 1; i < K; i++) {
+        x = ord[i];
+        if (D.pat[x][0] != 0) {   // LGM.cpp:3572-3585
+            const int s = D.pat[x][0], e = D.pat[x][1];
+            if (L == 0) { *L_out = 0; return ST_ERR_REF_UB; }
+            const int back = R.get_u(L - 1);
+            if (L + 2 > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
+            if (L + 2 > kCells) return kRegsGiveUp;
+            if (back == -s) { R.set_u(L, s, lane); R.set_u(L + 1, e, lane); L += 2; }
+            else if (back == e) { R.set_u(L, -e, lane); R.set_u(L + 1, -s, lane); L += 2; }
+            else break;
+        } else if (D.loop[x][0] != 0) {   // LGM.cpp:3586-3644
+            const int s = D.loop[x][0], e = D.loop[x][1], cn = D.loop[x][2];
+            // candidates: odd slots holding -s or e that pass the nesting test |cell[q-1]| vs |cell[q+2]| (only below L-2); the
+            // neighbours come from the lane below (same register: q is odd) and from two lanes above (the next register for lanes 62, 63)
+            const int up = (lane + 2) & 63, dn = (lane + 63) & 63;
+            const bool wrap = lane >= 62;
+            int above[NR + 1];
+#pragma unroll
+            for (int r = 0; r < NR; r++) above[r] = __shfl(R.c[r], up, 64);
+            above[NR] = 0;
+            int best = -1;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int q = 64 * r + lane, c = R.c[r];
+                const bool cand = q < L && (q & 1) && (c == -s || c == e);
+                const int below = __shfl(c, dn, 64);
+                bool skip = false;
+                if (q < L - 2) { const int xx = iabs(below), yy = iabs(wrap ? above[r + 1] : above[r]); skip = (c == -s) ? (xx < yy) : (xx > yy); }
+                const int enc = (c == -s) ? 0x10000 + q : q;
+                if (cand && !skip && enc > best) best = enc;
+            }
+            best = g.max_i32(best);
+            if (best < 0) break;
+            const bool viaV1 = best >= 0x10000;
+            const int f = viaV1 ? best - 0x10000 : best;
+            const int cnt = 4 * cn;
+            if (L + cnt > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
+            if (L + cnt > kCells) return kRegsGiveUp;
+            const bool hasNext = (f + 1 != L);
+            // cells [f+1, L) move up by cnt: cell i takes cell i - cnt -- a lane rotation by cnt & 63, the source register one lower for
+            // the lanes the rotation wraps (and cnt >> 6 lower for long loops)
+            {
+                const int rot = cnt & 63, sl = (lane - rot) & 63, down = (cnt >> 6) + (lane < rot ? 1 : 0);
+                int sh[NR];
+#pragma unroll
+                for (int r = 0; r < NR; r++) sh[r] = __shfl(R.c[r], sl, 64);
+                int qq0, qq1, qq2, qq3;
+                if (viaV1) { qq0 = s; qq1 = e; qq2 = -e; qq3 = -s; } else { qq0 = -e; qq1 = -s; qq2 = s; qq3 = e; }
+                const int w = (lane - (f + 1)) & 3, ins = w == 0 ? qq0 : w == 1 ? qq1 : w == 2 ? qq2 : qq3;   // (the register base is a multiple of 4)
+#pragma unroll
+                for (int r = NR - 1; r >= 0; r--) {
+                    const int ci = 64 * r + lane;
+                    int moved = 0;
+#pragma unroll
+                    for (int t = 0; t < NR; t++) moved = (r - down == t) ? sh[t] : moved;
+                    R.c[r] = ci >= f + 1 + cnt ? moved : (ci >= f + 1 ? ins : R.c[r]);
+                }
+            }
+            R.set_u(f, viaV1 ? -s : e, lane);                          // *temp (LGM.cpp:3627 / :3640)
+            if (hasNext) R.set_u(f + 1 + cnt, viaV1 ? s : -e, lane);   // *(temp+1): the cell that stood behind f, now behind the insert
+            L += cnt;
+        }
+        // both slots empty (possible after the library sort for K > 16): nothing is placed, the loop goes on
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) if (64 * r + lane < L) bkp[64 * r + lane] = (cell_t)R.c[r];
+    g.sync();
+    *L_out = L;
+    return i;
+}
+template <class DAG>
+__device__ inline int eval_place_regs(const DAG& D, const uint8_t* ord, bool forward, cell_t* bkp, int cap, int* L_out) {
+    if (cap <= 64) return eval_place_regs_n<1>(D, ord, forward, bkp, cap, L_out);
+    if (cap <= 128) return eval_place_regs_n<2>(D, ord, forward, bkp, cap, L_out);
+    if (cap <= 256) return eval_place_regs_n<4>(D, ord, forward, bkp, cap, L_out);
+    return kRegsGiveUp;
+}
+#endif
+
 // Evaluate one order.  Returns 1 valid / 0 invalid / negative Status on error.  *L_out = bkp length.
 template <class G, class DAG>
 AMBI_HD int eval_order(const G& g, const DAG& D, const uint8_t* ord, bool forward, const InvMap& inv,

@@ -1159,7 +1159,13 @@ AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
         int placed = -1, L = 0;
         if (dst == ST_OK) {
             gw.sync();
-            if (first_order(gw, *W.P.dag, W.F.ord)) placed = eval_place(gw, *W.P.dag, W.F.ord, forward, W.F.bkp, U.bkp_cap, &L);
+            if (first_order(gw, *W.P.dag, W.F.ord)) {
+                placed = kRegsGiveUp;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (GW::kLaneArrays) placed = eval_place_regs(*W.P.dag, W.F.ord, forward, W.F.bkp, U.bkp_cap, &L);   // breakpoint cells in registers (up to 256 of them)
+#endif
+                if (placed == kRegsGiveUp) placed = eval_place(gw, *W.P.dag, W.F.ord, forward, W.F.bkp, U.bkp_cap, &L);
+            }
             else placed = 0;   // no order: nothing assembles here; the lattice stage reports R = 0
         }
         if (gw.tid() == 0) { fl[2] = dst; fl[3] = placed; fl[4] = L; }
