@@ -318,7 +318,7 @@ __device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool f
             const int s = D.loop[x][0], e = D.loop[x][1], cn = D.loop[x][2];
             // candidates: odd slots holding -s or e that pass the nesting test |cell[q-1]| vs |cell[q+2]| (only below L-2); the
             // neighbours come from the lane below (same register: q is odd) and from two lanes above (the next register for lanes 62, 63)
-            const int up = (lane + 2) & 63, dn = (lane + 63) & 63;
+            const int up = (lane + 2) & 63;
             const bool wrap = lane >= 62;
             int above[NR + 1];
 #pragma unroll
@@ -329,7 +329,7 @@ __device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool f
             for (int r = 0; r < NR; r++) {
                 const int q = 64 * r + lane, c = R.c[r];
                 const bool cand = q < L && (q & 1) && (c == -s || c == e);
-                const int below = __shfl(c, dn, 64);
+                const int below = __builtin_amdgcn_update_dpp(0, c, 0x111 /* row_shr:1 */, 0xf, 0xf, false);   // lane - 1 (candidates sit in odd lanes: never the first lane of a row)
                 bool skip = false;
                 if (q < L - 2) { const int xx = iabs(below), yy = iabs(wrap ? above[r + 1] : above[r]); skip = (c == -s) ? (xx < yy) : (xx > yy); }
                 const int enc = (c == -s) ? 0x10000 + q : q;
