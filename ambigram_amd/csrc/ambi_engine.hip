@@ -1966,7 +1966,9 @@ class HipBackend : public Backend {
         const size_t U = hb().units.size();
         std::vector<int64_t> clk(U * kStageSlots);
         if (hipMemcpy(clk.data(), d_stage_clk_, clk.size() * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return;
-        // marks 0-8 and 22-31: prepare (22-24 inside constructDAG, 26-28 inside the lattice); 9-12: scan; 16-21: finish
+        // marks 0-8 and 22-31: prepare (22-24 inside constructDAG, 26-28 inside the lattice); 9-12: scan; 16-21: finish.
+        // Express kernel: 9 = start, 6 = junction side done, 7 = DAG built, 8 = order 0 found, 10 = both sides done (placement
+        // included), 11 = imperfectFBI done, 12 = finish stage done
         fprintf(stderr, "ambigram_hip stage profile (mean cycles from the first mark of the stage, %zu units):", U);
         for (int s = 1; s < kStageSlots; s++) {
             const int base = ((s >= 13 && s <= 15) || s == 29 || s == 30) ? 31 : (s == 25 ? 9 : ((s <= 8 || s >= 22) ? 0 : (s <= 12 ? 9 : 16)));   // 13-15, 29, 30: image build (from 31)
@@ -1975,7 +1977,7 @@ class HipBackend : public Backend {
             for (size_t u = 0; u < U; u++) {
                 int64_t a = clk[u * kStageSlots + base];
                 const int64_t b = clk[u * kStageSlots + s];
-                if (!a && base == 0) a = clk[u * kStageSlots + 9];   // express kernel: the marks of the prepare pieces count from its own first mark
+                if (!a && (base == 0 || base == 31)) a = clk[u * kStageSlots + 9];   // express kernel: the marks of the prepare pieces count from its own first mark
                 if (a && b && b >= a) { sum += (double)(b - a); cnt++; }
             }
             if (cnt) fprintf(stderr, " [%d]=%.0f", s, sum / cnt);

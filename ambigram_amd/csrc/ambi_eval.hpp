@@ -285,16 +285,21 @@ __device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool f
     const int lane = (int)(threadIdx.x & 63u);
     WaveGroup g;
     const int K = D.K;
+    if (K > 64) return kRegsGiveUp;
     int L = 0;
-    int x = ord[0];
-    const bool isPat = D.pat[x][0] != 0, isLoop = D.loop[x][0] != 0;
+    // the elements in placement order, one per lane: the loop below fetches element i with v_readlane instead of a chain of
+    // dependent reads (order -> node -> record)
+    int e_p0 = 0, e_p1 = 0, e_l0 = 0, e_l1 = 0, e_l2 = 0;
+    if (lane < K) { const int xj = ord[lane]; e_p0 = D.pat[xj][0]; e_p1 = D.pat[xj][1]; e_l0 = D.loop[xj][0]; e_l1 = D.loop[xj][1]; e_l2 = D.loop[xj][2]; }
+    auto elem = [&](int v, int i) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i)); };
+    const bool isPat = elem(e_p0, 0) != 0, isLoop = elem(e_l0, 0) != 0;
     if (!isPat && !isLoop) { *L_out = 0; return ST_ERR_REF_UB; }
     RegCells<NR> R;
     {
-        const int s = isPat ? D.pat[x][0] : D.loop[x][0], e = isPat ? D.pat[x][1] : D.loop[x][1];
+        const int s = isPat ? elem(e_p0, 0) : elem(e_l0, 0), e = isPat ? elem(e_p1, 0) : elem(e_l1, 0);
         int q0, q1, q2, q3;
         if (forward) { q0 = s; q1 = e; q2 = -e; q3 = -s; } else { q0 = -e; q1 = -s; q2 = s; q3 = e; }
-        const int len = isPat ? 2 : 4 * D.loop[x][2];
+        const int len = isPat ? 2 : 4 * elem(e_l2, 0);
         if (len > cap) { *L_out = 0; return ST_ERR_BKP_CAPACITY; }
         if (len > kCells) return kRegsGiveUp;
         const int w = lane & 3, v = w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3;      // (64 is a multiple of 4: the pattern is the same in every register)
@@ -304,9 +309,9 @@ __device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool f
     }
     int i;
     for (i = 1; i < K; i++) {
-        x = ord[i];
-        if (D.pat[x][0] != 0) {   // LGM.cpp:3572-3585
-            const int s = D.pat[x][0], e = D.pat[x][1];
+        const int p0 = elem(e_p0, i), l0 = elem(e_l0, i);
+        if (p0 != 0) {   // LGM.cpp:3572-3585
+            const int s = p0, e = elem(e_p1, i);
             if (L == 0) { *L_out = 0; return ST_ERR_REF_UB; }
             const int back = R.get_u(L - 1);
             if (L + 2 > cap) { *L_out = L; return ST_ERR_BKP_CAPACITY; }
@@ -314,8 +319,8 @@ __device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool f
             if (back == -s) { R.set_u(L, s, lane); R.set_u(L + 1, e, lane); L += 2; }
             else if (back == e) { R.set_u(L, -e, lane); R.set_u(L + 1, -s, lane); L += 2; }
             else break;
-        } else if (D.loop[x][0] != 0) {   // LGM.cpp:3586-3644
-            const int s = D.loop[x][0], e = D.loop[x][1], cn = D.loop[x][2];
+        } else if (l0 != 0) {   // LGM.cpp:3586-3644
+            const int s = l0, e = elem(e_l1, i), cn = elem(e_l2, i);
             // candidates: odd slots holding -s or e that pass the nesting test |cell[q-1]| vs |cell[q+2]| (only below L-2); the
             // neighbours come from the lane below (same register: q is odd) and from two lanes above (the next register for lanes 62, 63)
             const int up = (lane + 2) & 63;

@@ -1111,15 +1111,16 @@ AMBI_HD bool first_order(const G& g, const Dag& D, uint8_t* ord) {
     if (g.size() >= 64) {
         // node j in thread j: "all my predecessors are placed and I am not" is one ballot per step
         const int j = g.tid();
-        const uint64_t mine = j < K ? D.pred[j & 63] : ~0ull;
-        uint64_t placed = 0;
+        uint64_t waiting = j < K ? D.pred[j & 63] : ~0ull;   // my predecessors not yet placed
+        bool open_ = j < K;                                  // I am not placed yet
         bool ok = K > 0;
         for (int d = 0; d < K; d++) {
-            const uint64_t av = g.ballot_u64(j < K && !((placed >> j) & 1ull) && (mine & ~placed) == 0);
+            const uint64_t av = g.ballot_u64(open_ && waiting == 0);
             if (!av) { ok = false; break; }
             const int v = ctz64(av);
             if (j == 0) ord[d] = (uint8_t)v;
-            placed |= 1ull << v;
+            waiting &= ~(1ull << v);
+            open_ = open_ && j != v;
         }
         if (!ok && j == 0) ord[0] = 0xFF;
         g.sync();
@@ -1153,13 +1154,16 @@ AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
         int bias = 1; bool no_fbi = false; double inv_sum = 0;
         prep_junctions(gw, A, u, U, W.P, &bias, &no_fbi, &inv_sum);
         if (gw.tid() == 0) { fl[0] = bias; fl[1] = no_fbi ? 1 : 0; *inv_sum_slot = inv_sum; }
+        AMBI_MARK(A, gw, u, 6);
     }
     if (role == 1 || role < 0) {
         int dst = prep_dag(gw, A, u, U, W.P, role < 0 ? W.target : nullptr);   // (a third wavefront fills the target CN, below)
         int placed = -1, L = 0;
+        AMBI_MARK(A, gw, u, 7);
         if (dst == ST_OK) {
             gw.sync();
             if (first_order(gw, *W.P.dag, W.F.ord)) {
+                AMBI_MARK(A, gw, u, 8);
                 placed = kRegsGiveUp;
 #if defined(__HIP_DEVICE_COMPILE__)
                 if constexpr (GW::kLaneArrays) placed = eval_place_regs(*W.P.dag, W.F.ord, forward, W.F.bkp, U.bkp_cap, &L);   // breakpoint cells in registers (up to 256 of them)

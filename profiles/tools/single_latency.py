@@ -27,3 +27,5 @@ c = 0.0
 for _ in range(reps):
     t = time.perf_counter(); one.upload(); one.run(0); one.fetch_paths(); p = one.unit_path(0, 1); c += time.perf_counter() - t; one.wait()
 print("us: resident run->results %.1f   run->table %.1f   e2e upload->path %.1f" % (a / reps * 1e6, b / reps * 1e6, c / reps * 1e6))
+if os.environ.get("AMBI_STAGE_PROFILE"):
+    one.run(0); one.wait(); one.download()      # (the stage profile is printed by download())
