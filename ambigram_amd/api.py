@@ -65,6 +65,7 @@ def _declare(L):
         "ambi_batch_add_chromosome_sol": (C.c_int, [vp, vp, i32, C.c_char_p]),
         "ambi_batch_add_chromosome_sol_block": (C.c_int, [vp, vp, i32, C.c_char_p, i32, i32]),
         "ambi_graph_recalculate": (C.c_int, [vp]),
+        "ambi_graph_write_lh": (C.c_int, [vp, C.c_char_p]),
         "ambi_ilp_build_sc": (C.c_int, [vp, i32, i32, pd, pd, _P(vp)]),
         "ambi_batch_add_unit": (C.c_int, [vp, i32, i32, pd, i32, pi32, pi32, pi8, pi8, pd, i32, pi32, pi32, pi32, pi32, i32, i32]),
         "ambi_batch_size": (C.c_int, [vp, pi32]),
@@ -201,6 +202,12 @@ class Graph:
         if rc != 0:
             raise AmbiError(self.lib, rc, "read_juncs")
         self._refresh()
+
+    def write_lh(self, path):
+        """Graph::writeGraph (Graph.cpp:239-266): the graph as it stands, as .lh text"""
+        rc = self.lib.ambi_graph_write_lh(self.h, path.encode())
+        if rc != 0:
+            raise AmbiError(self.lib, rc, "write_lh")
 
     def segments(self):
         n = self.n_seg

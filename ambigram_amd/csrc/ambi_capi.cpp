@@ -162,6 +162,10 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
     copy_text(g->g.main_chr, main_chr, cap);
     return 0;
 }
+int ambi_graph_write_lh(ambi_graph_t* g, const char* lh_path) {
+    if (!g || !lh_path) return AMBI_ERR_ARG;
+    return write_lh(g->g, lh_path);
+}
 int ambi_graph_recalculate(ambi_graph_t* g) {
     if (!g) return AMBI_ERR_ARG;
     int rc = hap_depth(g->g);

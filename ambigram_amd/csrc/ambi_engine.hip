@@ -882,6 +882,14 @@ class DevicePool {
 };
 // a side stream of the lease: kind 0 lean finish / scan, 1 direct full finish, 2 scan ahead; prio 0 default, 1 lowest, 2 highest
 static int lease_stream(Lease* L, int kind, int prio, hipStream_t* out) {
+    static const bool shared = [] { const char* e = getenv("AMBI_SHARE_STREAMS"); return e && atoi(e) != 0; }();
+    if (shared && L->device >= 0 && L->device < 16) {
+        // experiment: one set of side streams per DEVICE, used by every lease (several resident batches then need no more hardware queues than one)
+        static std::recursive_mutex mu; static Lease* holder[16] = {};
+        std::lock_guard<std::recursive_mutex> lk(mu);
+        if (!holder[L->device]) holder[L->device] = L;
+        if (holder[L->device] != L) { const int rc = lease_stream(holder[L->device], kind, prio, out); if (!rc) L->side[kind][prio] = *out; return rc; }
+    }
     if (!L->side[kind][prio]) {
         int least = 0, greatest = 0;
         if (prio != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {

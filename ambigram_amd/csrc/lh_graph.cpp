@@ -282,6 +282,30 @@ int read_juncs(LhGraph& g, const std::string& path) {   // LGM.cpp:5096-5156
     return LH_OK;
 }
 
+// Graph::writeGraph (Graph.cpp:239-266): the graph as it stands (after the copy-number maths and any .juncs additions) back
+// into .lh text.  The reference writes a fixed sample name ("TEST"), only these header keys, every segment with its
+// lower-bound flag ('B': a freshly read segment always has it, Segment.cpp:16) and numbers through operator<< of a default
+// ostream (= printf %g); it also prints "write seg" to stdout, which goes to the graph's log here.
+int write_lh(LhGraph& g, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) return LH_ERR_OPEN;
+    auto num = [](double v) { char b[64]; snprintf(b, sizeof b, "%g", v); return std::string(b); };
+    std::string src, snk;
+    for (int32_t v : g.source_ids) { src += std::to_string(v); src += ','; }      // Graph.cpp:780-796: a comma behind every id
+    for (int32_t v : g.sink_ids) { snk += std::to_string(v); snk += ','; }
+    fprintf(f, "SAMPLE_NAME TEST\nAVG_SEG_DP %s\nAVG_JUNC_DP %s\nPURITY %s\nAVG_PLOIDY %s\nPLOIDY %s\nSOURCE %s\nSINK %s\n", num(g.avg_coverage).c_str(),
+            num(g.avg_cov_junc).c_str(), num(g.purity).c_str(), num(g.avg_ploidy).c_str(), g.ploidy.c_str(), src.c_str(), snk.c_str());
+    g.log.push_back("write seg");
+    for (int i = 0; i < g.n_seg(); i++)
+        fprintf(f, "SEG H:%d:%s:%d:%d %s %s B\n", g.seg_id[i], g.seg_chrom[i].c_str(), g.seg_start[i], g.seg_end[i], num(g.seg_cov[i]).c_str(), num(g.seg_cn[i]).c_str());
+    for (int j = 0; j < g.n_junc(); j++)
+        fprintf(f, "JUNC H:%d:%c H:%d:%c %s %s %c %c\n", g.j_src[j], g.j_sdir[j] > 0 ? '+' : '-', g.j_tgt[j], g.j_tdir[j] > 0 ? '+' : '-', num(g.j_cov[j]).c_str(),
+                num(g.j_cn[j]).c_str(), g.j_inferred[j] ? 'I' : 'U', g.j_bounded[j] ? 'B' : 'U');
+    const bool bad = ferror(f) != 0;
+    if (fclose(f) != 0 || bad) return LH_ERR_OPEN;
+    return LH_OK;
+}
+
 int read_sol(const std::string& path, SolFile& s) {   // localhap.cpp:184-212
     std::ifstream f(path);
     if (!f) return LH_ERR_SOL_OPEN;

@@ -72,7 +72,8 @@ const char* lh_error_string(int code);
 int read_lh(const std::string& path, LhGraph& g);                 // Graph.cpp:109-237 + calculateHapDepth/CopyNum + PROP
 int hap_depth(LhGraph& g);                                        // Graph.cpp:312-367 (part of read_lh; `--op sc_bfb` runs it a second time on its first graph)
 void copy_num(LhGraph& g);                                        // Graph.cpp:369-405
-int read_juncs(LhGraph& g, const std::string& path);              // LGM.cpp:5096-5156 (needs partitions set)
+int read_juncs(LhGraph& g, const std::string& path);
+int write_lh(LhGraph& g, const std::string& path);               // Graph.cpp:239-266 Graph::writeGraph              // LGM.cpp:5096-5156 (needs partitions set)
 void set_partitions(LhGraph& g);                                   // localhap.cpp:94-98
 
 struct SolFile {                                                   // localhap.cpp:192-212

@@ -96,6 +96,12 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
 /* calculateHapDepth + calculateCopyNum once more (`--op sc_bfb` does that to its first graph, localhap.cpp:438-439): entries
  * whose copy number is still <= 0 are recomputed and echoed again; new lines are appended to the graph's log. */
 int ambi_graph_recalculate(ambi_graph_t* g);
+/* replaces Graph::writeGraph (Graph.cpp:239-266): the graph as it stands -- after the copy-number maths and any junctions
+ * ambi_graph_read_juncs added -- as .lh text, byte for byte what the reference writes (fixed SAMPLE_NAME TEST, its seven
+ * header keys, numbers in %g form, a 'B' behind every segment); "write seg", which the reference prints to stdout, is
+ * appended to the graph's log. */
+int ambi_graph_write_lh(ambi_graph_t* g, const char* lh_path);
+
 int ambi_graph_components(const ambi_graph_t* g, int32_t* ids, int32_t ids_cap, int32_t* offsets, int32_t off_cap);
 
 /* ------------------------------------------------------------------------------------------------

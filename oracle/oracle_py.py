@@ -127,13 +127,16 @@ def translocation(lh, paths):
     return _take(L.oracle_translocation_json(lh.encode(), txt.encode()))
 
 
-def ref_graph_dump(lh, juncs=None):
+def ref_graph_dump(lh, juncs=None, write_to=None):
     """Parsed graph from the REAL reference graph model (oracle/_ref, container-only). None if unavailable.
     With `juncs`: after the graph-level effects of readComponents, driven through the reference's graph API."""
     exe = os.path.join(_HERE, "_ref", "ref_graph_dump")
     if not os.path.exists(exe):
         return None
-    out = subprocess.run([exe, lh] + ([juncs] if juncs else []), capture_output=True, text=True)
+    env = dict(os.environ)
+    if write_to:
+        env["REF_WRITE_LH"] = write_to      # Graph::writeGraph on the graph as it stands at the end
+    out = subprocess.run([exe, lh] + ([juncs] if juncs else []), capture_output=True, text=True, env=env)
     if out.returncode != 0:
         return {"ok": False, "err": "reference exited %d" % out.returncode}
     return json.loads(out.stdout.strip().splitlines()[-1])

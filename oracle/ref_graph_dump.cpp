@@ -11,8 +11,11 @@
 // Graph::getAvgCoverage(), copy number 1) or raises the found junction's copy number to 2 -- the calls LGM.cpp:5133-5141
 // makes, in that order.  The loop around those calls is this driver's (LocalGenomicMap.cpp itself cannot be compiled
 // here), so what this pins is the reference's matching rule, duplicate handling, coverage value and junction order.
+// With REF_WRITE_LH=<path> in the environment it also calls Graph::writeGraph (Graph.cpp:239-266) at the end: the fixtures the
+// product's .lh writer is pinned with (tests/golden/written_*.lh).
 // LocalGenomicMap.cpp (the BFB stages) is NOT buildable here: it includes <coin/CbcModel.hpp> and
 // <coin/OsiClpSolverInterface.hpp>, which the image lacks.
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -57,6 +60,8 @@ int main(int argc, char** argv) {
             }
         }
     }
+    // REF_WRITE_LH=<path>: also run the reference's Graph::writeGraph (Graph.cpp:239-266) on the graph as it stands now
+    if (const char* w = getenv("REF_WRITE_LH")) g->writeGraph(w);
     std::cout.rdbuf(old);
 
     std::ostringstream o;

@@ -38,14 +38,17 @@ def main():
     with open(os.path.join(out_dir, "syn24.lh"), "w") as f:
         f.write(s.lh_text)
     for name, path in cases.items():
-        d = oracle_py.ref_graph_dump(path)
+        # (the same run also writes the graph back through the reference's Graph::writeGraph: written_<name>.lh pins the product's writer)
+        d = oracle_py.ref_graph_dump(path, write_to=os.path.join(out_dir, "written_%s.lh" % name))
         assert d and d["ok"], (name, d)
+        d["log"] = [l for l in d["log"] if l != "write seg"]
         with open(os.path.join(out_dir, "graph_%s.json" % name), "w") as f:
             json.dump(d, f, indent=0, sort_keys=True)
         print("wrote graph_%s.json: %d segs, %d juncs" % (name, len(d["segs"]), len(d["juncs"])))
     for name, (lh, juncs) in JUNCS_CASES.items():
-        d = oracle_py.ref_graph_dump(lh, juncs)
+        d = oracle_py.ref_graph_dump(lh, juncs, write_to=os.path.join(out_dir, "written_%s.lh" % name))
         assert d and d["ok"], (name, d)
+        d["log"] = [l for l in d["log"] if l != "write seg"]
         with open(os.path.join(out_dir, "graph_%s.json" % name), "w") as f:
             json.dump(d, f, indent=0, sort_keys=True)
         print("wrote graph_%s.json: %d segs, %d juncs" % (name, len(d["segs"]), len(d["juncs"])))
