@@ -207,3 +207,88 @@ def test_ilp_entries_written_on_the_device(hip_lib, oracle, workdir):
     gbps = 12.0 * d.nnz / (d.kernel_ms * 1e-3) / 1e9
     print("ambi_ilp_fill_kernel: %.3f ms for %d non-zeros = %.0f GB/s of 12-byte entries" % (d.kernel_ms, d.nnz, gbps))
     assert d.kernel_ms > 0
+
+
+def _check_two_segment_model(lib, oracle, workdir, device):
+    """BFB_ILP (LGM.cpp:4397-4752) written out BY HAND for a chromosome of two segments, product and oracle both checked
+    against it -- the ILP restatement has no reference-held vector (the reference's own build needs the COIN-OR headers).
+
+    start = 1, end = 2.  combinations (LGM.cpp:3254-3264): (1,1) (1,2) (2,2); variableIdx (localhap.cpp:117-133):
+    p:1,1 = 0, p:1,2 = 1, p:2,2 = 2, l:1,1 = 3, l:1,2 = 4, l:2,2 = 5; numElements 6, four epsilons 6..9 (index
+    numElements + row/2 at the time the row is made, :4440 / :4447 / :4486 / :4493), bias variable 10.
+    With c_i = segment CN, f_i = juncCN[i][1], b = bias, entries in the order the reference inserts them:
+
+      segment 1  (:4423-4451)  r0  p11 + p12 + 2 l11 + 2 l12 + e6 >= c1          r1  ... - e6 <= c1
+                 (:4453-4494)  loops with an end at 1: l11, l12 (coef += 1); patterns sharing start 1 with a longer one:
+                               (p12, p11) -> 0.5 each; sharing end 1: only p11 -> nothing.  Inserted by ascending index (:4478-4483)
+                               r2  .5 p11 + .5 p12 + l11 + l12 + e7 >= f1         r3  ... - e7 <= f1
+      segment 2                r4  p12 + p22 + 2 l12 + 2 l22 + e8 >= c2          r5  ... - e8 <= c2
+                               loops with an end at 2: l12, l22; patterns sharing end 2: (p12, p22) -> 0.5 each
+                               r6  .5 p12 + .5 p22 + l12 + l22 + e9 >= f2         r7  ... - e9 <= f2
+      bias       (:4497-4503)  r8  x10 = b
+      patterns   (:4540-4583)  p11: larger with the same start p12, none smaller        r9   p12 - p11 >= 0
+                               p12: none larger; smaller p11 (same start), p22 (same end) r10  0 <= p11 + p22 + p12 <= 2
+                               p22: larger with the same end p12                         r11  p12 - p22 >= 0
+      loops      (:4587-4613)  l11: j = 2 behind the end: p12, l12                      r12  p12 + l12 - l11 >= 0
+                               l12: nothing outside -> no row
+                               l22: j = 1 before the start: p12, l12                    r13  p12 + l12 - l22 >= 0
+                 (:4615-4645)  l12 only (l11, l22 have nothing inside): l11, l22, then l12 / p12
+                               r14  0 <= l11 + l22 + l12 <= 2        r15  0 <= l11 + l22 + p12 <= 2
+      patterns   (:4647-4681)  p12 only: j=1: l11 | p11; j=2: p22 | l22; then p12 in both
+                               r16  0 <= l11 + p22 + p12 <= 2        r17  0 <= p11 + l22 + p12 <= 2
+    Columns (:4714-4741): p in [0,1], l in [0, sum of ALL segment CNs], e in [0,inf), x10 = b; objective 0 / 1 / -1; the six
+    elements are integer (:4746-4748)."""
+    lh = os.path.join(workdir, "two.lh")
+    with open(lh, "w") as f:
+        f.write("SAMPLE two\nAVG_CHR_SEG_DP 30\nAVG_WHOLE_HOST_DP 30\nAVG_JUNC_DP 30\nPURITY 1\nAVG_TUMOR_PLOIDY 2\nPLOIDY 2m1\nVIRUS_START 3\n"
+                "SOURCE 1\nSINK 2\nSEG H:1:chr1:1:1000 90.0 3.0\nSEG H:2:chr1:1001:2000 150.0 5.0\n"
+                "JUNC H:1:+ H:2:+ 90.0 3.0 U B\nJUNC H:2:+ H:2:- 60.0 2.0 U B\nJUNC H:1:- H:1:+ 30.0 1.0 U B\n")
+    m = _model_from_engine(lib, lh, 0, "", False, lib, device=device)
+    # what the prepare stages hand to BFB_ILP for this file (pinned by their own hand-derived tests): no SV edits the CNs,
+    # both fold-backs are perfect (bias 1), fold-back CN 1 at segment 1 and 2 at segment 2
+    c1, c2, f1, f2, b = 3.0, 5.0, 1.0, 2.0, 1.0
+    inf = float("inf")
+    rows = [
+        ([(0, 1), (1, 1), (3, 2), (4, 2), (6, 1)], c1, inf), ([(0, 1), (1, 1), (3, 2), (4, 2), (6, -1)], -inf, c1),
+        ([(0, .5), (1, .5), (3, 1), (4, 1), (7, 1)], f1, inf), ([(0, .5), (1, .5), (3, 1), (4, 1), (7, -1)], -inf, f1),
+        ([(1, 1), (2, 1), (4, 2), (5, 2), (8, 1)], c2, inf), ([(1, 1), (2, 1), (4, 2), (5, 2), (8, -1)], -inf, c2),
+        ([(1, .5), (2, .5), (4, 1), (5, 1), (9, 1)], f2, inf), ([(1, .5), (2, .5), (4, 1), (5, 1), (9, -1)], -inf, f2),
+        ([(10, 1)], b, b),
+        ([(1, 1), (0, -1)], 0, inf), ([(0, 1), (2, 1), (1, 1)], 0, 2), ([(1, 1), (2, -1)], 0, inf),
+        ([(1, 1), (4, 1), (3, -1)], 0, inf), ([(1, 1), (4, 1), (5, -1)], 0, inf),
+        ([(3, 1), (5, 1), (4, 1)], 0, 2), ([(3, 1), (5, 1), (1, 1)], 0, 2),
+        ([(3, 1), (2, 1), (1, 1)], 0, 2), ([(0, 1), (5, 1), (1, 1)], 0, 2),
+    ]
+    col_lo = [0] * 10 + [b]
+    col_up = [1, 1, 1, 8, 8, 8, inf, inf, inf, inf, b]
+    obj = [0] * 6 + [1] * 4 + [-1]
+
+    def clip(v):     # (the arrays carry the solver's "infinity", 1e30 or larger, for unbounded sides)
+        return inf if v >= 1e29 else (-inf if v <= -1e29 else v)
+
+    def check(n_cols, n_int, row_ptr, col, val, row_lo, row_up, clo, cup, ob):
+        assert (n_cols, n_int, len(row_ptr) - 1) == (11, 6, 18)
+        for r, (ent, lo, up) in enumerate(rows):
+            got = list(zip(col[row_ptr[r]:row_ptr[r + 1]], val[row_ptr[r]:row_ptr[r + 1]]))
+            assert sorted(got) == sorted((c, float(v)) for c, v in ent), (r, got)      # the set of entries ...
+            assert [c for c, _ in got] == [c for c, _ in ent], (r, got)                # ... and the reference's insertion order
+            assert (clip(row_lo[r]), clip(row_up[r])) == (lo, up), r
+        assert [clip(v) for v in clo] == col_lo and [clip(v) for v in cup] == col_up and list(ob) == obj
+
+    a = m.arrays()
+    check(m.n_cols, m.n_int, a["row_ptr"].tolist(), a["col"].tolist(), a["val"].tolist(), a["row_lo"].tolist(), a["row_up"].tolist(),
+          a["col_lo"].tolist(), a["col_up"].tolist(), a["obj"].tolist())
+    for literal in (False, True):
+        o = oracle.ilp(lh, 0, literal=literal)
+        assert o["ok"]
+        check(o["n_cols"], o["n_int"], o["row_ptr"], o["col"], o["val"], o["row_lo"], o["row_up"], o["col_lo"], o["col_up"], o["obj"])
+
+
+def test_two_segment_model_hand_derived(hostsim_lib, oracle, workdir):
+    _check_two_segment_model(hostsim_lib, oracle, workdir, False)
+
+
+@pytest.mark.gpu
+def test_two_segment_model_hand_derived_on_the_gpu(hip_lib, oracle, workdir):
+    _check_two_segment_model(hip_lib, oracle, workdir, False)     # prepare stages on the GPU, host generator
+    _check_two_segment_model(hip_lib, oracle, workdir, True)      # entries written by ambi_ilp_fill_kernel
