@@ -45,7 +45,7 @@ extern __shared__ __align__(16) uint8_t ambi_lds[];
 
 constexpr uint32_t kGuardWord = 0xA5B1C3D7u;
 // results of one unit as the express kernel mirrors them into the pinned mailbox (MailLayout); whole workgroup
-__device__ inline void mail_unit(const BatchArgs& A, int u) {
+__device__ inline void mail_unit(const BatchArgs& A, int u, bool path_there = false) {   // path_there: the finish stage wrote the path into the slot already
     const UnitIn& U = A.units[u];
     const UnitOut* h = unit_out(A.results, u);
     const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
@@ -56,7 +56,7 @@ __device__ inline void mail_unit(const BatchArgs& A, int u) {
         for (int64_t i = threadIdx.x; i < (bytes + 7) / 8; i += blockDim.x) reinterpret_cast<uint64_t*>(dst)[i] = reinterpret_cast<const uint64_t*>(src)[i];
     };
     copy8(slot, reinterpret_cast<const uint8_t*>(h), (int64_t)sizeof(UnitOut));
-    copy8(slot + M.path, res + L.path, (int64_t)sizeof(rcell_t) * h->path_len);
+    if (!path_there) copy8(slot + M.path, res + L.path, (int64_t)sizeof(rcell_t) * h->path_len);
     if (h->path_ind_stored) copy8(slot + M.path_ind, res + L.path_ind, (int64_t)sizeof(rcell_t) * h->path_indel_len);
     copy8(slot + M.out_junc, res + L.out_junc, (int64_t)sizeof(OutJunc) * h->n_out_junc);
     __threadfence_system();
@@ -101,9 +101,10 @@ __global__ __launch_bounds__(1024) void ambi_express_kernel(BatchArgs A) {
     WaveGroup gw;
     if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.n_pending = 0;
     const int wave = threadIdx.x >> 6, u = A.unit_base + (int)blockIdx.x;
-    stage_express(gw, gb, wave < 2 ? wave : 2, A, u, ambi_lds);
+    const bool path_there = stage_express(gw, gb, wave < 2 ? wave : 2, A, u, ambi_lds);
     __syncthreads();
-    if (A.mail && unit_out(A.results, u)->reserved) { mail_unit(A, u); __syncthreads(); }   // header, final path(s), output junctions -> pinned host memory
+    if (A.mail && unit_out(A.results, u)->reserved) { mail_unit(A, u, path_there); __syncthreads(); }   // header, final path(s), output junctions -> pinned host memory
+    AMBI_MARK(A, gb, u, 25);
     if (threadIdx.x == 0 && A.express_left) {
         if (!unit_out(A.results, u)->reserved) *A.express_left = 1;
         __threadfence_system();

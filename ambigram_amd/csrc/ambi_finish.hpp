@@ -505,7 +505,7 @@ AMBI_HD int run_offsets(const G& g, const cell_t* bkp, int L, int32_t* offs) {
 // (initialised by the caller) -- run-major, one sub-group (wavefront) per run as in expand_bkp
 template <class G>
 AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* offs, int16_t* gpath, int seg_base, int n,
-                         int32_t* first, int32_t* last) {
+                         int32_t* first, int32_t* last, int16_t* mirror = nullptr) {
     const int lanes = g.size() < 64 ? g.size() : 64;
     const int sub = g.tid() / lanes, nsub = g.size() / lanes, lane = g.tid() - sub * lanes;
     for (int j = sub; j < np; j += nsub) {
@@ -513,6 +513,7 @@ AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* o
         for (int k = lane; k < len; k += lanes) {
             const int v = a + k;
             gpath[o0 + k] = (int16_t)v;   // local id; readers add the base
+            if (mirror) mirror[o0 + k] = (int16_t)v;   // the caller's copy in pinned host memory (express path), in the same pass
             if (first) { atomic_min_i32(&first[v + n], o0 + k); atomic_max_i32(&last[v + n], o0 + k); }
         }
     }

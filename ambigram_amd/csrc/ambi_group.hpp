@@ -36,6 +36,7 @@ AMBI_HD uint32_t lane_get_u32(uint32_t v, int i) {
 }
 
 struct HostGroup {
+    static constexpr bool kIsBlock = false;
     static constexpr bool kLaneArrays = false;   // no cross-lane register arrays (ambi_sort.hpp: LaneWords)
     AMBI_HD int tid() const { return 0; }
     AMBI_HD int size() const { return 1; }
@@ -66,6 +67,7 @@ struct HostGroup {
 
 // One wavefront (64 lanes on gfx950). Lanes run in lockstep; sync() only has to order LDS traffic.
 struct WaveGroup {
+    static constexpr bool kIsBlock = false;
     static constexpr bool kLaneArrays = true;
     __device__ inline int tid() const { return (int)(threadIdx.x & 63u); }
     __device__ inline int size() const { return 64; }
@@ -142,6 +144,7 @@ struct WaveGroup {
 
 // One workgroup. `scratch` points at >= 40 ints of LDS reserved for the reductions.
 struct BlockGroup {
+    static constexpr bool kIsBlock = true;       // several wavefronts: group operations cost workgroup barriers
     static constexpr bool kLaneArrays = false;
     int* scratch;
     __device__ inline explicit BlockGroup(int* s) : scratch(s) {}

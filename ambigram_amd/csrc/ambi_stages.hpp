@@ -999,8 +999,9 @@ AMBI_HD FinishLeanWork carve_finish_lean(uint8_t* base, int n, int m, int bkp_ca
     return W;
 }
 
+// mirror: a second place for the cells of the final path (the express stage's slot of the pinned result mailbox)
 template <class G>
-AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* work) {
+AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* work, rcell_t* mirror = nullptr) {
     UnitOut* out = unit_out(A.results, u);
     const UnitIn U = A.units[u];
     const int n = U.n_seg, m = U.n_junc;
@@ -1043,7 +1044,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { W.first[i] = 0x7fffffff; W.last[i] = -1; }
         g.sync();
     }
-    expand_runs(g, W.bkp, np, W.offs, gpath, base, n, nsv > 0 ? W.first : nullptr, W.last);
+    expand_runs(g, W.bkp, np, W.offs, gpath, base, n, nsv > 0 ? W.first : nullptr, W.last, mirror);
     AMBI_MARK(A, g, u, 18);
     int printed = 0;
     if (nsv > 0) {
@@ -1056,7 +1057,17 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         }
     }
     AMBI_MARK(A, g, u, 19);
-    const int nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+    int nout;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (G::kIsBlock && np <= 256) {
+        // few candidate steps: ONE wavefront goes through the dozen dependent phases of the synthesis without a workgroup
+        // barrier between them
+        int v = 0;
+        if (g.tid() < 64) { WaveGroup w; v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base); }
+        nout = g.bcast_i32(v, 0);
+    } else
+#endif
+    nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
     AMBI_MARK(A, g, u, 20);
     if (g.tid() == 0) {
         out->path_len = P; out->path_indel_len = P; out->indel_printed = printed; out->path_ind_stored = 0;
@@ -1141,7 +1152,7 @@ AMBI_HD bool first_order(const G& g, const Dag& D, uint8_t* ord) {
 }
 
 template <class GW, class GB>
-AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs& A, int u, uint8_t* work) {
+AMBI_HD bool stage_express(const GW& gw, const GB& gb, int role, const BatchArgs& A, int u, uint8_t* work) {
     const UnitIn U = A.units[u];
     const int n = U.n_seg, m = U.n_junc, K = U.n_elem;
     ExpressWork W = carve_express(work, n, m, K, U.bkp_cap);
@@ -1195,20 +1206,23 @@ AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
     gb.sync();
     // finish: the lean stage (runs of the breakpoint path; any path length), the full stage when the lean one hands the
     // unit over or would leave it to the direct full-stage launch
+    bool mirrored = false;   // the final path went to the mailbox slot while it was written (uniform over the workgroup)
     auto finish = [&]() {
         bool need_full = U.direct_full && A.direct_full_on;
         if (!need_full) {
-            stage_finish_lean(gb, A, u, W.finish);
+            rcell_t* mirror = A.mail ? reinterpret_cast<rcell_t*>(A.mail + A.mail_off[u] + mail_layout(U.path_cap, U.out_cap).path) : nullptr;
+            stage_finish_lean(gb, A, u, W.finish, mirror);
             gb.sync();
             need_full = out->status == ST_REFINISH;
+            mirrored = mirror != nullptr && !need_full && out->status == ST_OK;
         }
         if (need_full) stage_finish(gb, A, u, W.finish);
         gb.sync();
         if (gb.tid() == 0) out->reserved = 1;   // done: the scan / finish kernels behind leave the unit alone
         gb.sync();
     };
-    if (status == ST_SHORTCUT || status == ST_INFEASIBLE) { finish(); return; }   // the reference path: the finish stage writes it
-    if (status != ST_OK) return;
+    if (status == ST_SHORTCUT || status == ST_INFEASIBLE) { finish(); return false; }   // (that branch writes the path itself: ordinary copy)   // the reference path: the finish stage writes it
+    if (status != ST_OK) return false;
     const int placed = fl[3], L = fl[4];
     if (role == 1 || role < 0) {
         int v = placed < 0 ? placed : eval_finish(gw, placed, K, W.F.bkp, L, InvMap{W.F.inv_src, W.F.inv_tgt});
@@ -1217,7 +1231,7 @@ AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
     }
     gb.sync();
     AMBI_MARK(A, gb, u, 11);
-    if (fl[5] != 1) return;   // order 0 does not assemble (or ends in an error): the ordinary scan takes the unit, from order 0
+    if (fl[5] != 1) return false;   // order 0 does not assemble (or ends in an error): the ordinary scan takes the unit, from order 0
     {
         const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
         cell_t* dst = reinterpret_cast<cell_t*>(A.results + U.res_off + Lay.bkp);
@@ -1227,6 +1241,7 @@ AMBI_HD void stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
     gb.sync();
     finish();
     AMBI_MARK(A, gb, u, 12);
+    return mirrored;
 }
 
 }  // namespace ambi
