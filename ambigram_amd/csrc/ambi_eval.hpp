@@ -159,11 +159,19 @@ AMBI_HD bool imperfect_fbi(const G& g, cell_t* bkp, int L, const InvMap& inv) {
     return true;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline int imperfect_fbi_regs(cell_t* bkp, int L, const InvMap& inv);   // (below, with the register form of the placement)
+#endif
 // Second part of the evaluation: imperfectFBI (LGM.cpp:3656, always before the validity test) and the verdict.
 // `placed` = what eval_place returned (>= 0).
 template <class G>
-AMBI_HD int eval_finish(const G& g, int placed, int K, cell_t* bkp, int L, const InvMap& inv) {
-    const bool ok = imperfect_fbi(g, bkp, L, inv);
+AMBI_HD int eval_finish(const G& g, int placed, int K, cell_t* bkp, int L, const InvMap& inv, bool try_regs = false) {
+    bool ok;
+    int fast = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (G::kLaneArrays) { if (try_regs) fast = imperfect_fbi_regs(bkp, L, inv); }   // cells in registers (up to 256 of them; stage_express)
+#endif
+    ok = fast >= 0 ? fast != 0 : imperfect_fbi(g, bkp, L, inv);
     // imperfectFBI reading past the end of the breakpoint vector (LGM.cpp:3436-3442 with pos+1 == end) is undefined in the
     // reference.  On an order that did not place all its elements the outcome is "invalid" whatever that read returns
     // (validity is i == K, fixed before imperfectFBI runs, and the breakpoints of an invalid order are thrown away,
@@ -378,6 +386,233 @@ __device__ inline int eval_place_regs_n(const DAG& D, const uint8_t* ord, bool f
     g.sync();
     *L_out = L;
     return i;
+}
+// imperfectFBI (LGM.cpp:3431-3512) with the breakpoint cells in registers (cell i in lane i mod 64 of register i / 64).
+// The reference walks pos over the path; a step either rewrites the two cells at pos ("plain") or a whole palindrome
+// [pos, r] from its middle outwards.  What a step SEES ahead of pos is untouched by the steps before it (a step writes
+// cells pos-1 .. r only), so the sequence of steps follows from the ORIGINAL cells alone, and the iterations p1 = mid - 2t
+// of a palindrome read nothing but their own original cell bkp[p1] -- except the last one, p1 = pos - 1, whose cell the
+// previous step may have rewritten (plain steps read bkp[pos-1] in the same way).  A step of a serial walk costs a lone
+// wavefront 600-1000 cycles (a chain of vector -> scalar hand-overs), so everything that can be is done for all cells at once:
+//   pass 0  every cell j as if the walk stood there: r(j) = first q >= j + 3 with cell[q] == -cell[j] (one v_readlane per q,
+//           compared by all lanes), plain(j), next(j), mid(j);
+//   pass 1  the walk itself is then one v_readlane per step (next(pos)); it gives every cell of a palindrome its (pos, mid);
+//   pass 2  ALL palindromes at once, every lane for the cell it holds: cell j takes w0(j) if j is a p1 of its palindrome,
+//           w1(j-1) if j-1 is, -w0(2 mid + 1 - j) as the mirrored p2, -w1(2 mid - j) as p2 - 1 (disjoint by parity, as the
+//           reference's iterations never share a cell): one shift by a lane and two lane reversals per register;
+//   pass 3  the walk again, in order, for what depends on the step before: the plain rewrites and the iteration
+//           p1 = pos - 1 of every palindrome (cells pos-1, pos and p2-1; no other iteration of that palindrome writes them).
+// Cells are read from / written back to `bkp` (group memory) once.  Returns false where imperfect_fbi does.
+template <int NR>
+__device__ inline bool imperfect_fbi_regs_n(cell_t* bkp, int L, const InvMap& inv) {
+    const int lane = (int)(threadIdx.x & 63u);
+    RegCells<NR> R, O;          // current / original cells
+    int MID[NR], POS[NR];       // the palindrome a cell lies in (-1: none)
+#pragma unroll
+    for (int r = 0; r < NR; r++) { R.c[r] = 64 * r + lane < L ? (int)bkp[64 * r + lane] : 0; O.c[r] = R.c[r]; MID[r] = -1; POS[r] = -1; }
+    // pass 0.  Cells behind L hold 0 and no cell of the path is 0: they match nothing.
+    RegCells<NR> NXP;           // next(j) * 2 + plain(j)
+    {
+        int RH[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) RH[r] = L;
+#pragma unroll
+        for (int t = NR - 1; t >= 0; t--) {
+#pragma unroll
+            for (int ql = 63; ql >= 0; ql--) {      // descending: the smallest q is assigned last.  Fully unrolled: the lane of every
+                const int q = 64 * t + ql;          // v_readlane is a constant and the iterations do not wait for one another
+                if (q < 3) continue;
+                const int want_of = -__builtin_amdgcn_readlane(O.c[t], ql);     // cell j matches if cell[j] == -cell[q]  (0 behind L: no match)
+#pragma unroll
+                for (int r = 0; r < NR; r++) if (64 * r + 3 <= q) RH[r] = (64 * r + lane + 3 <= q && O.c[r] == want_of) ? q : RH[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = 64 * r + lane, idx = RH[r] - 1;      // cell l = r - 1 and cell j + 1
+            int ol = 0, o1 = 0;
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const int a = __shfl(O.c[t], idx & 63, 64), b = __shfl(O.c[t], (lane + 1) & 63, 64);
+                ol = (idx >> 6) == t ? a : ol;
+                o1 = (lane == 63 ? r + 1 : r) == t ? b : o1;
+            }
+            const bool plain = RH[r] == L || ol != -o1;
+            NXP.c[r] = plain ? 2 * (j + 2) + 1 : 2 * (RH[r] + 1);
+        }
+    }
+    // pass 1
+    bool any_plain = false;
+    for (int pos = 0; pos < L;) {
+        if (pos + 1 >= L) return false;
+        const int np = NXP.get_u(pos), nxt = np >> 1;
+        if (!(np & 1)) {
+            const int rh = nxt - 1, mid = pos + ((rh - 1 - pos) / 2);
+#pragma unroll
+            for (int r = 0; r < NR; r++) { const int j = 64 * r + lane; const bool in = j >= pos && j <= rh; MID[r] = in ? mid : MID[r]; POS[r] = in ? pos : POS[r]; }
+        } else any_plain = true;
+        pos = nxt;
+    }
+    // pass 2
+    {
+        int W0[NR], W1[NR];     // what iteration "p1 = my cell" writes (0: nothing)
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = 64 * r + lane, mid = MID[r], pos = POS[r];
+            W0[r] = 0; W1[r] = 0;
+            if (mid >= 0 && j >= (pos > 1 ? pos : 1) && j <= mid && ((mid - j) & 1) == 0) {
+                const int v = O.c[r], id = iabs(v);
+                const int s = inv.src[id];
+                if (s != 0) {
+                    const int tt = inv.tgt[id];
+                    if (j + 1 >= L) bad = true;
+                    if (v > 0) { if (s < tt) { W0[r] = s; W1[r] = -tt; } else { W0[r] = tt; W1[r] = -s; } }
+                    else { if (s < tt) { W0[r] = -tt; W1[r] = s; } else { W0[r] = -s; W1[r] = tt; } }
+                    const int p2 = 2 * mid + 1 - j;
+                    if (p2 != j + 1 && p2 >= L) bad = true;
+                }
+            }
+        }
+        if (__ballot(bad)) return false;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = 64 * r + lane, mid = MID[r], pos = POS[r];
+            const int lo = pos > 1 ? pos : 1;
+            const int i1 = 2 * mid + 1 - j, i0 = 2 * mid - j;     // the p1 whose p2 / p2 - 1 this cell is
+            int below = 0, rev0 = 0, rev1 = 0;
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const int b = __shfl(W1[t], (lane + 63) & 63, 64);
+                below = (lane == 0 ? r - 1 : r) == t ? b : below;
+                const int x0 = __shfl(W0[t], i1 & 63, 64), x1 = __shfl(W1[t], i0 & 63, 64);
+                rev0 = (i1 >> 6) == t ? x0 : rev0;
+                rev1 = (i0 >> 6) == t ? x1 : rev1;
+            }
+            int c = R.c[r];
+            if (W0[r] != 0) c = W0[r];                                                                  // a p1
+            if (mid >= 0 && j >= 1 && j - 1 >= lo && j - 1 <= mid && below != 0) c = below;             // p1 + 1
+            if (mid >= 0 && i1 >= lo && i1 < mid && rev0 != 0) c = -rev0;                               // p2 (not of t = 0)
+            if (mid >= 0 && i0 >= lo && i0 < mid && rev1 != 0) c = -rev1;                               // p2 - 1 (not of t = 0)
+            R.c[r] = c;
+        }
+    }
+    // pass 3, all at once when no step feeds on what the step before it writes here: no plain step, and wherever the last
+    // iteration of a palindrome writes the cell in front of the NEXT palindrome (its p2 - 1 is that palindrome's r) and the next
+    // one reads it, the value written is the value the cell holds already (always so with perfect fold-backs, whose rewrites
+    // change nothing).  The cell in front of palindrome (pos, mid) is pos - 1: its lane computes the iteration (w0 into its
+    // own cell), cell pos takes w1 from the lane below, cell 2 mid - pos + 1 takes -w1; a later step's write wins.
+    bool done3 = false;
+    if (!any_plain) {
+        int W0[NR], W1[NR];
+        bool reads[NR];          // my cell is the p1 of the palindrome that starts behind it
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = 64 * r + lane;
+            int mid_n = -1, pos_n = -1;          // the palindrome of cell j + 1
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const int a = __shfl(MID[t], (lane + 1) & 63, 64), b = __shfl(POS[t], (lane + 1) & 63, 64);
+                const bool me = (lane == 63 ? r + 1 : r) == t;
+                mid_n = me ? a : mid_n; pos_n = me ? b : pos_n;
+            }
+            W0[r] = 0; W1[r] = 0;
+            reads[r] = j >= 1 && j + 1 < L && pos_n == j + 1 && ((mid_n - j) & 1) == 0;
+            if (reads[r]) {
+                const int v = R.c[r], id = iabs(v);
+                const int s = inv.src[id];
+                if (s != 0) {
+                    const int tt = inv.tgt[id];
+                    if (v > 0) { if (s < tt) { W0[r] = s; W1[r] = -tt; } else { W0[r] = tt; W1[r] = -s; } }
+                    else { if (s < tt) { W0[r] = -tt; W1[r] = s; } else { W0[r] = -s; W1[r] = tt; } }
+                }
+            }
+        }
+        bool conflict = false;
+        int below[NR], far[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int pos = POS[r];
+            below[r] = 0; far[r] = 0;
+#pragma unroll
+            for (int t = 0; t < NR; t++) {       // (every lane takes part in the exchanges)
+                const int b = __shfl(W1[t], (lane + 63) & 63, 64), a = __shfl(W1[t], (pos - 1) & 63, 64);
+                below[r] = (lane == 0 ? r - 1 : r) == t ? b : below[r];
+                far[r] = ((pos - 1) >> 6) == t ? a : far[r];
+            }
+            const int x = 64 * r + lane, mid = MID[r];
+            const bool third = mid >= 0 && pos >= 2 && x == 2 * mid - pos + 1 && far[r] != 0;   // my cell is the p2 - 1 of my palindrome's last iteration
+            if (!third) far[r] = 0;
+            if (third && reads[r] && -far[r] != R.c[r]) conflict = true;     // ... and the next palindrome reads it: it must find what it assumed
+        }
+        if (!__ballot(conflict)) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int x = 64 * r + lane;
+                int c = R.c[r];
+                if (far[r] != 0) c = -far[r];                                                   // p2 - 1 of the palindrome I lie in
+                if (MID[r] >= 0 && POS[r] == x && x >= 2 && below[r] != 0) c = below[r];        // p1 + 1 = pos
+                if (W0[r] != 0) c = W0[r];                                                      // p1 = pos - 1 of the palindrome behind me (a later step)
+                R.c[r] = c;
+            }
+            done3 = true;
+        }
+    }
+    // pass 3, step by step
+    for (int pos = 0; pos < L && !done3;) {
+        const int np = NXP.get_u(pos), nxt = np >> 1;
+        if (np & 1) {
+            const int c0 = O.get_u(pos), c1 = O.get_u(pos + 1);
+            int n0 = c0, n1 = c1;
+            {
+                const int id = iabs(c1);
+                const int s = inv.src[id];
+                if (s != 0) {
+                    const int t = inv.tgt[id];
+                    n1 = c1 > 0 ? ((s < t) ? s : t) : ((s < t) ? -t : -s);
+                }
+            }
+            if (pos > 0) {
+                const int id = iabs(c0);
+                const int s = inv.src[id];
+                if (s != 0 && iabs(R.get_u(pos - 1)) == id) {
+                    const int other = (s == id) ? inv.tgt[id] : s;
+                    n0 = c0 > 0 ? other : -other;
+                }
+            }
+            if (n0 > 0 && iabs(n0) > iabs(n1)) n1 = n0;
+            if (n0 < 0 && iabs(n0) < iabs(n1)) n1 = n0;
+            R.set_u(pos, n0, lane); R.set_u(pos + 1, n1, lane);
+        } else {
+            const int rh = nxt - 1, mid = pos + ((rh - 1 - pos) / 2);
+            const int p1 = pos - 1;
+            if (p1 >= 1 && ((mid - p1) & 1) == 0) {     // the last iteration of this palindrome: the cell in front of it
+                const int v = R.get_u(p1), id = iabs(v);
+                const int s = inv.src[id];
+                if (s != 0) {
+                    const int tt = inv.tgt[id];
+                    int w0, w1;
+                    if (v > 0) { if (s < tt) { w0 = s; w1 = -tt; } else { w0 = tt; w1 = -s; } }
+                    else { if (s < tt) { w0 = -tt; w1 = s; } else { w0 = -s; w1 = tt; } }
+                    R.set_u(p1, w0, lane); R.set_u(p1 + 1, w1, lane);
+                    const int p2 = 2 * mid + 1 - p1;
+                    if (p2 != p1 + 1) R.set_u(p2 - 1, -w1, lane);
+                }
+            }
+        }
+        pos = nxt;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) if (64 * r + lane < L) bkp[64 * r + lane] = (cell_t)R.c[r];
+    WaveGroup g;
+    g.sync();
+    return true;
+}
+// -1: path too long for the register form
+__device__ inline int imperfect_fbi_regs(cell_t* bkp, int L, const InvMap& inv) {
+    if (L <= 64) return imperfect_fbi_regs_n<1>(bkp, L, inv) ? 1 : 0;
+    if (L <= 128) return imperfect_fbi_regs_n<2>(bkp, L, inv) ? 1 : 0;
+    return -1;   // (pass 0 costs L x (2 + 4 NR) instructions: beyond two registers the serial walk in group memory is no slower)
 }
 template <class DAG>
 __device__ inline int eval_place_regs(const DAG& D, const uint8_t* ord, bool forward, cell_t* bkp, int cap, int* L_out) {

@@ -1196,6 +1196,7 @@ AMBI_HD bool stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
     const int status = prep_status(U, no_fbi, dag_status);
     const bool have_target = !(no_fbi && !U.has_components) && !U.infeasible && dag_status != ST_ERR_NO_ELEMENTS;
     prep_copy_out(gb, A, u, U, W.P, W.target, have_target, status);
+    AMBI_MARK(A, gb, u, 2);
     // the fold-back map in the form the evaluation reads (as load_first_work would fetch it from the blob)
     for (int i = gb.tid(); i <= n; i += gb.size()) {
         const int ji = W.P.inv_junc[i];
@@ -1224,8 +1225,9 @@ AMBI_HD bool stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
     if (status == ST_SHORTCUT || status == ST_INFEASIBLE) { finish(); return false; }   // (that branch writes the path itself: ordinary copy)   // the reference path: the finish stage writes it
     if (status != ST_OK) return false;
     const int placed = fl[3], L = fl[4];
+    AMBI_MARK(A, gb, u, 3);
     if (role == 1 || role < 0) {
-        int v = placed < 0 ? placed : eval_finish(gw, placed, K, W.F.bkp, L, InvMap{W.F.inv_src, W.F.inv_tgt});
+        int v = placed < 0 ? placed : eval_finish(gw, placed, K, W.F.bkp, L, InvMap{W.F.inv_src, W.F.inv_tgt}, true);
         if (A.inject_valid && A.inject_off[2 * (int64_t)u] >= 0) v = 0;   // injected verdicts (diagnostics) are indexed with R: the scan kernel applies them
         if (gw.tid() == 0) fl[5] = v;
     }
