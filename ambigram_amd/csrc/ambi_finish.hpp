@@ -522,14 +522,19 @@ AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* o
 
 // indelBFB when nothing chains and nothing edits: 1 = the SVs are all look-ups without effect (the reference prints its
 // caption and the unchanged path), 0 = the full stage has to take this unit.  nsv > 0, tables filled.
-template <class G>
-AMBI_HD int indel_lookups_only(const G& g, int n, const JuncEnds* ends, int nsv, const RunPath& path, int P, const IndelScratch& S) {
+// (the loop of one thread: SVs tid, tid + size, ..; 1 = one of them chains or edits)
+AMBI_HD int indel_lookups_thread(int tid, int size, int n, const JuncEnds* ends, int nsv, const RunPath& path, int P, const IndelScratch& S) {
     int stop = 0;
-    for (int i = g.tid(); i < nsv && !stop; i += g.size()) {
+    for (int i = tid; i < nsv && !stop; i += size) {
         if (S.has_ext[i]) { stop = 1; break; }
         const JuncEnds J = ends[S.sv[i]];
         if (eval_single(J.s, J.t, n, path, P, S.first, S.last).kind != 0) stop = 1;
     }
+    return stop;
+}
+template <class G>
+AMBI_HD int indel_lookups_only(const G& g, int n, const JuncEnds* ends, int nsv, const RunPath& path, int P, const IndelScratch& S) {
+    const int stop = indel_lookups_thread(g.tid(), g.size(), n, ends, nsv, path, P, S);
     return g.any(stop != 0) ? 0 : 1;
 }
 

@@ -999,9 +999,11 @@ AMBI_HD FinishLeanWork carve_finish_lean(uint8_t* base, int n, int m, int bkp_ca
     return W;
 }
 
-// mirror: a second place for the cells of the final path (the express stage's slot of the pinned result mailbox)
+// mirror: a second place for the cells of the final path (the express stage's slot of the pinned result mailbox).
+// pre_nsv >= 0: the junction ends are in the work area and indel_collect has run on them already (the express stage does that
+// on its junction-side wavefront while the DAG side is still busy): its result.
 template <class G>
-AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* work, rcell_t* mirror = nullptr) {
+AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* work, rcell_t* mirror = nullptr, int pre_nsv = -1) {
     UnitOut* out = unit_out(A.results, u);
     const UnitIn U = A.units[u];
     const int n = U.n_seg, m = U.n_junc;
@@ -1030,7 +1032,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     const int L = out->bkp_len, np = L / 2;
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
-    {
+    if (pre_nsv < 0) {
         const JuncEnds* ge = A.junc_ends + U.junc_off;   // 4 bytes per junction instead of the 24-byte record
         for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = ge[j];
     }
@@ -1039,35 +1041,40 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     const int P = run_offsets(g, W.bkp, L, W.offs);
     if (P > U.path_cap) { if (g.tid() == 0) out->status = ST_ERR_PATH_CAPACITY; g.sync(); return; }
     IndelScratch S{W.sv, W.taken, W.has_ext, nullptr, W.first, W.last};
-    const int nsv = indel_collect(g, n, W.ends, m, S);
+    const int nsv = pre_nsv >= 0 ? pre_nsv : indel_collect(g, n, W.ends, m, S);
     if (nsv > 0) {
         for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { W.first[i] = 0x7fffffff; W.last[i] = -1; }
         g.sync();
     }
     expand_runs(g, W.bkp, np, W.offs, gpath, base, n, nsv > 0 ? W.first : nullptr, W.last, mirror);
     AMBI_MARK(A, g, u, 18);
-    int printed = 0;
-    if (nsv > 0) {
-        const RunPath RP{W.bkp, W.offs, np};
-        printed = indel_lookups_only(g, n, W.ends, nsv, RP, P, S);
-        if (!printed) {   // chaining or editing SVs: the full stage redoes this unit
-            if (g.tid() == 0) { out->status = ST_REFINISH; if (A.refin_list) A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }   // (no list: the caller looks at the status itself)
-            g.sync();
-            return;
-        }
-    }
-    AMBI_MARK(A, g, u, 19);
-    int nout;
+    auto refinish = [&]() {   // chaining or editing SVs: the full stage redoes this unit
+        if (g.tid() == 0) { out->status = ST_REFINISH; if (A.refin_list) A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }   // (no list: the caller looks at the status itself)
+        g.sync();
+    };
+    int printed = 0, nout;
+    const RunPath RP{W.bkp, W.offs, np};
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (G::kIsBlock && np <= 256) {
-        // few candidate steps: ONE wavefront goes through the dozen dependent phases of the synthesis without a workgroup
-        // barrier between them
-        int v = 0;
+    if (G::kIsBlock && np <= 256 && g.size() >= 128) {
+        // few breakpoint pairs: the output-junction synthesis is a chain of short dependent phases -- ONE wavefront goes through
+        // it without a workgroup barrier, while the other wavefronts do the SV look-ups, which are independent of it (if the
+        // look-ups hand the unit to the full stage, that stage writes the output junctions again)
+        int v = 0, stop = 0;
         if (g.tid() < 64) { WaveGroup w; v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base); }
+        else if (nsv > 0) stop = indel_lookups_thread(g.tid() - 64, g.size() - 64, n, W.ends, nsv, RP, P, S);
         nout = g.bcast_i32(v, 0);
+        if (nsv > 0) { printed = g.any(stop != 0) ? 0 : 1; if (!printed) { refinish(); return; } }
+        AMBI_MARK(A, g, u, 19);
     } else
 #endif
-    nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+    {
+        if (nsv > 0) {
+            printed = indel_lookups_only(g, n, W.ends, nsv, RP, P, S);
+            if (!printed) { refinish(); return; }
+        }
+        AMBI_MARK(A, g, u, 19);
+        nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+    }
     AMBI_MARK(A, g, u, 20);
     if (g.tid() == 0) {
         out->path_len = P; out->path_indel_len = P; out->indel_printed = printed; out->path_ind_stored = 0;
@@ -1165,6 +1172,18 @@ AMBI_HD bool stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
         int bias = 1; bool no_fbi = false; double inv_sum = 0;
         prep_junctions(gw, A, u, U, W.P, &bias, &no_fbi, &inv_sum);
         if (gw.tid() == 0) { fl[0] = bias; fl[1] = no_fbi ? 1 : 0; *inv_sum_slot = inv_sum; }
+        // front part of indelBFB (needs the junction ends only) into the finish stage's work area, which nothing uses yet:
+        // this wavefront is done long before the DAG side
+        int nsv = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (role == 0) {
+            FinishLeanWork FL = carve_finish_lean(W.finish, n, m, U.bkp_cap);
+            for (int j = gw.tid(); j < m; j += gw.size()) FL.ends[j] = W.P.ends[j];
+            gw.sync();
+            nsv = indel_collect(gw, n, FL.ends, m, IndelScratch{FL.sv, FL.taken, FL.has_ext, nullptr, FL.first, FL.last});
+        }
+#endif
+        if (gw.tid() == 0) fl[8] = nsv;
         AMBI_MARK(A, gw, u, 6);
     }
     if (role == 1 || role < 0) {
@@ -1212,7 +1231,7 @@ AMBI_HD bool stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
         bool need_full = U.direct_full && A.direct_full_on;
         if (!need_full) {
             rcell_t* mirror = A.mail ? reinterpret_cast<rcell_t*>(A.mail + A.mail_off[u] + mail_layout(U.path_cap, U.out_cap).path) : nullptr;
-            stage_finish_lean(gb, A, u, W.finish, mirror);
+            stage_finish_lean(gb, A, u, W.finish, mirror, fl[8]);
             gb.sync();
             need_full = out->status == ST_REFINISH;
             mirrored = mirror != nullptr && !need_full && out->status == ST_OK;
