@@ -63,6 +63,11 @@ struct IndelScratch {
 struct LdsPath {
     const cell_t* p;
     AMBI_HD int at(int q) const { return p[q]; }
+    // first q in [from, hi] with at(q) == val, -1 if none
+    AMBI_HD int scan_for(int from, int hi, int val) const {
+        for (int q = from; q <= hi; q++) if (p[q] == val) return q;
+        return -1;
+    }
 };
 struct RunPath {
     const cell_t* bkp;      // [2*np]
@@ -72,6 +77,21 @@ struct RunPath {
         int lo = 0, hi = np;        // last run whose offset is <= q (empty runs share their offset with the next one)
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
         return (int)bkp[2 * lo] + (q - offs[lo]);
+    }
+    // first q in [from, hi] with at(q) == val, -1 if none: ONE bisection for the run of `from`, then run by run (inside a run
+    // the values count up by one, so the run holds val at most once, at a position that follows from its first value)
+    AMBI_HD int scan_for(int from, int hi, int val) const {
+        if (from > hi) return -1;
+        int lo = 0, up = np;
+        while (up - lo > 1) { const int mid = (lo + up) >> 1; if (offs[mid] <= from) lo = mid; else up = mid; }
+        for (; lo < np; lo++) {
+            const int o0 = offs[lo], o1 = offs[lo + 1];
+            if (o0 > hi) break;
+            if (o1 <= o0) continue;                               // empty run
+            const int q = o0 + (val - (int)bkp[2 * lo]);          // where this run would hold val
+            if (q >= o0 && q < o1 && q >= from && q <= hi) return q;
+        }
+        return -1;
     }
 };
 
@@ -93,7 +113,8 @@ AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const PATH& path, int P, c
             if (pos1 != P && last[g1 + n] > pos1) {
                 pos2 = -1;
                 int hi = pos1 + limit < P - 1 ? pos1 + limit : P - 1;
-                for (int q = pos1 + 1; q <= hi; q++) if (path.at(q) == g1) { pos2 = q; break; }
+                const int q = path.scan_for(pos1 + 1, hi, g1);
+                if (q >= 0) pos2 = q;
             }
             if (attempt == 0 && (pos1 == P || pos2 == P)) { int t = g0; g0 = -g1; g1 = -t; continue; }
             break;
