@@ -1502,9 +1502,11 @@ class HipBackend : public Backend {
         const double unit_us = 4.0 + avg_path_ / 900.0 + hb().max_m / 64.0;          // one unit through the lean finish stage (mean path capacity of the batch)
         if (enum_us < 8.0 * unit_us) return U;
         // (measured with the SV-carrying bench batch, 40 KB images: 160 / 192 / 256 / 320 workgroups = 1.24 / 1.17 / 1.20 / 1.24 ms
-        // per step, profiles/r02_notes.md; the rule lands on 192 there)
+        // per step in round 2, profiles/r02_notes.md; with round 3's shorter lean stage 128 / 144 / 160 / 176 / 192 / 224 / 288 =
+        // 1.16 / 1.14 / 1.09-1.11 / 1.087-1.091 / 1.10-1.13 / 1.10-1.14 / 1.13-1.15, profiles/r03_notes.md: the rule gives 164 there,
+        // rounded up to a multiple of 16 = 176; round 2 rounded to 32 = 192)
         int64_t grid = (int64_t)((double)U * unit_us / enum_us) + 1;
-        grid = (grid + 31) & ~int64_t(31);
+        grid = (grid + 15) & ~int64_t(15);
         if (grid < 32) grid = 32;
         return grid < U ? (int)grid : U;
     }
@@ -1569,7 +1571,7 @@ class HipBackend : public Backend {
         }
         tick("ambi_finish_kernel", s, 5, true, sb);
         const int fgrid = finish_grid_for(U);
-        if (debug_) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d\n", fgrid, block_lds_);
+        if (debug_) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d, mean path capacity %.0f, order bytes %lld\n", fgrid, block_lds_, avg_path_, (long long)last_needed_);
         if (lean_finish_) {
             hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A, (const int32_t*)nullptr, 0);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
