@@ -242,6 +242,41 @@ def test_resident_batch_run_again(hip_lib, oracle, workdir):
         g.close()
 
 
+@pytest.mark.gpu
+def test_resident_large_batch_run_again(hip_lib, oracle, workdir, monkeypatch):
+    """More units than the express path takes (two groups of 64), run again and again with the launch parameters the first
+    run taught the engine: the oracle's order tables and paths every time."""
+    specs = [("wide", 13, 64, 128), ("chain", 9, 40, 80), ("wide", 17, 96, 200), ("mixed", 11, 64, 128), ("wide", 15, 64, 128), ("chain", 5, 24, 48)]
+    items = []
+    for i in range(70):     # (two groups of 64 units: the second group's offsets start from the first group's sum)
+        tier, K, nseg, njunc = specs[i % len(specs)]
+        s = synth.make_sample(nseg, njunc, tier, K, seed=9300 + i, imperfect=i % 2, n_del=i % 3)
+        lh, sols = s.write(workdir, "sl%d" % i)
+        items.append((lh, sols[0]))
+    want = [oracle.run_bfb(lh, [sol], keep_orders=True)["chr"][0] for lh, sol in items]
+    for mode in ("resident",):
+        graphs, b = [], api.Batch(hip_lib)
+        for lh, sol in items:
+            g = api.Graph(hip_lib, lh)
+            graphs.append(g)
+            b.add_chromosome_sol(g, 0, sol)
+        b.upload()
+        for rep in range(4):
+            b.run(0); b.wait(); b.download()
+            for u, o in enumerate(want):
+                r = b.unit_result(u)
+                assert r["num_orders"] == o["num_orders"], (mode, rep, u)
+                if o["first_valid"] < 0:
+                    continue
+                assert r["status"] == 0, (mode, rep, u, r)
+                assert b.unit_orders(u, 0, r["num_orders"], r["n_nodes"]).tolist() == o["orders"], (mode, rep, u)
+                assert b.unit_path(u, 1).tolist() == o["path_indel"], (mode, rep, u)
+        b.close()
+        for g in graphs:
+            g.close()
+
+
+@pytest.mark.gpu
 def test_run_length_exchange_payload(hip_lib, oracle, workdir):
     """pack_runs -> expand_runs on the GPU reproduces the downloaded paths (the payload of bench.py's gather), for both
     path kinds, with far fewer runs than cells."""
