@@ -214,3 +214,113 @@ def test_product_prints_the_reference_held_lines_host(hostsim_lib):
 @pytest.mark.gpu
 def test_product_prints_the_reference_held_lines_gpu(hip_lib):
     _known(hip_lib)
+
+
+def _check_dag_hand_derived(lib, oracle, workdir, tag):
+    """constructDAG (LGM.cpp:3276-3378) and allTopologicalOrders (:3380-3409) walked by hand on a chromosome of 12 segments, where
+    the std::map's STRING order of the keys differs from their numeric order.
+
+    Elements (all cn 1): p(1,12), l(1,10), l(1,2), l(3,10).  Keys in map order (:3279; byte-wise): "l:1,10" < "l:1,2" (after the
+    common "l:1," comes '1' < '2') < "l:3,10" < "p:1,12"  ->  nodes 0 = l(1,10), 1 = l(1,2), 2 = l(3,10), 3 = p(1,12);
+    node2pat = [-, -, -, (1,12)], node2loop = [(1,10), (1,2), (3,10), -].
+    std::sort(node2loop, compareLoops) (:3303; 4 elements: libstdc++ runs a plain insertion sort; compareLoops is "longer first"
+    and says false whenever a side is empty, :3267-3274), lengths 9, 1, 7, -:
+      i=1 (1,2):   not before (1,10) (1 > 9 false); unguarded insert: (1,2) vs (1,10) false -> stays           [(1,10) (1,2) (3,10) -]
+      i=2 (3,10):  7 > 9 false; unguarded: vs (1,2) 7 > 1 true -> (1,2) moves up; vs (1,10) false -> placed     [(1,10) (3,10) (1,2) -]
+      i=3 empty:   false against everything -> stays
+    so node2loop = [(1,10), (3,10), (1,2), -]: node 1 now stands for l(3,10) and node 2 for l(1,2).
+    Edges.  p -> l (:3326-3336) from node 3 = p(1,12), length 11: node 0 l(1,10) same start, 11 > 9 -> 3->0; node 1 l(3,10) shares
+    nothing; node 2 l(1,2) same start, 11 > 1 -> 3->2.  Loops in index order (:3339-3377): node 0 l(1,10): l -> p: node 3 is its
+    parent -> skipped (:3343); l -> l: node 1 l(3,10) same end, 9 > 7 -> 0->1; node 2 l(1,2) same start, 9 > 1 -> 0->2.
+    node 1 l(3,10): pattern (1,12) shares neither end; loops: (1,10) same end but 7 > 9 false; (1,2) shares nothing.  node 2 l(1,2):
+    node 3 is a parent -> skipped; (1,10) same start but 1 > 9 false.
+    adj = {0: [1,2], 1: [], 2: [], 3: [0,2]}; in-degrees 1, 1, 2, 0 -> orders, lowest free node first: 3 0 1 2, then 3 0 2 1."""
+    n = 12
+    lh = _lh(os.path.join(workdir, "hand_%s_dag.lh" % tag), n, [(12, '+', 12, '-'), (1, '-', 1, '+')])
+    sol = _sol(os.path.join(workdir, "hand_%s_dag.sol" % tag), n, [("p", 1, 12, 1), ("l", 1, 10, 1), ("l", 1, 2, 1), ("l", 3, 10, 1)])
+    want_pat = [[], [], [], [1, 12, 1]]
+    want_loop = [[1, 10, 1], [3, 10, 1], [1, 2, 1], []]
+    want_adj = [[1, 2], [], [], [0, 2]]
+    want_orders = [[3, 0, 1, 2], [3, 0, 2, 1]]
+    oc = oracle.run_bfb(lh, [sol], keep_orders=True)["chr"][0]
+    assert oc["node2pat"] == want_pat and oc["node2loop"] == want_loop and [sorted(a) for a in oc["adj"]] == want_adj
+    assert oc["num_orders"] == 2 and oc["orders"] == want_orders
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sol)
+    b.upload(); b.run(0); b.download()
+    r = b.unit_result(0)
+    assert r["n_nodes"] == 4 and r["num_orders"] == 2
+    pat, loop, succ = b.unit_dag(0, 4)
+    assert [[] if p[0] == 0 else p for p in pat.tolist()] == want_pat
+    assert [[] if p[0] == 0 else p for p in loop.tolist()] == want_loop
+    assert [int(x) for x in succ] == [sum(1 << j for j in a) for a in want_adj]
+    assert b.unit_orders(0, 0, 2, 4).tolist() == want_orders
+    # what getBFB then makes of these orders is not part of this walk: engine and oracle must simply agree
+    assert (r["status"] == 0) == (oc["first_valid"] >= 0) and r["first_valid"] == oc["first_valid"] and r["evaluated"] == oc["evaluated"]
+    b.close(); g.close()
+
+
+def test_dag_hand_derived_host(hostsim_lib, oracle, workdir):
+    _check_dag_hand_derived(hostsim_lib, oracle, workdir, "cpu")
+
+
+@pytest.mark.gpu
+def test_dag_hand_derived_gpu(hip_lib, oracle, workdir):
+    _check_dag_hand_derived(hip_lib, oracle, workdir, "gpu")
+
+
+def _check_junc_cn_hand_derived(lib, oracle, workdir, tag):
+    """getJuncCN (LGM.cpp:3989-4050) and the bias (localhap.cpp:141-146) walked by hand.  Six segments, junctions in file order
+    (index = position in the graph's junction list; none is a duplicate or the complement of an earlier one, Graph.cpp:592-597):
+
+      0  1+ -> 2+  cn 2.0   same strand, source+1 == target            juncCN[1][0] += 2.0                         (:4003-4005)
+      1  2+ -> 3+  cn 0.7   0.5 < cn < 1 counts as 1 (:4000-4001)      juncCN[2][0] += 1.0
+      2  4- -> 3-  cn 1.5   same strand, source-1 == target            juncCN[3][0] += 1.5  (slot of the TARGET)   (:4007-4009)
+      3  4+ -> 5+  cn 1.0                                              juncCN[4][0] += 1.0
+      4  5+ -> 6+  cn 1.0                                              juncCN[5][0] += 1.0
+      5  6+ -> 6-  cn 3.0   opposite strands, |6-6| <= 2: fold-back; inversions[6] free -> junction 5, juncCN[6][1] += 3.0   (:4012-4016)
+      6  5+ -> 6-  cn 0.6   fold-back (|5-6| = 1); inversions[5] free -> junction 6, juncCN[5][1] += 1.0 (rounded)
+      7  6+ -> 4-  cn 2.0   fold-back (|6-4| = 2); inversions[6] taken, inversions[4] free -> junction 7, juncCN[4][1] += 2.0   (:4027-4029)
+      8  5- -> 6+  cn 1.0   fold-back; inversions[5] and [6] both taken: nothing recorded, its CN counted nowhere
+      9  2- -> 1+  cn 1.0   fold-back; inversions[2] free -> junction 9, juncCN[2][1] += 1.0
+    second pass (:4042-4049): every end of a fold-back still without an entry: only segment 1 (target of junction 9) -> junction 9.
+    bias = 1 + sum over segments with juncCN[i][1] > 0 whose recorded fold-back joins two DIFFERENT segments of int(juncCN[i][1]) % 2:
+      i=2 (junction 9: 2 vs 1) 1 % 2 = 1;  i=4 (junction 7: 6 vs 4) 2 % 2 = 0;  i=5 (junction 6: 5 vs 6) 1;  i=6 (junction 5: 6 vs 6) skipped  ->  3.
+    No same-strand junction skips a segment: getIndelBias leaves the segment CNs alone."""
+    lh = os.path.join(workdir, "hand_%s_jcn.lh" % tag)
+    J = [(1, '+', 2, '+', 2.0), (2, '+', 3, '+', 0.7), (4, '-', 3, '-', 1.5), (4, '+', 5, '+', 1.0), (5, '+', 6, '+', 1.0),
+         (6, '+', 6, '-', 3.0), (5, '+', 6, '-', 0.6), (6, '+', 4, '-', 2.0), (5, '-', 6, '+', 1.0), (2, '-', 1, '+', 1.0)]
+    with open(lh, "w") as f:
+        f.write("SAMPLE_NAME hand\nAVG_CHR_SEG_DP 30\nAVG_WHOLE_HOST_DP 30\nAVG_JUNC_DP 30\nPURITY 1\nAVG_TUMOR_PLOIDY 2\nPLOIDY 2m1\nVIRUS_START 7\nSOURCE 1\nSINK 6\n")
+        for i in range(1, 7):
+            f.write("SEG H:%d:chr1:%d:%d 60.0 4.0\n" % (i, i * 1000 + 1, i * 1000 + 1000))
+        for (a, ad, b, bd, cn) in J:
+            f.write("JUNC H:%d:%s H:%d:%s %.1f %.1f U B\n" % (a, ad, b, bd, 30 * cn, cn))
+    sol = _sol(os.path.join(workdir, "hand_%s_jcn.sol" % tag), 6, [("l", 1, 6, 1)])
+    want_jcn = [[2.0, 0.0], [1.0, 1.0], [1.5, 0.0], [1.0, 2.0], [1.0, 1.0], [0.0, 3.0]]        # segments 1..6: [normal, fold-back]
+    want_inv = {1: 9, 2: 9, 4: 7, 5: 6, 6: 5}
+    oc = oracle.run_bfb(lh, [sol])["chr"][0]
+    import numpy as np
+    assert np.array(oc["junc_cn"], dtype=float).reshape(-1, 2)[1:7].tolist() == want_jcn      # (rows by segment id, row 0 unused)
+    assert dict(zip(oc["inv_seg"], oc["inv_junc"])) == want_inv and oc["bias"] == 3
+    g = api.Graph(lib, lh)
+    assert g.n_junc == 10
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sol)
+    b.upload(); b.run(0); b.download()
+    prep = b.unit_prepare(0, 6)
+    assert prep["junc_cn"][1:].tolist() == want_jcn
+    assert {i: int(j) for i, j in enumerate(prep["inv_junc"]) if i >= 1 and j >= 0} == want_inv
+    assert b.unit_result(0)["bias"] == 3
+    assert prep["seg_cn"][1:].tolist() == [4.0] * 6
+    b.close(); g.close()
+
+
+def test_junc_cn_hand_derived_host(hostsim_lib, oracle, workdir):
+    _check_junc_cn_hand_derived(hostsim_lib, oracle, workdir, "cpu")
+
+
+@pytest.mark.gpu
+def test_junc_cn_hand_derived_gpu(hip_lib, oracle, workdir):
+    _check_junc_cn_hand_derived(hip_lib, oracle, workdir, "gpu")
