@@ -324,3 +324,77 @@ def test_junc_cn_hand_derived_host(hostsim_lib, oracle, workdir):
 @pytest.mark.gpu
 def test_junc_cn_hand_derived_gpu(hip_lib, oracle, workdir):
     _check_junc_cn_hand_derived(hip_lib, oracle, workdir, "gpu")
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check_readme_out_junctions(lib, oracle):
+    """Output-junction synthesis (localhap.cpp:267-289) on the README example, whose path the reference holds (README.md:122):
+      1+2+3+4+5+6+|6-5-4-3-2-|2+3+4+|4-3-|3+4+|4-3-2-|2+3+4+5+6+|6-5-4-3-2-1-
+    A step u -> v is a junction unless the ids are one apart on the same strand; a repeat of the same edge (or its complement)
+    raises the count of the first entry, which starts at 1.  Steps at the seven '|': 6+ -> 6- (new), 2- -> 2+ (new), 4+ -> 4- (new),
+    3- -> 3+ (new), 4+ -> 4- (2nd), 2- -> 2+ (2nd), 6+ -> 6- (2nd)  ->  in first-appearance order (6+,6-) x2, (2-,2+) x2, (4+,4-) x2, (3-,3+) x1."""
+    lh, sol = os.path.join(ROOT, "tests", "data", "readme6.lh"), os.path.join(ROOT, "tests", "data", "readme6.sol")
+    want = [(6, -6, 2), (-2, 2, 2), (4, -4, 2), (-3, 3, 1)]
+    o = oracle.run_bfb(lh, [sol])
+    assert [tuple(x) for x in o["out_juncs"]] == want
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sol)
+    b.upload(); b.run(0); b.download()
+    assert b.unit_path(0, 1).tolist() == [1, 2, 3, 4, 5, 6, -6, -5, -4, -3, -2, 2, 3, 4, -4, -3, 3, 4, -4, -3, -2, 2, 3, 4, 5, 6, -6, -5, -4, -3, -2, -1]
+    assert b.unit_out_juncs(0) == want
+    b.close(); g.close()
+
+
+def test_readme_out_junctions_host(hostsim_lib, oracle):
+    _check_readme_out_junctions(hostsim_lib, oracle)
+
+
+@pytest.mark.gpu
+def test_readme_out_junctions_gpu(hip_lib, oracle):
+    _check_readme_out_junctions(hip_lib, oracle)
+
+
+def _check_readme_reversed_walk(lib, oracle):
+    """getBFB with --reversed (LGM.cpp:3519-3658, seed :3524-3568, loop placement :3586-3644) walked by hand on the README example.
+    The .sol selects columns 26, 29, 31, 33 = loops l(1,6), l(2,4), l(2,6), l(3,4) (numPat 21; rank(a,b) of localhap.cpp:117-133).
+    constructDAG: keys "l:1,6" < "l:2,4" < "l:2,6" < "l:3,4"; lengths 5, 2, 4, 1 -> after the sort node2loop = (1,6) (2,6) (2,4) (3,4);
+    edges (1,6)->(2,6) (same end), (2,6)->(2,4) (same start), (2,4)->(3,4) (same end): a chain, ONE order 0 1 2 3.
+    Reversed orientation: the seed of a loop (s,e) is  e- s- s+ e+  (:3548-3566), an insert behind a slot holding s- is
+    s+ e+ e- s-, behind a slot holding e+ it is e- s- s+ e+ (:3605-3643); the slot is the LAST odd cell holding s- or e+ that
+    passes the nesting test |cell[q-1]| vs |cell[q+2]| (only for q < L-2):
+      seed (1,6)        6- 1- 1+ 6+
+      (2,6): odd cells 1- 6+ : cell 3 = 6+ = e+ (q = 3 = L-1: no test)            -> behind it  6- 2- 2+ 6+
+                        6- 1- 1+ 6+ 6- 2- 2+ 6+
+      (2,4): odd cells 1- 6+ 2- 6+ : cell 5 = 2- = s- (q = 5 < 6: |6-| vs |6+| equal: kept)  -> behind it  2+ 4+ 4- 2-
+                        6- 1- 1+ 6+ 6- 2- 2+ 4+ 4- 2- 2+ 6+
+      (3,4): odd cells .. cell 7 = 4+ = e+ (q = 7 < 10: |2+| vs |2-| equal: kept)  -> behind it  4- 3- 3+ 4+
+                        6- 1- 1+ 6+ 6- 2- 2+ 4+ 4- 3- 3+ 4+ 4- 2- 2+ 6+
+    (the in-place fix-ups :3626-3628 / :3639-3641 rewrite cells with the values they hold).  All four placed; every fold-back of
+    the file is perfect: imperfectFBI changes nothing.  Pairs -> 6-..1- | 1+..6+ | 6-..2- | 2+3+4+ | 4-3- | 3+4+ | 4-3-2- | 2+..6+
+    (the same line the survey's run of the reference printed for --reversed, tests/golden/known_answers.json)."""
+    lh, sol = os.path.join(ROOT, "tests", "data", "readme6.lh"), os.path.join(ROOT, "tests", "data", "readme6.sol")
+    bkp = [-6, -1, 1, 6, -6, -2, 2, 4, -4, -3, 3, 4, -4, -2, 2, 6]
+    path = expand(bkp)
+    o = oracle.run_bfb(lh, [sol], reversed_=True, keep_orders=True)["chr"][0]
+    assert o["node2loop"] == [[1, 6, 1], [2, 6, 1], [2, 4, 1], [3, 4, 1]] and o["orders"] == [[0, 1, 2, 3]]
+    assert list(o["bkp"]) == bkp and list(o["path"]) == path and (o["first_valid"], o["first_forward"]) == (0, 0)
+    g = api.Graph(lib, lh)
+    b = api.Batch(lib)
+    b.add_chromosome_sol(g, 0, sol)
+    b.upload(); b.run(api.FLAG_REVERSED); b.download()
+    r = b.unit_result(0)
+    assert (r["status"], r["first_valid"], r["first_forward"], r["evaluated"]) == (0, 0, 0, 1)
+    assert b.unit_bkp(0).tolist() == bkp and b.unit_path(0, 0).tolist() == path and b.unit_path(0, 1).tolist() == path
+    b.close(); g.close()
+
+
+def test_readme_reversed_walk_host(hostsim_lib, oracle):
+    _check_readme_reversed_walk(hostsim_lib, oracle)
+
+
+@pytest.mark.gpu
+def test_readme_reversed_walk_gpu(hip_lib, oracle):
+    _check_readme_reversed_walk(hip_lib, oracle)
