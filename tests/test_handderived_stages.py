@@ -59,6 +59,25 @@ TELOQ = [(6, '+', 6, '-'), (2, '-', 2, '+')]
 
 # name -> dict(n, juncs, elems, bkp, path, path_indel, printed, cn_delta {segment: delta after getIndelBias}, bias)
 CASES = {
+    # ---------------------------------------------------------------- getBFB, loop placement (:3586-3644): a candidate that fails the nesting test
+    # G1.  6 segments; loops l(1,6), l(2,6), l(3,6), all cn 1, perfect fold-backs at 6 and 1.  Keys "l:1,6" < "l:2,6" < "l:3,6", lengths 5, 4, 3
+    #  (the sort leaves them), edges by the shared end 6: 0->1, 0->2, 1->2: one order 0 1 2.  Forward: seed 1+ 6+ 6- 1-  (:3548-3566).
+    #  l(2,6): v1 = 2- is not in the path -> v2 = 6+, searched from the back (:3599-3604): cell 1 (odd; 1 < L-2 = 2 is false: no test)
+    #   -> 6- 2- 2+ 6+ goes in behind it:  1+ 6+ 6- 2- 2+ 6+ 6- 1-.
+    #  l(3,6): no 3-; 6+ from the back: cell 5 is odd, 5 < L-2 = 6: id(cell 4) = 2 > id(cell 7) = 1 -> SKIPPED (:3601); next 6+ is cell 1:
+    #   id(cell 0) = 1 > id(cell 3) = 2 is false -> taken; 6- 3- 3+ 6+ behind it:  1+ 6+ 6- 3- 3+ 6+ 6- 2- 2+ 6+ 6- 1-.
+    #   (in-place fix-ups :3639-3641: cell 1 := 6+, the cell behind it := 6-: the values they hold.)
+    #  imperfectFBI: pos 0: 1- is found at cell 11 and cell 10 = 6- = -cell 1: one palindrome over everything, mid = 5; iterations
+    #   p1 = 5 (6+: perfect fold-back, cells 5, 6 keep 6+ 6-), p1 = 3 (3-: NO fold-back recorded at 3: nothing), p1 = 1 (6+: cells 1, 2
+    #   and the mirrored 10, 9 keep their values).  Nothing changes.
+    "G1 loop placement: the last candidate fails the nesting test": dict(n=6, juncs=TELO6,
+        elems=[("l", 1, 6, 1), ("l", 2, 6, 1), ("l", 3, 6, 1)], bkp=[1, 6, -6, -3, 3, 6, -6, -2, 2, 6, -6, -1], bias=1),
+    # G2.  The same with perfect fold-backs at 2 and 3 as well: the placement is the same, but now iteration p1 = 3 of the palindrome
+    #  rewrite finds inv[3] (3- -> 3+): w0 = 3-, w1 = 3+ into cells 3, 4 (unchanged) AND, mirrored about mid (:3493-3500: p2 = 8),
+    #  cell 8 = -w0 = 3+, cell 7 = -w1 = 3-: the right half, which held 2- 2+, now repeats the left one -- imperfectFBI takes the two
+    #  halves of whatever lies between a vertex and its complement for mirror images.
+    "G2 palindrome rewrite mirrors the left half over a different right half": dict(n=6, juncs=[(6, '+', 6, '-'), (1, '-', 1, '+'), (2, '-', 2, '+'), (3, '-', 3, '+')],
+        elems=[("l", 1, 6, 1), ("l", 2, 6, 1), ("l", 3, 6, 1)], bkp=[1, 6, -6, -3, 3, 6, -6, -3, 3, 6, -6, -1], bias=1),
     # ---------------------------------------------------------------- imperfectFBI, plain rewrite (:3442-3471)
     # F1.  7 segments; elements p(1,6), p(3,6), p(3,5).  Nodes in string-key order (LGM.cpp:3279): 0 = p:1,6  1 = p:3,5  2 = p:3,6;
     #  edges (:3314-3324) 0->2 (same end, longer), 2->1 (same start, longer): the only order is 0,2,1.  getBFB forward (:3527-3585):
