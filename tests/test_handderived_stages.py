@@ -253,7 +253,20 @@ def _check_dag_hand_derived(lib, oracle, workdir, tag):
     parent -> skipped (:3343); l -> l: node 1 l(3,10) same end, 9 > 7 -> 0->1; node 2 l(1,2) same start, 9 > 1 -> 0->2.
     node 1 l(3,10): pattern (1,12) shares neither end; loops: (1,10) same end but 7 > 9 false; (1,2) shares nothing.  node 2 l(1,2):
     node 3 is a parent -> skipped; (1,10) same start but 1 > 9 false.
-    adj = {0: [1,2], 1: [], 2: [], 3: [0,2]}; in-degrees 1, 1, 2, 0 -> orders, lowest free node first: 3 0 1 2, then 3 0 2 1."""
+    adj = {0: [1,2], 1: [], 2: [], 3: [0,2]}; in-degrees 1, 1, 2, 0 -> orders, lowest free node first: 3 0 1 2, then 3 0 2 1.
+
+    getBFB on them (fold-backs at 12 and 1 only).  FORWARD: both orders seed p(1,12) = 1+ 12+ and then meet l(1,10): neither 1- nor 10+
+    is in the path -> break (:3610): both invalid, the last one too -> the orientation flips (:3691-3695).  REVERSED, order 3 0 1 2:
+      seed p(1,12) reversed        12- 1-
+      l(1,10): v1 = 1- at cell 1 (odd, the last cell: no nesting test) -> behind it 1+ 10+ 10- 1-        12- 1- 1+ 10+ 10- 1-
+      l(3,10): no 3-; 10+ from the back: cell 3 (odd; 3 < L-2 = 4: id(cell 2) = 1 > id(cell 5) = 1 false) -> 10- 3- 3+ 10+ behind it
+                                   12- 1- 1+ 10+ 10- 3- 3+ 10+ 10- 1-
+      l(1,2): 1- from the back: cell 9 (odd, the last cell) -> 1+ 2+ 2- 1- at the end
+                                   12- 1- 1+ 10+ 10- 3- 3+ 10+ 10- 1- 1+ 2+ 2- 1-
+    All placed.  imperfectFBI: pos 0 (12- 1-): no 12+ behind -> plain, the perfect fold-back at 1 rewrites 1- as 1-.  pos 2: 1- found at
+    cell 9, cell 8 = 10- = -cell 3: palindrome, mid 5; p1 = 5 (3-), 3 (10+): no fold-back there; p1 = 1 = pos-1 (1-): cells 1, 2 and the
+    mirrored cell 9 get the values they hold.  pos 10: 1- at cell 13, cell 12 = 2- = -cell 11: palindrome, mid 11; p1 = 11 (2+): none;
+    p1 = 9 = pos-1 (1-): cells 9, 10, 13 unchanged.  -> first valid order 0 of the REVERSED pass, three evaluations."""
     n = 12
     lh = _lh(os.path.join(workdir, "hand_%s_dag.lh" % tag), n, [(12, '+', 12, '-'), (1, '-', 1, '+')])
     sol = _sol(os.path.join(workdir, "hand_%s_dag.sol" % tag), n, [("p", 1, 12, 1), ("l", 1, 10, 1), ("l", 1, 2, 1), ("l", 3, 10, 1)])
@@ -275,8 +288,10 @@ def _check_dag_hand_derived(lib, oracle, workdir, tag):
     assert [[] if p[0] == 0 else p for p in loop.tolist()] == want_loop
     assert [int(x) for x in succ] == [sum(1 << j for j in a) for a in want_adj]
     assert b.unit_orders(0, 0, 2, 4).tolist() == want_orders
-    # what getBFB then makes of these orders is not part of this walk: engine and oracle must simply agree
-    assert (r["status"] == 0) == (oc["first_valid"] >= 0) and r["first_valid"] == oc["first_valid"] and r["evaluated"] == oc["evaluated"]
+    want_bkp = [-12, -1, 1, 10, -10, -3, 3, 10, -10, -1, 1, 2, -2, -1]
+    assert (oc["first_valid"], oc["first_forward"], oc["evaluated"], list(oc["bkp"])) == (0, 0, 3, want_bkp) and list(oc["path"]) == expand(want_bkp)
+    assert (r["status"], r["first_valid"], r["first_forward"], r["evaluated"]) == (0, 0, 0, 3)
+    assert b.unit_bkp(0).tolist() == want_bkp and b.unit_path(0, 0).tolist() == expand(want_bkp)
     b.close(); g.close()
 
 
