@@ -292,6 +292,17 @@ def _check_dag_hand_derived(lib, oracle, workdir, tag):
     assert (oc["first_valid"], oc["first_forward"], oc["evaluated"], list(oc["bkp"])) == (0, 0, 3, want_bkp) and list(oc["path"]) == expand(want_bkp)
     assert (r["status"], r["first_valid"], r["first_forward"], r["evaluated"]) == (0, 0, 0, 3)
     assert b.unit_bkp(0).tolist() == want_bkp and b.unit_path(0, 0).tolist() == expand(want_bkp)
+    # --all (LGM.cpp:3519-3696 with printAll): every order of a pass is evaluated and every valid one printed; the reversed pass runs
+    # because the LAST forward order was invalid.  Reversed order 3 0 2 1: 12- 1- | l(1,10) as above | l(1,2): 1- from the back is cell 5,
+    # the last cell -> 1+ 2+ 2- 1- at the end | l(3,10): 10+ from the back is cell 3 (3 < L-2 = 8: 1 > 1 false) -> 10- 3- 3+ 10+ behind it:
+    # the SAME cells as order 3 0 1 2.  So: four evaluations, the valid ones are evaluations 2 and 3, the path printed twice.
+    line = "12-11-10-9-8-7-6-5-4-3-2-1-|1+2+3+4+5+6+7+8+9+10+|10-9-8-7-6-5-4-3-|3+4+5+6+7+8+9+10+|10-9-8-7-6-5-4-3-2-1-|1+2+|2-1-"
+    oa = oracle.run_bfb(lh, [sol], all_=True)
+    ea = api.reconstruct_sample(lib, lh, [sol], all_=True)
+    for who, res in (("oracle", oa), ("engine", ea)):
+        c = res["chr"][0]
+        assert [list(x) for x in c["all_paths"]] == [expand(want_bkp)] * 2 and c["evaluated"] == 4, who
+        assert [l for l in res["log"] if l and l[0].isdigit()] == [line, line], who
     b.close(); g.close()
 
 
