@@ -3,7 +3,8 @@
 // Inputs (uploaded once, resident in HBM while a batch is run any number of times):
 //   UnitIn[U]           fixed-size descriptor per unit: sizes + offsets into the pools below
 //   seg_cn   f64        (n+1) per unit, slot 0 unused, indexed by LOCAL segment id      ("8n"  of SURVEY 8d)
-//   juncs    Junction   24-byte records, reference junction order preserved             ("24m")
+//   junc_ends, junc_cn  strand-signed ends (4 bytes) + copy number (f64) per junction, reference junction order preserved
+//                       (12 of the 24 bytes of the host's Junction record -- SURVEY 8d counts "24m" -- are all the device reads)
 //   elems    Element    16-byte records (solution columns with value > 0)               ("16K")
 // Working set (device only): per-unit Dag, ideal tables, the order-table arena (R x K uint8 rows, 16-byte aligned
 // per unit), bkp cells.
@@ -118,7 +119,7 @@ struct BatchArgs {
     int32_t* block_hdr;          // [U][8]  BlockImageHeader
     const UnitIn* units;
     const double* seg_cn;
-    const Junction* juncs;
+    const double* junc_cn;      // [sum m] copy number of every junction (the 24-byte records stay on the host: the device reads 12 bytes per junction)
     const JuncEnds* junc_ends;  // [sum m] the strand-signed ends of every junction (4 bytes; the finish stages need nothing else of a junction)
     const Element* elems;
     Dag* dags;                   // [U]

@@ -74,7 +74,7 @@ static_assert(sizeof(Junction) == 24, "junction record is 24 bytes");
 struct JuncEnds { int16_t s, t; };
 struct JuncView {
     const JuncEnds* e;       // [m] group memory
-    const Junction* full;    // [m] the unit's records in HBM (copy numbers)
+    const double* cn;        // [m] the unit's junction copy numbers in HBM
 };
 AMBI_HD JuncEnds junc_ends(const Junction& j) {
     JuncEnds E;

@@ -950,7 +950,7 @@ class HipBackend : public Backend {
     hipStream_t stream_ = nullptr;
     Lease* lease_ = nullptr;
     // device buffers: all carved from ONE block of the lease (layout()); inputs first, in the order of the staging image
-    UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; Junction* d_juncs_ = nullptr; JuncEnds* d_junc_ends_ = nullptr; Element* d_elems_ = nullptr;
+    UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; double* d_junc_cn_ = nullptr; JuncEnds* d_junc_ends_ = nullptr; Element* d_elems_ = nullptr;
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
     uint64_t* d_ikeys_ = nullptr; uint64_t* d_icnt_ = nullptr; uint32_t* d_ilink_ = nullptr; int32_t* d_ilvl_off_ = nullptr; int32_t* d_icounter_ = nullptr;
     int32_t* d_ipos_ = nullptr; uint64_t* d_aavail_ = nullptr; uint64_t* d_acnt_ = nullptr; int32_t* d_acbase_ = nullptr; uint16_t* d_achild_ = nullptr;
@@ -1099,7 +1099,7 @@ class HipBackend : public Backend {
         const HostBatch& H = hb();
         const size_t U = H.units.size();
         Carver c{base};
-        c.take(&d_units_, U); c.take(&d_seg_cn_, H.seg_cn.size()); c.take(&d_juncs_, H.juncs.size()); c.take(&d_junc_ends_, H.junc_ends.size());
+        c.take(&d_units_, U); c.take(&d_seg_cn_, H.seg_cn.size()); c.take(&d_junc_cn_, H.junc_cn.size()); c.take(&d_junc_ends_, H.junc_ends.size());
         c.take(&d_elems_, H.elems.size()); c.take(&d_scratch_off_, U); c.take(&d_direct_list_, direct_list.size()); c.take(&d_mail_off_, U);
         c.take(&d_wide_index_, U); c.take(&d_wide_units_, (size_t)H.n_wide);
         c.take(&d_inject_, H.inject.size()); c.take(&d_inject_off_, H.inject.empty() ? 0 : 2 * U);
@@ -1317,7 +1317,7 @@ class HipBackend : public Backend {
         auto put = [&](const void* dptr, const void* src, size_t bytes) { if (bytes) memcpy(img + (reinterpret_cast<const uint8_t*>(dptr) - L->d_block), src, bytes); };
         put(d_units_, H.units.data(), U * sizeof(UnitIn));
         put(d_seg_cn_, H.seg_cn.data(), H.seg_cn.size() * sizeof(double));
-        put(d_juncs_, H.juncs.data(), H.juncs.size() * sizeof(Junction));
+        put(d_junc_cn_, H.junc_cn.data(), H.junc_cn.size() * sizeof(double));
         put(d_junc_ends_, H.junc_ends.data(), H.junc_ends.size() * sizeof(JuncEnds));
         put(d_elems_, H.elems.data(), H.elems.size() * sizeof(Element));
         put(d_scratch_off_, H.scratch_off.data(), U * sizeof(int64_t));
@@ -1367,7 +1367,7 @@ class HipBackend : public Backend {
         A_.enum_stack_lds = enum_stack_lds_; A_.enum_auto_lds = enum_auto_lds_;
         A_.block_lds = block_lds_; A_.block_scratch_lds = block_scratch_lds_; A_.block_max = block_max_; A_.build_in_emit = build_in_emit_; A_.emit_interleave = emit_interleave_; A_.order_align = order_align_; A_.block_dfs = block_dfs_; A_.finish_path_cells = finish_path_cells_; A_.unit_fallback = d_fallback_; A_.block_img = d_blk_img_; A_.block_hdr = d_blk_hdr_;
         A_.ideal_pos = d_ipos_; A_.auto_avail = d_aavail_; A_.auto_cnt = d_acnt_; A_.auto_cbase = d_acbase_; A_.auto_child = d_achild_; A_.auto_nblk = d_anblk_; A_.auto_depth = d_adepth_;
-        A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.juncs = d_juncs_; A_.junc_ends = d_junc_ends_; A_.elems = d_elems_;
+        A_.units = d_units_; A_.seg_cn = d_seg_cn_; A_.junc_cn = d_junc_cn_; A_.junc_ends = d_junc_ends_; A_.elems = d_elems_;
         A_.dags = d_dags_; A_.results = d_results_;
         A_.ideal_keys = d_ikeys_; A_.ideal_cnt = d_icnt_; A_.ideal_link = d_ilink_; A_.ideal_lvl_off = d_ilvl_off_; A_.ideal_counter = d_icounter_;
         A_.first_rows = d_first_rows_;

@@ -28,6 +28,7 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
         J.same_chr = 1; J.cn = j_cn[j];
         juncs.push_back(J);
         junc_ends.push_back(ambi::junc_ends(J));
+        junc_cn.push_back(J.cn);
     }
     U.elem_off = (int64_t)elems.size();
     int64_t L = 0;
@@ -125,6 +126,7 @@ int HostBatch::add_unit_from(const HostBatch& src, int u) {
     U.junc_off = (int64_t)juncs.size();
     juncs.insert(juncs.end(), src.juncs.begin() + S.junc_off, src.juncs.begin() + S.junc_off + S.n_junc);
     junc_ends.insert(junc_ends.end(), src.junc_ends.begin() + S.junc_off, src.junc_ends.begin() + S.junc_off + S.n_junc);
+    junc_cn.insert(junc_cn.end(), src.junc_cn.begin() + S.junc_off, src.junc_cn.begin() + S.junc_off + S.n_junc);
     U.elem_off = (int64_t)elems.size();
     elems.insert(elems.end(), src.elems.begin() + S.elem_off, src.elems.begin() + S.elem_off + S.n_elem);
     U.ideal_cap = ideal_cap;

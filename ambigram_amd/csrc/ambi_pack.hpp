@@ -18,6 +18,7 @@ struct HostBatch {
     std::vector<double> seg_cn;
     std::vector<Junction> juncs;
     std::vector<JuncEnds> junc_ends;   // junc_ends(juncs[i]) of every record
+    std::vector<double> junc_cn;       // juncs[i].cn: ends + copy number (12 bytes) are all the device reads of a junction
     std::vector<Element> elems;
     std::vector<int64_t> scratch_off;       // per unit, ints
     std::vector<std::vector<int32_t>> junc_global;   // per unit: local junction index -> index in the sample's graph

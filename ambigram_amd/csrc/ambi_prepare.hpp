@@ -101,7 +101,7 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
                     if (s + 1 == t) slot[q] = s;
                     else if (s - 1 == t) slot[q] = t;
                 }
-                if (slot[q] >= 0) { cn[q] = J.full[ji].cn; shared[q] = slot_cnt[slot[q]] != 1; }
+                if (slot[q] >= 0) { cn[q] = J.cn[ji]; shared[q] = slot_cnt[slot[q]] != 1; }
             }
         }
 #pragma unroll
@@ -145,7 +145,7 @@ AMBI_HD void get_junc_cn_g(const G& g, int n, const JuncView& J, int m, double* 
     g.sync();
     for (int i = g.tid(); i <= n; i += g.size()) {
         const int ji = inv_junc[i];
-        if (ji >= 0) junc_cn[2 * i + 1] = 0.0 + junc_cn_round(J.full[ji].cn);
+        if (ji >= 0) junc_cn[2 * i + 1] = 0.0 + junc_cn_round(J.cn[ji]);
     }
     g.sync();
     // LGM.cpp:4043-4049: remaining ends point at their junction, no copy number.  Serial in the reference, but here the

@@ -147,10 +147,10 @@ AMBI_HD void prep_junctions(const G& g, const BatchArgs& A, int u, const UnitIn&
     const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
     // staging: junction ends (4 of the 24 bytes of a record) into group memory; the segment CNs go straight into their
     // slot of the result blob (getIndelBias edits them there)
-    const JuncView J{W.ends, A.juncs + U.junc_off};
+    const JuncView J{W.ends, A.junc_cn + U.junc_off};
     double* junc_cn = reinterpret_cast<double*>(res + Lay.junc_cn);
     double* seg_cn = reinterpret_cast<double*>(res + Lay.seg_cn);
-    for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = junc_ends(J.full[j]);
+    { const JuncEnds* ge = A.junc_ends + U.junc_off; for (int j = g.tid(); j < m; j += g.size()) W.ends[j] = ge[j]; }
     copy_words(g, reinterpret_cast<uint32_t*>(seg_cn), reinterpret_cast<const uint32_t*>(A.seg_cn + U.seg_off), 2ll * (n + 1));
     g.sync();
     AMBI_MARK(A, g, u, 1);

@@ -69,7 +69,7 @@ class HostSimBackend : public Backend {
           if (bm < 1) bm = 1; if (bm > kBlockMaxLimit) bm = kBlockMaxLimit; A_.block_max = bm; }
         A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
         A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data(); A_.auto_nblk = anblk_.data(); A_.auto_depth = adepth_.data();
-        A_.units = units_.data(); A_.seg_cn = hb_.seg_cn.data(); A_.juncs = hb_.juncs.data(); A_.junc_ends = hb_.junc_ends.data(); A_.elems = hb_.elems.data();
+        A_.units = units_.data(); A_.seg_cn = hb_.seg_cn.data(); A_.junc_cn = hb_.junc_cn.data(); A_.junc_ends = hb_.junc_ends.data(); A_.elems = hb_.elems.data();
         A_.dags = dags_.data(); A_.results = results_.data();
         A_.ideal_keys = ikeys_.data(); A_.ideal_cnt = icnt_.data(); A_.ideal_link = ilink_.data();
         A_.ideal_lvl_off = ilvl_off_.data(); A_.ideal_counter = icounter_.data();
