@@ -2030,7 +2030,8 @@ class HipBackend : public Backend {
         const int stride = row_stride(h.K);
         std::vector<uint8_t> tmp((size_t)(count * stride));
         HIP_CK(hipMemcpy(tmp.data(), d_arena_ + h.order_off + first * stride, tmp.size(), hipMemcpyDeviceToHost));
-        for (int64_t r = 0; r < count; r++) memcpy(out + r * h.K, tmp.data() + r * stride, (size_t)h.K);
+        // (5 bits per node up to 32 nodes, a byte above: row_node unpacks either)
+        for (int64_t r = 0; r < count; r++) for (int d = 0; d < h.K; d++) out[r * h.K + d] = (uint8_t)row_node(tmp.data() + r * stride, h.K, d);
         return 0;
     }
     int copy_dag(int unit, Dag* out) override {

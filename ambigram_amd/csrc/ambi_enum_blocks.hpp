@@ -116,6 +116,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     BuildTables B;
     if (carve_build_tables(scratch, nI, nC, B) > scratch_bytes) return false;
     const int S = dir_stride(NW);
+    const int fb = row_packed(K) ? kRowNodeBits : 8;     // bits per node of a row
     uint32_t* img = reinterpret_cast<uint32_t*>(image);
     // automaton, levels and blocks-below counts as the prepare stage left them (ideal_build_and_count)
     for (int i = g.tid(); i < nI; i += g.size()) {
@@ -183,7 +184,9 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         int i = 0, d = 0;
         uint32_t rem = (uint32_t)b;
         uint64_t row = 0;
-        uint32_t w = 0, w0 = 0, w1 = 0, w2 = 0;   // word being assembled; the first three prefix words (wrap copies)
+        uint32_t w0 = 0, w1 = 0, w2 = 0;   // the first three prefix words (wrap copies)
+        RowBits rb;                        // the prefix fields, fb bits each (ambi_orders.hpp: 5 up to 32 nodes, else 8)
+        auto flush = [&](int wi, uint32_t w) { e[2 + wi] = w; if (wi == 0) w0 = w; else if (wi == 1) w1 = w; else if (wi == 2) w2 = w; };
         while (B.cnt16[i] > block_max) {
             uint64_t av = B.avail[i];
             int k = B.cbase[i];
@@ -197,22 +200,12 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
                 rem -= nb;
                 row += B.cnt64[nxt];
             }
-            w |= (uint32_t)chosen << ((d & 3) * 8);
-            if ((d & 3) == 3) {
-                const int wi = d >> 2;
-                e[2 + wi] = w;
-                if (wi == 0) w0 = w; else if (wi == 1) w1 = w; else if (wi == 2) w2 = w;
-                w = 0;
-            }
+            rb.put((uint32_t)chosen, fb, flush);
             i = nxt; d++;
         }
         {   // the partial word and the all-zero words behind the prefix
-            int wi = d >> 2;
-            if ((d & 3) != 0) {
-                e[2 + wi] = w;
-                if (wi == 0) w0 = w; else if (wi == 1) w1 = w; else if (wi == 2) w2 = w;
-                wi++;
-            }
+            int wi = rb.wi;
+            if (rb.n != 0) { flush(wi, (uint32_t)rb.acc); wi++; }
             for (; wi < NW; wi++) e[2 + wi] = 0;
         }
         e[0] = (uint32_t)row;
@@ -230,8 +223,10 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         int rr = f - (int)B.root_row[q];
         uint32_t* dst = suf + B.soff[p] + rr * NW;
         const int D = B.depth[p];
-        for (int x = 0; x < (D >> 2); x++) dst[x] = 0;
-        uint32_t w = 0;                       // word being assembled (bytes < D of word D>>2 stay zero)
+        RowBits rb;                           // fields < D stay zero
+        rb.start(D * fb);
+        for (int x = 0; x < rb.wi; x++) dst[x] = 0;
+        auto flush = [&](int wi, uint32_t w) { dst[wi] = w; };
         int j = p, d = D;
         if (K <= 32) {   // 32-bit masks (low halves of the 64-bit ones), one packed read per sibling
             const uint32_t* av32 = reinterpret_cast<const uint32_t*>(B.avail);
@@ -248,8 +243,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
                     if (rr < cc) { chosen = v; break; }
                     rr -= cc;
                 }
-                w |= (uint32_t)chosen << ((d & 3) * 8);
-                if ((d & 3) == 3) { dst[d >> 2] = w; w = 0; }
+                rb.put((uint32_t)chosen, fb, flush);
                 j = nxt;
             }
         }
@@ -266,14 +260,10 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
                 if (rr < cc) { chosen = v; break; }
                 rr -= cc;
             }
-            w |= (uint32_t)chosen << ((d & 3) * 8);
-            if ((d & 3) == 3) { dst[d >> 2] = w; w = 0; }
+            rb.put((uint32_t)chosen, fb, flush);
             j = nxt;
         }
-        for (; d < NW * 4; d++) {             // 0xFF padding behind the K nodes
-            w |= 0xFFu << ((d & 3) * 8);
-            if ((d & 3) == 3) { dst[d >> 2] = w; w = 0; }
-        }
+        rb.finish(NW, flush);                 // ones behind the K nodes
     }
     g.sync();
     clk_mark(g, clk, 30);
@@ -351,11 +341,19 @@ AMBI_HD void emit_blocks_dfs_wave(const BuildTables& B, const uint32_t* suf, int
     if (rlo >= rhi) return;
     // every lane of the wave runs this bookkeeping with identical values; the stores to the wave's own stack / pw slots
     // are the same from all of them
+    const int fb = row_packed(K) ? kRowNodeBits : 8;     // bits per node of a row (a field may straddle two words)
+    const uint32_t fmask = (1u << fb) - 1u;
+    auto put_word = [&](int wi, uint32_t w) { pw[wi] = w; if (wi < 3) pw[NW + wi] = w; };
     auto set_byte = [&](int d, uint32_t v) {
-        const int wi = d >> 2, sh = (d & 3) * 8;
-        const uint32_t w = (uniu(pw[wi]) & ~(0xFFu << sh)) | (v << sh);
-        pw[wi] = w;
-        if (wi < 3) pw[NW + wi] = w;
+        const int bit = d * fb, wi = bit >> 5, sh = bit & 31;
+        put_word(wi, (uniu(pw[wi]) & ~(fmask << sh)) | (v << sh));
+        if (sh > 32 - fb) put_word(wi + 1, (uniu(pw[wi + 1]) & ~(fmask >> (32 - sh))) | (v >> (32 - sh)));
+    };
+    auto get_byte = [&](int d) {
+        const int bit = d * fb, wi = bit >> 5, sh = bit & 31;
+        uint32_t v = uniu(pw[wi]) >> sh;
+        if (sh > 32 - fb) v |= uniu(pw[wi + 1]) << (32 - sh);
+        return (int)(v & fmask);
     };
     for (int x = 0; x < NW + 3; x++) pw[x] = 0;
     int i = 0, d = 0;
@@ -388,7 +386,7 @@ AMBI_HD void emit_blocks_dfs_wave(const BuildTables& B, const uint32_t* suf, int
         while (d > 0) {
             d--;
             const int p = uni(stack[d]);
-            const int v = (int)((uniu(pw[d >> 2]) >> ((d & 3) * 8)) & 0xFFu);           // the node taken at depth d
+            const int v = get_byte(d);                                                  // the node taken at depth d
             const uint64_t av = uniu64(B.avail[p]);
             const uint64_t rest = v >= 63 ? 0ull : (av & ~((2ull << v) - 1ull));       // nodes behind it
             if (rest) {

@@ -25,9 +25,45 @@ constexpr uint64_t kEmptyKey = ~0ull;     // K <= 63, so no ideal mask equals th
 constexpr uint64_t kCountSat = 1ull << 62;
 constexpr int kFirstRowStride = 64;       // bytes between the pre-unranked first orders of a unit (K <= 63)
 
-// Kpad: bytes per row of the order table (a multiple of 4; coarser buckets above 32 nodes keep the number of
-// enumerate-kernel instantiations small)
-AMBI_HD int row_stride(int K) { return K <= 32 ? ((K + 3) & ~3) : (K <= 48 ? 48 : (K <= 63 ? 64 : 128)); }   // (64..127 nodes: wide units, ambi_wide.hpp)
+// Row of the order table.  Up to 32 nodes: kRowNodeBits = 5 bits per node, node d in bits [5d, 5d + 5) of the row's dwords
+// (little end first: a field may straddle two dwords), the bits behind the K-th field all ones, rows a whole number of dwords --
+// 12 bytes for K = 19 where round 1-3 wrote 20.  The table is the reference's `orders` (LGM.cpp:3380-3409) in the engine's own
+// layout: nothing but the engine's kernels and ambi_batch_unit_orders (which unpacks) ever reads it, and the block emission
+// (ambi_enum_blocks.hpp) ORs prefix and suffix DWORDS, whatever the fields inside them are.  33..63 nodes: one byte per node as
+// before (48 / 64 bytes), 64..127 (wide units, ambi_wide.hpp): 128 bytes.
+constexpr int kRowNodeBits = 5;
+AMBI_HD bool row_packed(int K) { return K <= 32; }
+AMBI_HD int row_stride(int K) { return K <= 32 ? 4 * ((K * kRowNodeBits + 31) >> 5) : (K <= 48 ? 48 : (K <= 63 ? 64 : 128)); }
+// dwords of the register form of a row in the general enumerate path (one byte per node there; packed when it is stored)
+AMBI_HD int row_byte_words(int K) { return K <= 32 ? ((K + 3) >> 2) : row_stride(K) / 4; }
+// node d of a row (`row` = its first dword)
+AMBI_HD int row_node(const uint32_t* row, int K, int d) {
+    if (!row_packed(K)) return (int)reinterpret_cast<const uint8_t*>(row)[d];
+    const int bit = d * kRowNodeBits, wi = bit >> 5, sh = bit & 31;
+    uint32_t v = row[wi] >> sh;
+    if (sh > 32 - kRowNodeBits) v |= row[wi + 1] << (32 - sh);
+    return (int)(v & ((1u << kRowNodeBits) - 1u));
+}
+AMBI_HD int row_node(const uint8_t* row, int K, int d) { return row_node(reinterpret_cast<const uint32_t*>(row), K, d); }
+// appends fields to a row being assembled dword by dword
+struct RowBits {
+    uint64_t acc = 0;     // bits not yet flushed (low end first)
+    int n = 0;            // their number (< 32 after every put)
+    int wi = 0;           // dword the low end of acc belongs to
+    AMBI_HD void start(int bit) { wi = bit >> 5; n = bit & 31; acc = 0; }          // the row's bits below `bit` are zero
+    template <class F> AMBI_HD void put(uint32_t v, int bits, F&& flush) {         // flush(wi, dword) for every completed dword
+        acc |= (uint64_t)v << n;
+        n += bits;
+        if (n >= 32) { flush(wi, (uint32_t)acc); acc >>= 32; n -= 32; wi++; }
+    }
+    template <class F> AMBI_HD void finish(int total_words, F&& flush) {           // ones up to the end of the row
+        while (wi < total_words) {
+            const uint32_t ones = n >= 32 ? 0u : (0xFFFFFFFFu << n);
+            flush(wi, (uint32_t)acc | ones);
+            acc = 0; n = 0; wi++;
+        }
+    }
+};
 
 // ---- atomics usable from both builds ----
 AMBI_HD uint64_t atomic_cas_u64(uint64_t* p, uint64_t expected, uint64_t desired) {
@@ -416,6 +452,8 @@ AMBI_HD void store4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t 
 template <int NW, class AUTO>
 AMBI_HD void enumerate_rows(const AUTO& au, const AutoView& cntView, int K, uint64_t first, int nrows,
                             const LaneStacks& S, uint32_t* out) {
+    // (NW = dwords of the register form, one byte per node; `out` = this lane's first row in the table, whose rows are
+    // row_stride(K) bytes: the same for more than 32 nodes, 5 bits per node below -- packed when a row is stored)
     PackedRow<NW> row;
     row.fill(0xFFFFFFFFu);
     int top = -1;
@@ -476,6 +514,30 @@ AMBI_HD void enumerate_rows(const AUTO& au, const AutoView& cntView, int K, uint
         row.set_word(wi, cur);
         top = nt;
     };
+    if (row_packed(K)) {
+        // 5-bit fields: the general path is the rare one (units whose block image does not fit group memory), so a row is
+        // simply re-packed from its byte form when it leaves, dword by dword
+        const int onw = row_stride(K) / 4;
+        for (int r0 = 0; r0 < nrows; r0++) {
+            uint32_t p[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) p[i] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < NW * 4 && e < 32; e++) {
+                if (e < K) {
+                    const uint32_t v = (row.w[e >> 2] >> ((e & 3) * 8)) & 0x1Fu;
+                    const int bit = e * kRowNodeBits, wi = bit >> 5, sh = bit & 31;
+                    p[wi] = (p[wi] & ~(0x1Fu << sh)) | (v << sh);
+                    if (sh > 32 - kRowNodeBits) p[wi + 1] = (p[wi + 1] & ~(0x1Fu >> (32 - sh))) | (v >> (32 - sh));
+                }
+            }
+            uint32_t* dst = out + (size_t)r0 * onw;
+#pragma unroll
+            for (int k = 0; k < 5; k++) if (k < onw) dst[k] = p[k];
+            if (r0 + 1 < nrows) successor();
+        }
+        return;
+    }
     // rows leave in groups of four (4*NW dwords = NW 16-byte stores); every register index below is static
     for (int r0 = 0; r0 < nrows; r0 += 4) {
         PackedRow<NW> b0 = row, b1 = row, b2 = row, b3 = row;

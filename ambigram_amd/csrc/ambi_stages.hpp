@@ -427,7 +427,7 @@ AMBI_HD void enumerate_lane(const AUTO& au, const AutoView& V, int K, int64_t R,
     S.stride = lanes;
     S.idx = reinterpret_cast<uint16_t*>(stack_mem) + lane;
     S.prev = stack_mem + (size_t)lanes * K * 2 + lane;
-    uint32_t* out = reinterpret_cast<uint32_t*>(unit_rows + first_rank * (int64_t)(NW * 4));
+    uint32_t* out = reinterpret_cast<uint32_t*>(unit_rows + first_rank * (int64_t)row_stride(K));
     enumerate_rows<NW, AUTO>(au, V, K, (uint64_t)first_rank, (int)nrows, S, out);
 }
 
@@ -438,8 +438,9 @@ AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t r
     const int nw = row_stride(K) / 4;
     uint32_t* table = reinterpret_cast<uint32_t*>(unit_rows);
 #define AMBI_EB(N) emit_blocks_wave<N>(img, nB, rlo, rhi, table, lane_lo, lane_hi, part, parts); return;
-    if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_EB(1) case 2: AMBI_EB(2) case 3: AMBI_EB(3) case 4: AMBI_EB(4) case 5: AMBI_EB(5) default: break; } }
-    if (CLS < 0 || CLS == 1) { switch (nw) { case 6: AMBI_EB(6) case 7: AMBI_EB(7) case 8: AMBI_EB(8) default: break; } }
+    // (5 bits per node up to 32 nodes: class 0, K <= 20, has 1..4 dwords per row, class 1, K <= 32, has 4 or 5)
+    if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_EB(1) case 2: AMBI_EB(2) case 3: AMBI_EB(3) case 4: AMBI_EB(4) default: break; } }
+    if (CLS < 0 || CLS == 1) { switch (nw) { case 4: AMBI_EB(4) case 5: AMBI_EB(5) default: break; } }
     if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_EB(12) } else if (nw == 16) { AMBI_EB(16) } }
 #undef AMBI_EB
 }
@@ -449,6 +450,18 @@ AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t r
 template <class G>
 AMBI_HD void copy_first_rows(const G& g, const uint8_t* first, int K, int64_t R, uint8_t* rows) {
     const int stride = row_stride(K);
+    if (row_packed(K)) {   // one thread per row (at most first_budget = 64 of them): its dwords assembled from the row's bytes
+        uint32_t* out = reinterpret_cast<uint32_t*>(rows);
+        const int nw = stride / 4;
+        for (int64_t r = g.tid(); r < R; r += g.size()) {
+            uint32_t* dst = out + r * nw;
+            RowBits rb;
+            auto flush = [&](int wi, uint32_t w) { dst[wi] = w; };
+            for (int d = 0; d < K; d++) rb.put(first[r * kFirstRowStride + d], kRowNodeBits, flush);
+            rb.finish(nw, flush);
+        }
+        return;
+    }
     const int64_t bytes = R * stride;
     for (int64_t x = g.tid(); x < bytes; x += g.size()) {
         const int64_t r = x / stride;
@@ -464,8 +477,8 @@ AMBI_HD void emit_blocks_dfs_dispatch(const BuildTables& B, const uint32_t* suf,
     const int nw = row_stride(K) / 4;
     uint32_t* table = reinterpret_cast<uint32_t*>(unit_rows);
 #define AMBI_ED(N) emit_blocks_dfs_wave<N>(B, suf, K, block_max, rlo, rhi, table, stack, pw, lane_lo, lane_hi); return;
-    if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_ED(1) case 2: AMBI_ED(2) case 3: AMBI_ED(3) case 4: AMBI_ED(4) case 5: AMBI_ED(5) default: break; } }
-    if (CLS < 0 || CLS == 1) { switch (nw) { case 6: AMBI_ED(6) case 7: AMBI_ED(7) case 8: AMBI_ED(8) default: break; } }
+    if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_ED(1) case 2: AMBI_ED(2) case 3: AMBI_ED(3) case 4: AMBI_ED(4) default: break; } }
+    if (CLS < 0 || CLS == 1) { switch (nw) { case 4: AMBI_ED(4) case 5: AMBI_ED(5) default: break; } }
     if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_ED(12) } else if (nw == 16) { AMBI_ED(16) } }
 #undef AMBI_ED
 }
@@ -482,7 +495,7 @@ AMBI_HD int enum_class_of(int K) { return K <= 20 ? 0 : (K <= 32 ? 1 : (K <= kMa
 template <int CLS, class AUTO32, class AUTO64>
 AMBI_HD void enumerate_lane_dispatch(const AUTO32& a32, const AUTO64& a64, const AutoView& V, int K, int64_t R,
                                      int64_t first_rank, int T, uint8_t* stack_mem, int lane, int lanes, uint8_t* unit_rows) {
-    const int nw = row_stride(K) / 4;
+    const int nw = row_byte_words(K);   // (register form: one byte per node)
     if (CLS < 0 || CLS == 0) {
         switch (nw) {
             case 1: enumerate_lane<1, uint32_t>(a32, V, K, R, first_rank, T, stack_mem, lane, lanes, unit_rows); return;
@@ -596,7 +609,7 @@ AMBI_HD void stage_first(const G& g, const BatchArgs& A, int u, uint8_t* work) {
     for (int pass = 0; pass < 2 && found < 0; pass++) {
         int64_t lim = R < A.first_budget ? R : A.first_budget;
         for (int64_t nidx = 0; nidx < lim; nidx++) {
-            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * rstride + d];
+            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = A.first_rows ? rows[nidx * rstride + d] : (uint8_t)row_node(rows + nidx * rstride, K, d);
             g.sync();
             int Lo = 0;
             int v = eval_order(g, *W.dag, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, &Lo, A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
@@ -636,7 +649,7 @@ AMBI_HD int eval_indexed(const G& g, const BatchArgs& A, int u, const FirstWork&
     const UnitIn& U = A.units[u];
     const int K = out->K;
     const uint8_t* rows = A.order_arena + out->order_off;
-    for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = rows[nidx * row_stride(K) + d];
+    for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = (uint8_t)row_node(rows + nidx * row_stride(K), K, d);
     g.sync();
     InvMap inv{W.inv_src, W.inv_tgt};
     const int v = eval_order_w(g, W, W.ord, forwardDir, inv, W.bkp, U.bkp_cap, L);
@@ -749,7 +762,7 @@ AMBI_HD void stage_all_chunk(const G& g, const BatchArgs& A, int u, const FirstW
         const uint8_t* ord = rows + (int64_t)i * kFirstRowStride;
         if (wide) {
             const uint8_t* trow = A.order_arena + out->order_off + (first + i) * row_stride(K);
-            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = trow[d];
+            for (int d = g.tid(); d < K; d += g.size()) W.ord[d] = (uint8_t)row_node(trow, K, d);
             g.sync();
             ord = W.ord;
         }
@@ -787,7 +800,7 @@ AMBI_HD void stage_all_chunk_lanes(const G& g, const BatchArgs& A, int u, const 
         if (i < cnt) {
             if (A.all_rows_from_table && out->order_off >= 0) {   // experiment switch: the orders from the table the enumerate kernel wrote
                 const uint8_t* row = A.order_arena + out->order_off + (first + i) * row_stride(K);
-                for (int d = 0; d < K; d++) rows_t[d * 64 + i] = row[d];
+                for (int d = 0; d < K; d++) rows_t[d * 64 + i] = (uint8_t)row_node(row, K, d);
             } else
                 (void)order_unrank(V, K, (uint64_t)(first + i), rows_t + i, 64);
             int L = 0;

@@ -415,7 +415,7 @@ class HostSimBackend : public Backend {
         if (h->order_off < 0 || first < 0 || first + count > h->num_orders) return ST_ERR_BAD_INPUT;
         const int stride = row_stride(h->K);
         for (int64_t r = 0; r < count; r++)
-            memcpy(out + r * h->K, arena_.data() + h->order_off + (first + r) * stride, (size_t)h->K);
+            for (int d = 0; d < h->K; d++) out[r * h->K + d] = (uint8_t)row_node(arena_.data() + h->order_off + (first + r) * stride, h->K, d);
         return 0;
     }
     int copy_dag(int unit, Dag* out) override { *out = dags_[unit]; return 0; }
