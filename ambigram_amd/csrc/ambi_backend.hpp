@@ -15,7 +15,7 @@ struct EngineConfig {
     int32_t first_budget = 64;
     int32_t block_lds = 49152;       // LDS bytes per workgroup for a unit's block-emission image (env AMBI_BLOCK_LDS overrides)
     int32_t block_scratch_lds = 16384;   // LDS of the image-build kernel (automaton copy; env AMBI_BLOCK_SCRATCH_LDS overrides)
-    int32_t block_max = 128;         // largest suffix block in rows (env AMBI_BLOCK_MAX overrides; 128 / 192 / 256 / 320 measure the same on one box, profiles/r01_slices.md; an image that does not fit the LDS budget sends the unit down the general path)
+    int32_t block_max = 256;         // largest suffix block in rows (env AMBI_BLOCK_MAX overrides; rows of a byte per node: 128 / 192 / 256 / 320 measure the same, profiles/r01_slices.md; 5-bit rows: 64 / 96 / 128 / 192 / 256 / 320 / 384 / 512 = 1.47 / 1.01 / 0.918 / 0.92 / 0.900 / 0.903 / 0.914 / 1.00 ms per step, profiles/r03_notes.md; an image that does not fit the LDS budget sends the unit down the general path)
     int32_t target_lanes = 524288;   // enumerate kernel: rows of the batch are spread over about this many lanes
     int32_t slices = 0;              // unit ranges run on separate streams (0: automatic; env AMBI_SLICES overrides)
 };

@@ -207,12 +207,16 @@ def main():
     n, m = args.segs, None
     per_kernel = {"ambi_prepare_kernel": 0, "ambi_plan_kernel": 0, "ambi_blocks_build_kernel": 0, "ambi_enumerate_kernel": 0, "ambi_first_kernel": 0, "ambi_finish_kernel": 0}
     formula = 0
+    stored_table_bytes = 0      # what the order tables occupy in the engine's own row layout (5 bits per node up to 32 nodes, csrc/ambi_orders.hpp)
+    def row_bytes(K):
+        return 4 * ((5 * K + 31) // 32) if K <= 32 else (48 if K <= 48 else (64 if K <= 63 else 128))
     for u, r in enumerate(res):
         mj = graphs[u].n_junc
         K, R, E, L, P, P2 = r["n_nodes"], r["num_orders"], r["evaluated"], r["bkp_len"], r["path_len"], r["path_indel_len"]
         per_kernel["ambi_prepare_kernel"] += 8 * n + 24 * mj + 16 * K
         per_kernel["ambi_plan_kernel"] += 64
-        per_kernel["ambi_enumerate_kernel"] += R * K                 # every order written once
+        per_kernel["ambi_enumerate_kernel"] += R * K                 # every order written once (one byte per node)
+        stored_table_bytes += R * row_bytes(K)
         per_kernel["ambi_first_kernel"] += E * K + 2 * E * L         # orders read until the first valid one, bkp written
         # bkp read, path written; the path after indelBFB is written only when indelBFB changed it
         per_kernel["ambi_finish_kernel"] += 2 * L + 4 * P + (4 * P2 if r["path_indel_stored"] else 0)
@@ -236,9 +240,15 @@ def main():
                 step_traffic = tj.get("hbm_bytes_per_step_all_kernels")
         except Exception:
             traffic = None
+    stored = (stored_table_bytes / slices) if dom == "ambi_enumerate_kernel" else None
+    stored_rate = stored / (dom_ms * 1e-3) / 1e9 if stored and dom_ms and dom_ms > 0 else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": dom_ms, "launches_per_step": slices,
+                # the same launch counted in the bytes the table really has: the engine stores a row at 5 bits per node (12 bytes at
+                # K = 19 where SURVEY 8d's algorithmic figure, used for `achieved`, counts 19), so `traffic` is BELOW the algorithmic bytes
+                "stored_bytes_per_launch": stored, "stored_GBps": stored_rate, "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
+                "row_layout": "5 bits per node up to 32 nodes (lossless; ambi_batch_unit_orders unpacks), one byte per node above",
                 "all_kernels_ms": ktimes, "all_kernels_note": "%s: HIP events over the timed steps; the other kernels: over the warm-up steps" % dom,
                 "step_hbm_bytes_pmc": step_traffic,
                 "step_hbm_GBps_pmc": (step_traffic / (dt / args.steps) / 1e9) if step_traffic else None}
