@@ -1261,8 +1261,8 @@ class HipBackend : public Backend {
                     // the direct full-finish stream: default priority, or the lowest (AMBI_FULL_PRIORITY=1: a few per cent on some
                     // boxes).  The stream belongs to the lease and is never destroyed -- with round 2's per-batch create / destroy of
                     // this priority stream a long soak showed stray writes into host memory.
-                    const char* e9 = getenv("AMBI_FULL_PRIORITY"); const bool low_full = e9 ? atoi(e9) != 0 : false;
-                    if ((rc = lease_stream(L, 1, low_full ? 1 : 0, &full_stream_))) return rc;
+                    const char* e9 = getenv("AMBI_FULL_PRIORITY"); const int fp = e9 ? atoi(e9) : 0;   // 0 default, 1 lowest, 2 highest priority
+                    if ((rc = lease_stream(L, 1, fp == 1 ? 1 : (fp == 2 ? 2 : 0), &full_stream_))) return rc;
                     if (direct_ext_) lds_finish_ext_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, 0, H.max_out);
                 }
             }
