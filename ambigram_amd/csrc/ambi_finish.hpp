@@ -201,10 +201,17 @@ AMBI_HD int indel_bfb(const G& g, int n, const JuncEnds* ends, int m, cell_t* pa
     auto rebuild_tables = [&]() {
         for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { S.first[i] = 0x7fffffff; S.last[i] = -1; }
         g.sync();
-        for (int i = g.tid(); i < P; i += g.size()) {
-            int v = path[i] + n;
-            atomic_min_i32(&S.first[v], i);
-            atomic_max_i32(&S.last[v], i);
+        // eight cells per thread and round: their loads are issued together (the path may live in device memory, the direct
+        // full-finish launch: one round trip per CELL made a rebuild ~15 k cycles, and every edit is followed by one)
+        for (int base = 0; base < P; base += 8 * g.size()) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int i = base + k * g.size() + g.tid(); v[k] = i < P ? (int)path[i] : 0; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = base + k * g.size() + g.tid();
+                if (i < P) { atomic_min_i32(&S.first[v[k] + n], i); atomic_max_i32(&S.last[v[k] + n], i); }
+            }
         }
         g.sync();
     };
