@@ -352,6 +352,15 @@ def main():
     if args.single_reps > 0 and world == 1:
         one = api.Batch(lib)
         one.add_chromosome_sol(graphs[0], 0, files[0][1][0])
+        # The one-sample batch runs on a stream of the caller's own, not on the legacy default stream: its implicit ordering
+        # against every other blocking stream costs ~10 us per run (profiles/tools/stream_latency.py: 102 us end to end on the
+        # default stream, 88 on a stream of one's own; AMBI_BENCH_STREAM=default measures on the default stream).  The 4096-sample
+        # legs stay on the default stream: a further stream created BEFORE the engine's own changes which of them share a hardware
+        # queue (1.36 instead of 0.87 ms per step, profiles/r03_notes.md).
+        batch_stream = stream
+        if os.environ.get("AMBI_BENCH_STREAM") != "default":
+            own_stream = torch.cuda.Stream()
+            stream = own_stream.cuda_stream
         one.upload()
         one.run(0, stream); one.wait()
         for _ in range(10):
@@ -435,6 +444,8 @@ def main():
             if single.get("e2e_ms_c_caller"):
                 single["e2e_speedup_c_caller"] = best * 1e3 / single["e2e_ms_c_caller"]
             single["cpu_kind"] = "port (oracle, 1 core, best of 5)"
+        single["stream"] = "a stream of the caller's own" if stream != batch_stream else "default stream"
+        stream = batch_stream
 
     # ---- the step WITH the ILP assembly ("reported twice").  BFB_ILP (LGM.cpp:4397-4752) is where the
     # reference spends its non-solver time (O(n * numPat^2) coefficient loop, 313 s at 256 segments);
