@@ -57,8 +57,10 @@ constexpr bool small_div_exact() {
         if (small_div<N>(x) != x / N || small_mod<N>(x) != x % N) return false;
     return true;
 }
-static_assert(small_div_exact<3>() && small_div_exact<5>() && small_div_exact<6>() && small_div_exact<7>() && small_div_exact<12>(),
-              "small_div must be exact over the in-block offset range");
+static_assert(small_div_exact<3>() && small_div_exact<5>() && small_div_exact<6>(), "small_div must be exact over the in-block offset range");
+static_assert(small_div_exact<7>() && small_div_exact<9>(), "small_div must be exact over the in-block offset range");
+static_assert(small_div_exact<10>() && small_div_exact<11>(), "small_div must be exact over the in-block offset range");
+static_assert(small_div_exact<12>(), "small_div must be exact over the in-block offset range");
 
 // header of a unit's image, kept in HBM (BatchArgs::block_hdr, 8 ints per unit)
 struct BlockImageHeader { int32_t fits, nB, suf_words, image_bytes, nI, nC, block_max, pad; };
@@ -116,7 +118,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     BuildTables B;
     if (carve_build_tables(scratch, nI, nC, B) > scratch_bytes) return false;
     const int S = dir_stride(NW);
-    const int fb = row_packed(K) ? kRowNodeBits : 8;     // bits per node of a row
+    const int fb = row_bits(K);     // bits per node of a row
     uint32_t* img = reinterpret_cast<uint32_t*>(image);
     // automaton, levels and blocks-below counts as the prepare stage left them (ideal_build_and_count)
     for (int i = g.tid(); i < nI; i += g.size()) {
@@ -341,7 +343,7 @@ AMBI_HD void emit_blocks_dfs_wave(const BuildTables& B, const uint32_t* suf, int
     if (rlo >= rhi) return;
     // every lane of the wave runs this bookkeeping with identical values; the stores to the wave's own stack / pw slots
     // are the same from all of them
-    const int fb = row_packed(K) ? kRowNodeBits : 8;     // bits per node of a row (a field may straddle two words)
+    const int fb = row_bits(K);     // bits per node of a row (a field may straddle two words)
     const uint32_t fmask = (1u << fb) - 1u;
     auto put_word = [&](int wi, uint32_t w) { pw[wi] = w; if (wi < 3) pw[NW + wi] = w; };
     auto set_byte = [&](int d, uint32_t v) {

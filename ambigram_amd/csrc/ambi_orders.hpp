@@ -25,24 +25,24 @@ constexpr uint64_t kEmptyKey = ~0ull;     // K <= 63, so no ideal mask equals th
 constexpr uint64_t kCountSat = 1ull << 62;
 constexpr int kFirstRowStride = 64;       // bytes between the pre-unranked first orders of a unit (K <= 63)
 
-// Row of the order table.  Up to 32 nodes: kRowNodeBits = 5 bits per node, node d in bits [5d, 5d + 5) of the row's dwords
-// (little end first: a field may straddle two dwords), the bits behind the K-th field all ones, rows a whole number of dwords --
-// 12 bytes for K = 19 where round 1-3 wrote 20.  The table is the reference's `orders` (LGM.cpp:3380-3409) in the engine's own
-// layout: nothing but the engine's kernels and ambi_batch_unit_orders (which unpacks) ever reads it, and the block emission
-// (ambi_enum_blocks.hpp) ORs prefix and suffix DWORDS, whatever the fields inside them are.  33..63 nodes: one byte per node as
-// before (48 / 64 bytes), 64..127 (wide units, ambi_wide.hpp): 128 bytes.
-constexpr int kRowNodeBits = 5;
-AMBI_HD bool row_packed(int K) { return K <= 32; }
-AMBI_HD int row_stride(int K) { return K <= 32 ? 4 * ((K * kRowNodeBits + 31) >> 5) : (K <= 48 ? 48 : (K <= 63 ? 64 : 128)); }
+// Row of the order table.  row_bits(K) bits per node -- 5 up to 32 nodes, 6 up to 63 -- node d in bits [d * bits, (d + 1) * bits) of
+// the row's dwords (little end first: a field may straddle two dwords), the bits behind the K-th field all ones, rows a whole
+// number of dwords: 12 bytes for K = 19 where rounds 1-3 wrote 20, 32 for K = 41 instead of 48.  The table is the reference's
+// `orders` (LGM.cpp:3380-3409) in the engine's own layout: nothing but the engine's kernels and ambi_batch_unit_orders (which
+// unpacks) ever reads it, and the block emission (ambi_enum_blocks.hpp) ORs prefix and suffix DWORDS, whatever the fields inside
+// them are.  64..127 nodes (wide units, ambi_wide.hpp): one byte per node, 128 bytes.
+AMBI_HD int row_bits(int K) { return K <= 32 ? 5 : (K <= 63 ? 6 : 8); }
+AMBI_HD bool row_packed(int K) { return K <= 63; }
+AMBI_HD int row_stride(int K) { return K <= 63 ? 4 * ((K * row_bits(K) + 31) >> 5) : 128; }
 // dwords of the register form of a row in the general enumerate path (one byte per node there; packed when it is stored)
-AMBI_HD int row_byte_words(int K) { return K <= 32 ? ((K + 3) >> 2) : row_stride(K) / 4; }
+AMBI_HD int row_byte_words(int K) { return K <= 32 ? ((K + 3) >> 2) : (K <= 48 ? 12 : (K <= 63 ? 16 : 32)); }
 // node d of a row (`row` = its first dword)
 AMBI_HD int row_node(const uint32_t* row, int K, int d) {
     if (!row_packed(K)) return (int)reinterpret_cast<const uint8_t*>(row)[d];
-    const int bit = d * kRowNodeBits, wi = bit >> 5, sh = bit & 31;
+    const int fb = row_bits(K), bit = d * fb, wi = bit >> 5, sh = bit & 31;
     uint32_t v = row[wi] >> sh;
-    if (sh > 32 - kRowNodeBits) v |= row[wi + 1] << (32 - sh);
-    return (int)(v & ((1u << kRowNodeBits) - 1u));
+    if (sh > 32 - fb) v |= row[wi + 1] << (32 - sh);
+    return (int)(v & ((1u << fb) - 1u));
 }
 AMBI_HD int row_node(const uint8_t* row, int K, int d) { return row_node(reinterpret_cast<const uint32_t*>(row), K, d); }
 // appends fields to a row being assembled dword by dword
@@ -515,25 +515,28 @@ AMBI_HD void enumerate_rows(const AUTO& au, const AutoView& cntView, int K, uint
         top = nt;
     };
     if (row_packed(K)) {
-        // 5-bit fields: the general path is the rare one (units whose block image does not fit group memory), so a row is
+        // packed fields: the general path is the rare one (units whose block image does not fit group memory), so a row is
         // simply re-packed from its byte form when it leaves, dword by dword
         const int onw = row_stride(K) / 4;
+        constexpr int fb = NW <= 8 ? 5 : 6;         // (NW <= 8 <=> up to 32 nodes: row_bits(K), as a constant of the instantiation)
+        constexpr uint32_t fmask = (1u << fb) - 1u;
+        constexpr int kPW = NW <= 8 ? 6 : 13;      // packed dwords (+1 for the straddle of the last field): 5 up to 32 nodes, 12 up to 63
         for (int r0 = 0; r0 < nrows; r0++) {
-            uint32_t p[6];
+            uint32_t p[kPW];
 #pragma unroll
-            for (int i = 0; i < 6; i++) p[i] = 0xFFFFFFFFu;
+            for (int i = 0; i < kPW; i++) p[i] = 0xFFFFFFFFu;
 #pragma unroll
-            for (int e = 0; e < NW * 4 && e < 32; e++) {
+            for (int e = 0; e < NW * 4 && e < 64; e++) {
                 if (e < K) {
-                    const uint32_t v = (row.w[e >> 2] >> ((e & 3) * 8)) & 0x1Fu;
-                    const int bit = e * kRowNodeBits, wi = bit >> 5, sh = bit & 31;
-                    p[wi] = (p[wi] & ~(0x1Fu << sh)) | (v << sh);
-                    if (sh > 32 - kRowNodeBits) p[wi + 1] = (p[wi + 1] & ~(0x1Fu >> (32 - sh))) | (v >> (32 - sh));
+                    const uint32_t v = (row.w[e >> 2] >> ((e & 3) * 8)) & fmask;
+                    const int bit = e * fb, wi = bit >> 5, sh = bit & 31;      // (constants once the loop is unrolled)
+                    p[wi] = (p[wi] & ~(fmask << sh)) | (v << sh);
+                    if (sh > 32 - fb) p[wi + 1] = (p[wi + 1] & ~(fmask >> (32 - sh))) | (v >> (32 - sh));
                 }
             }
             uint32_t* dst = out + (size_t)r0 * onw;
 #pragma unroll
-            for (int k = 0; k < 5; k++) if (k < onw) dst[k] = p[k];
+            for (int k = 0; k < kPW - 1; k++) if (k < onw) dst[k] = p[k];
             if (r0 + 1 < nrows) successor();
         }
         return;

@@ -441,7 +441,7 @@ AMBI_HD void emit_blocks_dispatch(const uint32_t* img, int nB, int K, uint32_t r
     // (5 bits per node up to 32 nodes: class 0, K <= 20, has 1..4 dwords per row, class 1, K <= 32, has 4 or 5)
     if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_EB(1) case 2: AMBI_EB(2) case 3: AMBI_EB(3) case 4: AMBI_EB(4) default: break; } }
     if (CLS < 0 || CLS == 1) { switch (nw) { case 4: AMBI_EB(4) case 5: AMBI_EB(5) default: break; } }
-    if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_EB(12) } else if (nw == 16) { AMBI_EB(16) } }
+    if (CLS < 0 || CLS == 2) { switch (nw) { case 7: AMBI_EB(7) case 8: AMBI_EB(8) case 9: AMBI_EB(9) case 10: AMBI_EB(10) case 11: AMBI_EB(11) case 12: AMBI_EB(12) default: break; } }   // (6 bits per node, 33..63 nodes)
 #undef AMBI_EB
 }
 
@@ -457,7 +457,7 @@ AMBI_HD void copy_first_rows(const G& g, const uint8_t* first, int K, int64_t R,
             uint32_t* dst = out + r * nw;
             RowBits rb;
             auto flush = [&](int wi, uint32_t w) { dst[wi] = w; };
-            for (int d = 0; d < K; d++) rb.put(first[r * kFirstRowStride + d], kRowNodeBits, flush);
+            for (int d = 0; d < K; d++) rb.put(first[r * kFirstRowStride + d], row_bits(K), flush);
             rb.finish(nw, flush);
         }
         return;
@@ -479,7 +479,7 @@ AMBI_HD void emit_blocks_dfs_dispatch(const BuildTables& B, const uint32_t* suf,
 #define AMBI_ED(N) emit_blocks_dfs_wave<N>(B, suf, K, block_max, rlo, rhi, table, stack, pw, lane_lo, lane_hi); return;
     if (CLS < 0 || CLS == 0) { switch (nw) { case 1: AMBI_ED(1) case 2: AMBI_ED(2) case 3: AMBI_ED(3) case 4: AMBI_ED(4) default: break; } }
     if (CLS < 0 || CLS == 1) { switch (nw) { case 4: AMBI_ED(4) case 5: AMBI_ED(5) default: break; } }
-    if (CLS < 0 || CLS == 2) { if (nw == 12) { AMBI_ED(12) } else if (nw == 16) { AMBI_ED(16) } }
+    if (CLS < 0 || CLS == 2) { switch (nw) { case 7: AMBI_ED(7) case 8: AMBI_ED(8) case 9: AMBI_ED(9) case 10: AMBI_ED(10) case 11: AMBI_ED(11) case 12: AMBI_ED(12) default: break; } }
 #undef AMBI_ED
 }
 // group memory of the walk per wave: the ideals of the current path + prefix words with wrap copies

@@ -209,7 +209,7 @@ def main():
     formula = 0
     stored_table_bytes = 0      # what the order tables occupy in the engine's own row layout (5 bits per node up to 32 nodes, csrc/ambi_orders.hpp)
     def row_bytes(K):
-        return 4 * ((5 * K + 31) // 32) if K <= 32 else (48 if K <= 48 else (64 if K <= 63 else 128))
+        return 4 * ((5 * K + 31) // 32) if K <= 32 else (4 * ((6 * K + 31) // 32) if K <= 63 else 128)
     for u, r in enumerate(res):
         mj = graphs[u].n_junc
         K, R, E, L, P, P2 = r["n_nodes"], r["num_orders"], r["evaluated"], r["bkp_len"], r["path_len"], r["path_indel_len"]
@@ -248,7 +248,7 @@ def main():
                 # the same launch counted in the bytes the table really has: the engine stores a row at 5 bits per node (12 bytes at
                 # K = 19 where SURVEY 8d's algorithmic figure, used for `achieved`, counts 19), so `traffic` is BELOW the algorithmic bytes
                 "stored_bytes_per_launch": stored, "stored_GBps": stored_rate, "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
-                "row_layout": "5 bits per node up to 32 nodes (lossless; ambi_batch_unit_orders unpacks), one byte per node above",
+                "row_layout": "5 bits per node up to 32 nodes, 6 up to 63 (lossless; ambi_batch_unit_orders unpacks), one byte per node above",
                 "all_kernels_ms": ktimes, "all_kernels_note": "%s: HIP events over the timed steps; the other kernels: over the warm-up steps" % dom,
                 "step_hbm_bytes_pmc": step_traffic,
                 "step_hbm_GBps_pmc": (step_traffic / (dt / args.steps) / 1e9) if step_traffic else None}
