@@ -257,7 +257,9 @@ int ambi_batch_all_paths(ambi_batch_t* b, int32_t unit, int32_t pass, int64_t fi
 int ambi_batch_all_set_shard(ambi_batch_t* b, int32_t rank, int32_t world);
 int ambi_batch_all_device(ambi_batch_t* b, void** ptr, int64_t* bytes);
 int ambi_batch_all_finish(ambi_batch_t* b);
-/* Copies rows [first,first+count) of the unit's order table (count x K uint8) from the device. */
+/* Rows [first,first+count) of the unit's order table -- the reference's `orders` (LocalGenomicMap.cpp:3380-3409), row r = the r-th
+ * topological order it pushes -- as count x K uint8 node ids.  (On the device a row holds 5 bits per node up to 32 nodes, 6 up to 63,
+ * a byte above; this call unpacks.) */
 int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t count, uint8_t* out);
 
 /* Per-kernel timing (HIP events on the streams the kernels are launched on, milliseconds): the average duration of
