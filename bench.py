@@ -503,7 +503,7 @@ def main():
         "metric": "BFB reconstructions/sec (synthetic .lh, 256 seg) at 1/2/4/8 MI355X",
         "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8/int16 (order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
+        "dtype": "u8/int16 (node ids, stored as 5-bit fields of the order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
         "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, %s; every %s sample carries 2 deletions + 1 duplication that edit the path (full finish stage); %d samples per GPU resident in HBM"
                                % (args.segs, args.juncs, args.tier, args.K, "--all mode" if args.mode == "all" else "default CLI mode",
                                   ("%d-th" % args.sv_every) if args.sv_every > 0 else "no", B),
