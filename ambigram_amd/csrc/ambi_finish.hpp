@@ -494,6 +494,13 @@ AMBI_HD int synth_out_juncs(const G& g, const cell_t* path, int P, OutJunc* out,
         cand[c] = pack_step(path[pos], path[pos + 1]);
     }
     g.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (G::kIsBlock && nc <= 256) {   // few steps: one wavefront goes through the phases of the tail without workgroup barriers (as the lean stage does)
+        int v = 0;
+        if (g.tid() < 64) { WaveGroup w; v = synth_classes(w, cand, nc, out, cap, seg_base); }
+        return g.bcast_i32(v, 0);
+    }
+#endif
     return synth_classes(g, cand, nc, out, cap, seg_base);
 }
 
