@@ -1501,8 +1501,10 @@ class HipBackend : public Backend {
         // order-table bytes of the previous run at the rate the enumerate kernel reaches: an optimistic 5.2 TB/s for rows of a byte
         // per node; rows of 5 bits per node (up to 32 nodes) leave at ~3.5 TB/s -- fewer bytes per row for the same work per row
         // (measured on the bench batch, 12-byte rows: 160 / 176 / 192 / 208 / 240 / 272 workgroups = 0.92-0.93 / 0.916-0.938 /
-        // 0.903-0.919 / 0.914-0.933 / 0.93-0.94 / 0.95 ms per step; this rule gives 184 -> 192)
-        const double enum_us = (double)last_needed_ / ((enum_classes_ & 3) ? 3.5e6 : 5.2e6);
+        // 0.903-0.919 / 0.914-0.933 / 0.93-0.94 / 0.95 ms per step with the 16-byte-group emission; with one row per lane the
+        // table is done earlier and the finish kernels want more room: 192 / 208 / 224 / 256 / 288 = 0.887 / 0.864 / 0.857 / 0.876 /
+        // 0.885 (means of 3-6 runs, the build before: 0.867); this rule gives 210 -> 224)
+        const double enum_us = (double)last_needed_ / ((enum_classes_ & 3) ? 4.1e6 : 5.2e6);
         const double unit_us = 4.0 + avg_path_ / 900.0 + hb().max_m / 64.0;          // one unit through the lean finish stage (mean path capacity of the batch)
         if (enum_us < 8.0 * unit_us) return U;
         // (measured with the SV-carrying bench batch, 40 KB images: 160 / 192 / 256 / 320 workgroups = 1.24 / 1.17 / 1.20 / 1.24 ms

@@ -24,6 +24,7 @@
 
 namespace ambi {
 
+constexpr bool kEmitRows = true;     // narrow rows leave one row per lane (emit_piece_rows); false: the 16-byte-group form for every width
 constexpr int kBlockMaxLimit = 1024;   // upper bound of BatchArgs::block_max (keeps in-block dword offsets < 2^15)
 
 // wave-uniform value: broadcast lane 0's copy so that the compiler keeps it in scalar registers
@@ -276,9 +277,36 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
 // One piece of the table: rows [cur, end) of the block whose first row is r0, whose suffix rows start at dword `so` of
 // `suf` and whose prefix words (with three wrap copies) are pp[0 .. NW+2].  lane_lo/lane_hi: the lanes this call
 // stands for ([lane, lane+1) on the GPU, [0, 64) in the host simulation).
+// Narrow rows (up to five dwords: the packed rows of up to 32 nodes): one ROW per lane and step instead of one 16-byte group --
+// the prefix words are the same for every row of the piece and stay in registers, a row is NW suffix dwords ORed with them and
+// stored as one NW-dword store; consecutive lanes write consecutive rows, so a wavefront's store covers 64 * 4 NW contiguous bytes.
+template <int NW>
+AMBI_HD void emit_piece_rows(const uint32_t* suf, uint32_t so, uint32_t r0, uint32_t cur, uint32_t end, const uint32_t* pp, uint32_t* table,
+                             int lane_lo, int lane_hi) {
+    uint32_t pw[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) pw[w] = pp[w];
+    const uint32_t* sp = suf + so + (cur - r0) * NW;
+    uint32_t* out = table + (int64_t)cur * NW;
+    const int n = (int)(end - cur);
+    for (int base = 0; base < n; base += 64) {
+        for (int lane = lane_lo; lane < lane_hi; lane++) {
+            const int r = base + lane;
+            if (r < n) {
+                uint32_t v[NW];
+#pragma unroll
+                for (int w = 0; w < NW; w++) v[w] = sp[r * NW + w] | pw[w];
+#pragma unroll
+                for (int w = 0; w < NW; w++) out[r * NW + w] = v[w];
+            }
+        }
+    }
+}
+
 template <int NW>
 AMBI_HD void emit_piece(const uint32_t* suf, uint32_t so, uint32_t r0, uint32_t cur, uint32_t end, const uint32_t* pp, uint32_t* table,
                         int lane_lo, int lane_hi) {
+    if constexpr (NW <= 5) { if (kEmitRows) { emit_piece_rows<NW>(suf, so, r0, cur, end, pp, table, lane_lo, lane_hi); return; } }
     const int n = (int)(end - cur) * NW;                 // dwords of this piece (starts at a row boundary)
     const int64_t g0 = (int64_t)cur * NW;
     int head = (int)((-g0) & 3); if (head > n) head = n;   // dwords before the first 16-byte boundary
