@@ -201,6 +201,7 @@ int ambi_batch_create(ambi_batch_t** out) {
 }
 // AMBI_DEBUG_QUARANTINE=1 (diagnostics): destroyed batches are not returned to the allocator but filled with a pattern and
 // checked at every later destroy -- a write into a destroyed batch or backend object shows up with its offset.
+extern "C++" {
 namespace {
 struct Quarantined { unsigned char* p; size_t n; const char* what; };
 std::vector<Quarantined>& quarantine() { static std::vector<Quarantined> q; return q; }
@@ -210,6 +211,7 @@ void check_quarantine() {
             if (q.p[i] != 0xAB) { fprintf(stderr, "ambigram_hip QUARANTINE: destroyed %s object %p modified at offset %zu: 0x%02x\n", q.what, (void*)q.p, i, q.p[i]); q.p[i] = 0xAB; }
 }
 }  // namespace
+}  // extern "C++"
 void ambi_batch_destroy(ambi_batch_t* b) {
     static const bool quarantine_on = getenv("AMBI_DEBUG_QUARANTINE") != nullptr;
     if (!quarantine_on || !b) { delete b; return; }
@@ -332,7 +334,9 @@ int ambi_batch_run_sharded(ambi_batch_t* b, uint32_t flags, const int32_t* devic
         for (int d = 0; d < n; d++) devs.push_back(d);
     }
     const int N = (int)devs.size(), U = (int)b->hb.units.size();
-    bool same = (int)b->shards.size() == N;
+    // the shares of an earlier call are kept (inputs resident on their devices) only for the same devices AND the same units:
+    // units added since then (ambi_batch_add_* stays open on a sharded batch) mean new shares
+    bool same = (int)b->shards.size() == N && (int)b->where.size() == U;
     for (int k = 0; same && k < N; k++) same = b->shards[k]->device == devs[k];
     if (!same) {
         b->shards.clear(); b->where.assign(U, {0, 0});
@@ -346,7 +350,7 @@ int ambi_batch_run_sharded(ambi_batch_t* b, uint32_t flags, const int32_t* devic
         for (int u = 0; u < U; u++) {
             Shard& s = *b->shards[u % N];
             int l = s.hb.add_unit_from(b->hb, u);
-            if (l < 0) return l;
+            if (l < 0) { b->shards.clear(); b->where.clear(); return l; }   // no half-dealt shares for the next call to find
             s.units.push_back(u);
             b->where[u] = {u % N, l};
         }
@@ -362,9 +366,10 @@ int ambi_batch_run_sharded(ambi_batch_t* b, uint32_t flags, const int32_t* devic
         if ((s->rc = s->be->run(flags, nullptr))) return;
         s->rc = s->be->download(s->blob);
     };
+    // every share on a thread of its own, the first one too: set_device changes the current device of the thread that calls
+    // it, and the caller's thread keeps the device it had
     std::vector<std::thread> threads;
-    for (int k = 1; k < N; k++) threads.emplace_back(work, b->shards[k].get());
-    work(b->shards[0].get());
+    for (int k = 0; k < N; k++) threads.emplace_back(work, b->shards[k].get());
     for (auto& t : threads) t.join();
     for (auto& s : b->shards) if (s->rc) return s->rc;
     // merge: the header and the variable part of every unit go where a single-device download would have put them

@@ -474,13 +474,14 @@ __global__ __launch_bounds__(256) void ambi_enumerate_wide_kernel(BatchArgs A, c
     const int w = blockIdx.y;
     if (w >= n_wide) return;
     const int u = wide_units[w];
+    if (u < A.unit_base || u >= A.unit_base + A.n_units) return;   // another slice's unit (its WideUnit may be being rebuilt right now)
     const UnitOut* out = unit_out(A.results, u);
     if (out->order_off < 0 || out->num_orders <= 0) return;
     const WideUnit& X = A.wide[A.wide_index[u]];
     const int K = out->K, stride = row_stride(K);
     uint8_t* rows = A.order_arena + out->order_off;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < out->num_orders; r += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t row[128];
+        alignas(16) uint8_t row[128];
         unrank_wide(X, (uint64_t)r, row);
         for (int d = K; d < stride; d++) row[d] = 0xFF;
         uint4* dst = reinterpret_cast<uint4*>(rows + r * stride);
@@ -933,6 +934,18 @@ struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
+// Every backend entry that touches the GPU runs on the device of the batch's lease, whatever device the calling thread has
+// current (a batch dealt over several devices answers its per-unit getters from the device that holds the unit; a host
+// program working on another device finds its current device unchanged afterwards).  dev < 0: nothing to select.
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0 || hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete; DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // ------------------------------------------------------------------------------------------------
 // backend
@@ -949,6 +962,7 @@ class HipBackend : public Backend {
     uint32_t timing_mask_ = ~0u;   // kernels that get events (bit = kernel index)
     hipStream_t stream_ = nullptr;
     Lease* lease_ = nullptr;
+    int device_ = -1;                  // the device of the lease (set at upload): every entry below selects it for its duration
     // device buffers: all carved from ONE block of the lease (layout()); inputs first, in the order of the staging image
     UnitIn* d_units_ = nullptr; double* d_seg_cn_ = nullptr; double* d_junc_cn_ = nullptr; JuncEnds* d_junc_ends_ = nullptr; Element* d_elems_ = nullptr;
     Dag* d_dags_ = nullptr; uint8_t* d_results_ = nullptr;
@@ -1064,6 +1078,7 @@ class HipBackend : public Backend {
         return bad;
     }
     void free_all() {
+        DeviceGuard dg_(device_);
         sync_all();
         (void)check_guards("release");
         // per-batch allocations outside the lease's blocks (--all bitmaps, stage profile)
@@ -1084,6 +1099,7 @@ class HipBackend : public Backend {
         }
         stage_big_.clear(); stage_big_.shrink_to_fit();
         mail_valid_ = false;
+        device_ = -1;
     }
 
     // Layout of the device block: [inputs, in the order of the staging image] [zero-filled: result blob, image headers, flags,
@@ -1153,6 +1169,7 @@ class HipBackend : public Backend {
         debug_ = getenv("AMBI_DEBUG") != nullptr;
         if ((rc = DevicePool::get().acquire(&lease_))) return rc;
         Lease* L = lease_;
+        device_ = L->device;
         h_npending_ = &L->h_words->npending; h_needed_ = L->h_words->needed;
         dh_npending_ = &L->dh_words->npending; dh_needed_ = L->dh_words->needed;
         h_express_left_ = &L->h_words->express_left; dh_express_left_ = &L->dh_words->express_left;
@@ -1193,7 +1210,6 @@ class HipBackend : public Backend {
             static std::mutex mu; static uint64_t done = 0; hipError_t err = hipSuccess;   // (per device: one bit each)
             std::lock_guard<std::mutex> lk(mu);
             if (!((done >> (L->device & 63)) & 1ull)) {
-                done |= 1ull << (L->device & 63);
                 const void* fns[] = {(const void*)ambi_blocks_build_kernel, (const void*)ambi_prepare_kernel, (const void*)ambi_first_kernel, (const void*)ambi_resolve_kernel,
                                      (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel,
                                      (const void*)ambi_enumerate_kernel<0>, (const void*)ambi_enumerate_kernel<1>, (const void*)ambi_enumerate_kernel<2>,
@@ -1201,6 +1217,7 @@ class HipBackend : public Backend {
                                      (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_lattice_own_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
                                      (const void*)ambi_all_lanes_kernel, (const void*)ambi_order_paths_kernel};
                 for (const void* f : fns) { hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxDynamic); if (e != hipSuccess) err = e; }
+                if (err == hipSuccess) done |= 1ull << (L->device & 63);   // (a failed attempt is tried again by the next upload)
             }
             HIP_CK(err);
         }
@@ -1599,6 +1616,7 @@ class HipBackend : public Backend {
     // if that was not enough (round 2 ran prepare + plan, synchronised, sized the arena and only then queued the run --
     // two host round trips in front of every fresh batch).  AMBI_SLICES > 1 (an experiment) keeps the sizing pass.
     int run(uint32_t flags, void* stream) override {
+        DeviceGuard dg_(device_);
         if (!uploaded_) return -32;
         if (ran_ && !tuned_ && tables_written_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
@@ -1878,6 +1896,7 @@ class HipBackend : public Backend {
     }
 
     int wait() override {
+        DeviceGuard dg_(device_);
         if (!ran_) return 0;
         HIP_CK(hipStreamSynchronize(stream_));
         inflight_ = false;
@@ -1933,6 +1952,7 @@ class HipBackend : public Backend {
     // that has completed a run that is known (inputs are immutable); for a fresh batch the host also waits for the plan
     // kernel's verdict, which reaches it through pinned memory like the express kernel's.  Otherwise the same as wait().
     int wait_results() override {
+        DeviceGuard dg_(device_);
         if (!ran_) return 0;
         static const bool lat = getenv("AMBI_DEBUG_LATENCY") != nullptr;   // diagnostics: when the two pinned words arrived, from the start of run()
         auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run_).count(); };
@@ -1970,6 +1990,7 @@ class HipBackend : public Backend {
         return lease_->h_mail + mail_off_[unit];
     }
     int download(std::vector<uint8_t>& blob) override {
+        DeviceGuard dg_(device_);
         int rc = wait();
         if (rc) return rc;
         if (upload_pending_) { if ((rc = flush_upload(nullptr))) return rc; HIP_CK(hipStreamSynchronize(nullptr)); }   // never run: the blob is all zeroes
@@ -2007,6 +2028,7 @@ class HipBackend : public Backend {
         return 0;
     }
     int pack_paths(int which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap, int64_t* dev_total, void* stream) override {
+        DeviceGuard dg_(device_);
         hipStream_t s = (hipStream_t)stream;
         bind(A_.flags);
         hipLaunchKernelGGL(ambi_pack_scan_kernel, dim3(1), dim3(1024), 0, s, A_, which, dev_lengths, d_pack_off_, dev_total);
@@ -2016,6 +2038,7 @@ class HipBackend : public Backend {
     }
     int pack_runs(int which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start, int32_t* dev_run_len, int64_t run_cap,
                   int64_t* dev_totals, void* stream) override {
+        DeviceGuard dg_(device_);
         hipStream_t s = (hipStream_t)stream;
         bind(A_.flags);
         hipLaunchKernelGGL(ambi_pack_runs_count_kernel, dim3(A_.n_units), dim3(256), 0, s, A_, which, dev_lengths, dev_run_counts);
@@ -2027,6 +2050,7 @@ class HipBackend : public Backend {
         return 0;
     }
     int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {
+        DeviceGuard dg_(device_);
         if (int rc = wait()) return rc;
         if (int rc = materialise_tables()) return rc;
         UnitOut h;
@@ -2041,10 +2065,12 @@ class HipBackend : public Backend {
         return 0;
     }
     int copy_dag(int unit, Dag* out) override {
+        DeviceGuard dg_(device_);
         HIP_CK(hipMemcpy(out, d_dags_ + unit, sizeof(Dag), hipMemcpyDeviceToHost));
         return 0;
     }
     int copy_dag_wide(int unit, int32_t* pat, int32_t* loop, uint64_t* succ2) override {
+        DeviceGuard dg_(device_);
         if (unit < 0 || unit >= (int)hb().units.size() || hb().wide_index[unit] < 0) return ST_ERR_BAD_INPUT;
         const WideUnit* X = d_wide_ + hb().wide_index[unit];
         const uint8_t* base = reinterpret_cast<const uint8_t*>(X);
@@ -2146,6 +2172,7 @@ class HipBackend : public Backend {
         return 0;
     }
     int all_finish() override {
+        DeviceGuard dg_(device_);
         if (!d_all_bits_) return 0;
         const int U = (int)hb().units.size();
         hipLaunchKernelGGL(ambi_all_finalize_kernel, dim3((U + 255) / 256), dim3(256), 0, stream_, A_);
@@ -2180,6 +2207,7 @@ class HipBackend : public Backend {
         return 0;
     }
     int all_orders(int unit, int pass, int64_t first, int64_t count, int64_t* idx) override {
+        DeviceGuard dg_(device_);
         if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
         const std::vector<int64_t>* vp = nullptr;
         if (int rc = all_indices(unit, pass, &vp)) return rc;
@@ -2189,6 +2217,7 @@ class HipBackend : public Backend {
         return 0;
     }
     int all_paths(int unit, int pass, int64_t first, int64_t count, int32_t* lengths, int32_t* cells, int64_t stride) override {
+        DeviceGuard dg_(device_);
         if (pass < 0 || pass > 1 || unit < 0 || unit >= (int)all_idx_[pass].size()) return ST_ERR_BAD_INPUT;
         const std::vector<int64_t>* vp = nullptr;
         if (int rc = all_indices(unit, pass, &vp)) return rc;
