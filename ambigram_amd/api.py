@@ -28,6 +28,12 @@ class UnitResult(C.Structure):
                 ("path_indel_stored", C.c_int32), ("reserved", C.c_int32)]
 
 
+class RunsView(C.Structure):     # ambi_runs_view_t
+    _fields_ = [("n_runs", C.c_int64), ("n_cells", C.c_int64), ("bytes", C.c_int64), ("copied_bytes", C.c_int64),
+                ("lengths", C.POINTER(C.c_int32)), ("run_counts", C.POINTER(C.c_int32)),
+                ("run_start", C.POINTER(C.c_int32)), ("run_len", C.POINTER(C.c_int32))]
+
+
 class AmbiError(RuntimeError):
     def __init__(self, lib, code, what=""):
         self.code = code
@@ -82,6 +88,9 @@ def _declare(L):
         "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
         "ambi_batch_pack_runs": (C.c_int, [vp, i32, vp, vp, vp, vp, i64, vp, vp]),
         "ambi_expand_runs": (C.c_int, [vp, vp, vp, i64, vp, i64, vp]),
+        "ambi_batch_runs_to_host": (C.c_int, [vp, i32, i32, vp]),
+        "ambi_batch_runs_wait": (C.c_int, [vp, i32, _P(RunsView)]),
+        "ambi_batch_runs_unit_path": (C.c_int, [vp, i32, i32, pi32, i32]),
         "ambi_batch_unit_result": (C.c_int, [vp, i32, _P(UnitResult)]),
         "ambi_batch_unit_path": (C.c_int, [vp, i32, i32, pi32, i32]),
         "ambi_batch_unit_bkp": (C.c_int, [vp, i32, pi32, i32]),
@@ -403,6 +412,29 @@ class Batch:
         self._ck(self.lib.ambi_batch_pack_runs(self.h, which, C.c_void_p(dev_lengths_ptr), C.c_void_p(dev_run_counts_ptr),
                                                 C.c_void_p(dev_run_start_ptr), C.c_void_p(dev_run_len_ptr), run_cap,
                                                 C.c_void_p(dev_totals_ptr), C.c_void_p(stream or 0)), "pack_runs")
+
+    def runs_to_host(self, which=1, slot=0, stream=None):
+        """Queues the packing of the final paths (run-length form) and their ONE copy into pinned host memory behind `stream`
+        (ambi_batch_runs_to_host); slots 0 / 1 alternate so that one step's copy travels while the next step computes."""
+        self._ck(self.lib.ambi_batch_runs_to_host(self.h, which, slot, C.c_void_p(stream or 0)), "runs_to_host")
+
+    def runs_wait(self, slot=0):
+        """Waits for the slot's copy; returns {n_runs, n_cells, bytes, copied_bytes, lengths, run_counts, run_start, run_len} with
+        numpy views of the engine's pinned block (valid until the slot is queued again)."""
+        v = RunsView()
+        self._ck(self.lib.ambi_batch_runs_wait(self.h, slot, C.byref(v)), "runs_wait")
+        U = self.size()
+        view = lambda p, n: np.ctypeslib.as_array(p, shape=(max(int(n), 0),)) if n > 0 else np.zeros(0, np.int32)
+        return {"n_runs": v.n_runs, "n_cells": v.n_cells, "bytes": v.bytes, "copied_bytes": v.copied_bytes,
+                "lengths": view(v.lengths, U), "run_counts": view(v.run_counts, U),
+                "run_start": view(v.run_start, v.n_runs), "run_len": view(v.run_len, v.n_runs)}
+
+    def runs_unit_path(self, slot, u):
+        """One unit's path expanded on the host from the runs that arrived in `slot` (== unit_path after a download)."""
+        n = self._ck(self.lib.ambi_batch_runs_unit_path(self.h, slot, u, None, 0), "runs_unit_path")
+        buf = np.empty(max(n, 1), np.int32)
+        self.lib.ambi_batch_runs_unit_path(self.h, slot, u, buf.ctypes.data_as(_P(C.c_int32)), n)
+        return buf[:n]
 
     def pack_paths(self, which, dev_lengths_ptr, dev_cells_ptr, cell_cap, dev_total_ptr, stream=None):
         self._ck(self.lib.ambi_batch_pack_paths(self.h, which, C.c_void_p(dev_lengths_ptr), C.c_void_p(dev_cells_ptr), cell_cap,

@@ -21,6 +21,14 @@ struct EngineConfig {
 };
 
 struct KernelTime { const char* name; float ms; };
+// the final paths of a batch in run-length form, in HOST memory (Backend::runs_wait): per unit its cells and runs, then the runs of
+// all units one after the other (start value = absolute signed segment id, length); headers: UnitOut[U] or nullptr
+struct RunsView {
+    int64_t n_runs, n_cells;
+    const int32_t* lengths; const int32_t* run_counts; const int32_t* run_start; const int32_t* run_len;
+    const void* headers;
+    int64_t bytes, copied_bytes;
+};
 
 class Backend {
   public:
@@ -41,6 +49,10 @@ class Backend {
                           int64_t run_cap, int64_t* dev_totals, void* stream) = 0;
     virtual int pack_paths(int which, int32_t* dev_lengths, int32_t* dev_cells, int64_t cell_cap, int64_t* dev_total,
                            void* stream) = 0;
+    // final paths (which: 0 getBFB, 1 after indelBFB) packed into run-length form and copied to pinned host memory behind `stream`,
+    // without blocking it: slot 0 / 1 alternate so that the copy of one run travels while the next run computes
+    virtual int runs_to_host(int which, int slot, int with_headers, void* stream) { (void)which; (void)slot; (void)with_headers; (void)stream; return ST_ERR_BAD_INPUT; }
+    virtual int runs_wait(int slot, RunsView* out) { (void)slot; (void)out; return ST_ERR_BAD_INPUT; }
     virtual int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) = 0;
     virtual int copy_dag(int unit, Dag* out) = 0;
     // the same for a wide unit (64..127 nodes): node records [K][3] each, successor sets as [K][2] 64-bit words

@@ -41,6 +41,8 @@ struct ambi_batch {
         return shards[where[unit].first]->be.get();
     }
     std::vector<uint8_t> blob;
+    RunsView runs[2] = {};                              // ambi_batch_runs_wait: what arrived in the slot
+    std::vector<int64_t> runs_off[2];                   // ... and the prefix sums of its run counts (filled when a unit is asked for)
     bool uploaded = false, downloaded = false;
     bool mail_view = false;   // header / final paths / output junctions are read from the backend's pinned mailbox (ambi_batch_fetch_paths)
 };
@@ -395,6 +397,37 @@ int ambi_batch_pack_runs(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, i
     if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     if (!dev_lengths || !dev_run_counts || !dev_run_start || !dev_run_len || run_cap < 0) return AMBI_ERR_ARG;
     return b->be->pack_runs(which, dev_lengths, dev_run_counts, dev_run_start, dev_run_len, run_cap, dev_totals, hip_stream);
+}
+int ambi_batch_runs_to_host(ambi_batch_t* b, int32_t which, int32_t slot, void* hip_stream) {
+    if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    if (slot < 0 || slot > 1 || which < 0 || which > 1) return AMBI_ERR_ARG;
+    b->runs[slot] = RunsView{}; b->runs_off[slot].clear();
+    return b->be->runs_to_host(which, slot, 0, hip_stream);
+}
+int ambi_batch_runs_wait(ambi_batch_t* b, int32_t slot, ambi_runs_view_t* out) {
+    if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    if (slot < 0 || slot > 1) return AMBI_ERR_ARG;
+    RunsView v{};
+    int rc = b->be->runs_wait(slot, &v);
+    if (rc) return rc;
+    b->runs[slot] = v; b->runs_off[slot].clear();
+    if (out) { out->n_runs = v.n_runs; out->n_cells = v.n_cells; out->bytes = v.bytes; out->copied_bytes = v.copied_bytes;
+               out->lengths = v.lengths; out->run_counts = v.run_counts; out->run_start = v.run_start; out->run_len = v.run_len; }
+    return 0;
+}
+int ambi_batch_runs_unit_path(ambi_batch_t* b, int32_t slot, int32_t unit, int32_t* out, int32_t cap) {
+    if (!b || slot < 0 || slot > 1 || unit < 0 || unit >= (int)b->hb.units.size()) return AMBI_ERR_ARG;
+    const RunsView& v = b->runs[slot];
+    if (!v.lengths) return AMBI_ERR_STATE;
+    std::vector<int64_t>& off = b->runs_off[slot];
+    if (off.empty()) {
+        off.assign(b->hb.units.size() + 1, 0);
+        for (size_t u = 0; u < b->hb.units.size(); u++) off[u + 1] = off[u] + v.run_counts[u];
+    }
+    int at = 0;
+    for (int64_t r = off[unit]; r < off[unit + 1]; r++)
+        for (int k = 0; k < v.run_len[r]; k++, at++) if (out && at < cap) out[at] = v.run_start[r] + k;
+    return at;
 }
 int ambi_expand_runs(const int32_t* dev_run_start, const int32_t* dev_run_len, const int64_t* dev_cell_off, int64_t n_runs,
                      int32_t* dev_cells, int64_t cell_cap, void* hip_stream) {

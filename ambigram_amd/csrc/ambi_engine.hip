@@ -43,6 +43,56 @@ namespace ambi {
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __align__(16) uint8_t ambi_lds[];
 
+// Register budgets of the kernels that share the CUs during a step.  A SIMD holds 512 vector registers per lane and 800 scalar
+// registers: five wavefronts of the order-table kernel at 96 vector registers (what the compiler takes when left alone) fill 480
+// of them, and a finish wavefront (96) then only fits where an order-table workgroup has been pushed off the CU.  Asking for
+// AMBI_*_WAVES wavefronts per SIMD caps the kernel's vector registers at 512 / waves (in granules of 8).
+// Measured on the bench batch, builds interleaved on one box (profiles/r04_notes.md): left alone (96 / 95 / 112 registers)
+// 0.865 ms per step; order table 80 alone 0.91-0.92 (six of its workgroups then fit a CU and squeeze the finish kernels out);
+// order table 80 + lean finish 80 + direct full finish 96: 0.824-0.830.
+#ifndef AMBI_ENUM_WAVES
+#define AMBI_ENUM_WAVES 6
+#endif
+#ifndef AMBI_LEAN_WAVES
+#define AMBI_LEAN_WAVES 6
+#endif
+#ifndef AMBI_EXT_WAVES
+#define AMBI_EXT_WAVES 5
+#endif
+#ifndef AMBI_FIRST_WAVES
+#define AMBI_FIRST_WAVES 0
+#endif
+#ifndef AMBI_PREP_WAVES
+#define AMBI_PREP_WAVES 0
+#endif
+#define AMBI_WAVES_ATTR_(n) __attribute__((amdgpu_waves_per_eu(n)))
+#define AMBI_WAVES_ATTR(n) AMBI_WAVES_ATTR_(n)
+#if AMBI_ENUM_WAVES > 0
+#define AMBI_ENUM_ATTR AMBI_WAVES_ATTR(AMBI_ENUM_WAVES)
+#else
+#define AMBI_ENUM_ATTR
+#endif
+#if AMBI_LEAN_WAVES > 0
+#define AMBI_LEAN_ATTR AMBI_WAVES_ATTR(AMBI_LEAN_WAVES)
+#else
+#define AMBI_LEAN_ATTR
+#endif
+#if AMBI_EXT_WAVES > 0
+#define AMBI_EXT_ATTR AMBI_WAVES_ATTR(AMBI_EXT_WAVES)
+#else
+#define AMBI_EXT_ATTR
+#endif
+#if AMBI_FIRST_WAVES > 0
+#define AMBI_FIRST_ATTR AMBI_WAVES_ATTR(AMBI_FIRST_WAVES)
+#else
+#define AMBI_FIRST_ATTR
+#endif
+#if AMBI_PREP_WAVES > 0
+#define AMBI_PREP_ATTR AMBI_WAVES_ATTR(AMBI_PREP_WAVES)
+#else
+#define AMBI_PREP_ATTR
+#endif
+
 constexpr uint32_t kGuardWord = 0xA5B1C3D7u;
 // results of one unit as the express kernel mirrors them into the pinned mailbox (MailLayout); whole workgroup
 __device__ inline void mail_unit(const BatchArgs& A, int u, bool path_there = false) {   // path_there: the finish stage wrote the path into the slot already
@@ -86,7 +136,7 @@ __global__ void ambi_guard_check_kernel(const uint8_t* cells, int64_t stride, in
 }
 
 
-__global__ __launch_bounds__(64) void ambi_prepare_kernel(BatchArgs A) {
+__global__ __launch_bounds__(64) AMBI_PREP_ATTR void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
     if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { *A.n_pending = 0; *A.refin_count = 0; }   // nothing counts pending / handed-over units before the scan
     stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
@@ -360,7 +410,7 @@ __global__ __launch_bounds__(256) void ambi_blocks_build_kernel(BatchArgs A) {
 // workgroups of the CU -- and the separate build kernel only serves the units that several workgroups share.
 // LDS: [block_lds] image (+ automaton copy while building).
 template <int CLS>
-__global__ __launch_bounds__(1024) void ambi_enumerate_blocks_kernel(BatchArgs A) {
+__global__ __launch_bounds__(1024) AMBI_ENUM_ATTR void ambi_enumerate_blocks_kernel(BatchArgs A) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -490,7 +540,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_wide_kernel(BatchArgs A, c
     }
 }
 
-__global__ __launch_bounds__(64) void ambi_first_kernel(BatchArgs A) {
+__global__ __launch_bounds__(64) AMBI_FIRST_ATTR void ambi_first_kernel(BatchArgs A) {
     WaveGroup g;
     stage_first(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
@@ -653,7 +703,7 @@ __global__ __launch_bounds__(1024) void ambi_finish_kernel(BatchArgs A, const in
 }
 // The direct full-stage launch with the path cells in device memory (stage_finish<true>): a workgroup works in its own
 // slot of `cells` (stride bytes apart; gridDim.x slots) for every unit it takes.
-__global__ __launch_bounds__(1024) void ambi_finish_ext_kernel(BatchArgs A, const int32_t* unit_list, int count, uint8_t* cells, int64_t stride) {
+__global__ __launch_bounds__(1024) AMBI_EXT_ATTR void ambi_finish_ext_kernel(BatchArgs A, const int32_t* unit_list, int count, uint8_t* cells, int64_t stride) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
@@ -665,7 +715,7 @@ __global__ __launch_bounds__(1024) void ambi_finish_ext_kernel(BatchArgs A, cons
 
 // Lean finish (ambi_stages.hpp: stage_finish_lean): every unit of the slice; units it cannot take are counted in
 // n_pending with status ST_REFINISH.  The last workgroup to finish reports n_pending to the host.
-__global__ __launch_bounds__(256) void ambi_finish_lean_kernel(BatchArgs A, const int32_t* unit_list = nullptr, int list_count = 0) {
+__global__ __launch_bounds__(256) AMBI_LEAN_ATTR void ambi_finish_lean_kernel(BatchArgs A, const int32_t* unit_list = nullptr, int list_count = 0) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
     if (unit_list) {   // the listed units only (the units the parallel search has just resolved)
@@ -689,6 +739,25 @@ __global__ __launch_bounds__(256) void ambi_finish_lean_kernel(BatchArgs A, cons
                 *A.host_pending = atomicAdd(A.n_pending, 0);
                 *A.blocks_done = 0;
             }
+        }
+    }
+}
+
+// The lean stage with ONE WAVEFRONT per unit: the stage is a chain of short dependent phases (offsets, SV collection, look-ups,
+// output junctions) in which the 256 threads of the workgroup form mostly wait for each other at barriers -- a CU gets through one
+// unit per ~10 us whether one or five such workgroups are resident (profiles/r04_notes.md).  A lone wavefront has no barriers, a
+// quarter of the registers and the same group memory per unit, so several units per CU are in flight beside the order-table kernel.
+__global__ __launch_bounds__(64) AMBI_LEAN_ATTR void ambi_finish_lean_wave_kernel(BatchArgs A) {
+    WaveGroup g;
+    for (int i = (int)blockIdx.x; i < A.n_units; i += (int)gridDim.x) {
+        stage_finish_lean(g, A, A.unit_base + i, ambi_lds);
+        g.sync();
+    }
+    if (A.host_pending && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(A.blocks_done, 1) == (int)gridDim.x - 1) {
+            *A.host_pending = atomicAdd(A.n_pending, 0);
+            *A.blocks_done = 0;
         }
     }
 }
@@ -833,13 +902,18 @@ struct Lease {
     uint8_t* d_cells = nullptr; int64_t d_cells_bytes = 0;      // path areas of the direct full-finish launch
     uint8_t* h_stage = nullptr; uint8_t* dh_stage = nullptr; int64_t h_stage_bytes = 0;   // pinned image of the inputs (one H2D copy, or read by the ingest kernel)
     uint8_t* h_mail = nullptr; uint8_t* dh_mail = nullptr; int64_t h_mail_bytes = 0;   // pinned result mailbox (express path)
+    // final paths in run-length form on their way to the host (runs_to_host): two slots, each a device block and its pinned mirror,
+    // a copy stream of the lease's own and two events per slot (packed / arrived)
+    uint8_t* d_runs[2] = {nullptr, nullptr}; int64_t d_runs_bytes[2] = {0, 0};
+    uint8_t* h_runs[2] = {nullptr, nullptr}; int64_t h_runs_bytes[2] = {0, 0};
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_runs_packed[2] = {nullptr, nullptr}, ev_runs_done[2] = {nullptr, nullptr};
     std::vector<TimingEvents> evs;
     std::vector<hipStream_t> slice_streams; std::vector<hipEvent_t> slice_events;     // AMBI_SLICES experiments
     long uses = 0;
     int32_t seq = 0;   // run sequence numbers (the kernels report completion by storing the run's number into a pinned word)
 };
 // what stays cached in a lease between batches (larger blocks go back to the device when the batch is destroyed)
-constexpr int64_t kKeepBlock = 64ll << 20, kKeepArena = 256ll << 20, kKeepCells = 64ll << 20, kKeepStage = 16ll << 20, kKeepMail = 8ll << 20;
+constexpr int64_t kKeepBlock = 64ll << 20, kKeepArena = 256ll << 20, kKeepCells = 64ll << 20, kKeepStage = 16ll << 20, kKeepMail = 8ll << 20, kKeepRuns = 16ll << 20;
 
 class DevicePool {
     std::mutex mu_;
@@ -984,6 +1058,7 @@ class HipBackend : public Backend {
     BatchArgs A_{};
     int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_finish_lean_ = 0, lds_enum_ = 0;
     bool lean_finish_ = true;   // env AMBI_LEAN_FINISH=0: every unit through the full finish stage
+    int lean_wave_ = 0, lean_wave_grid_ = 0;   // env AMBI_LEAN_WAVE=1: the lean stage on one wavefront per unit; AMBI_LEAN_WAVE_GRID: its wavefronts
     int finish_grid_ = 0;       // workgroups of the lean finish kernel; 0 = sized per run (env AMBI_FINISH_GRID overrides)
     int32_t* d_blocks_done_ = nullptr; int32_t* d_refin_list_ = nullptr; int32_t* d_refin_count_ = nullptr;
     uint32_t* d_anblk_ = nullptr; uint8_t* d_adepth_ = nullptr;
@@ -1057,6 +1132,7 @@ class HipBackend : public Backend {
         if (inflight_) { (void)hipStreamSynchronize(stream_); inflight_ = false; }
         for (auto& kind : lease_->side) for (hipStream_t s : kind) if (s) (void)hipStreamSynchronize(s);
         for (hipStream_t s : lease_->slice_streams) (void)hipStreamSynchronize(s);
+        if (lease_->copy_stream) (void)hipStreamSynchronize(lease_->copy_stream);
         (void)hipGetLastError();
     }
     // guard words around the pinned words the kernels write through (always) and around the path areas of the direct
@@ -1094,6 +1170,10 @@ class HipBackend : public Backend {
             if (L->d_cells_bytes > kKeepCells) { (void)hipFree(L->d_cells); L->d_cells = nullptr; L->d_cells_bytes = 0; }
             if (L->h_stage_bytes > kKeepStage) { (void)hipHostFree(L->h_stage); L->h_stage = nullptr; L->dh_stage = nullptr; L->h_stage_bytes = 0; }
             if (L->h_mail_bytes > kKeepMail) { (void)hipHostFree(L->h_mail); L->h_mail = nullptr; L->dh_mail = nullptr; L->h_mail_bytes = 0; }
+            for (int k = 0; k < 2; k++) {
+                if (L->d_runs_bytes[k] > kKeepRuns) { (void)hipFree(L->d_runs[k]); L->d_runs[k] = nullptr; L->d_runs_bytes[k] = 0; }
+                if (L->h_runs_bytes[k] > kKeepRuns) { (void)hipHostFree(L->h_runs[k]); L->h_runs[k] = nullptr; L->h_runs_bytes[k] = 0; }
+            }
             lease_ = nullptr;
             DevicePool::get().release(L);
         }
@@ -1190,6 +1270,8 @@ class HipBackend : public Backend {
         lds_finish_lean_ = (int)finish_lean_work_bytes(H.max_n, H.max_m, H.max_bkp);
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
+        { const char* e = getenv("AMBI_LEAN_WAVE"); lean_wave_ = e ? atoi(e) : 0; }
+        { const char* e = getenv("AMBI_LEAN_WAVE_GRID"); lean_wave_grid_ = e ? atoi(e) : 0; if (lean_wave_grid_ < 0) lean_wave_grid_ = 0; }
         enum_stack_lds_ = (int)enum_stack_bytes(H.max_k > 0 ? H.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
@@ -1211,7 +1293,7 @@ class HipBackend : public Backend {
             std::lock_guard<std::mutex> lk(mu);
             if (!((done >> (L->device & 63)) & 1ull)) {
                 const void* fns[] = {(const void*)ambi_blocks_build_kernel, (const void*)ambi_prepare_kernel, (const void*)ambi_first_kernel, (const void*)ambi_resolve_kernel,
-                                     (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel,
+                                     (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel, (const void*)ambi_finish_lean_wave_kernel,
                                      (const void*)ambi_enumerate_kernel<0>, (const void*)ambi_enumerate_kernel<1>, (const void*)ambi_enumerate_kernel<2>,
                                      (const void*)ambi_enumerate_blocks_kernel<0>, (const void*)ambi_enumerate_blocks_kernel<1>, (const void*)ambi_enumerate_blocks_kernel<2>,
                                      (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_lattice_own_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
@@ -1596,6 +1678,10 @@ class HipBackend : public Backend {
         const int fgrid = finish_grid_for(U);
         if (debug_) fprintf(stderr, "ambigram_hip: lean finish grid %d, image budget %d, mean path capacity %.0f, order bytes %lld\n", fgrid, block_lds_, avg_path_, (long long)last_needed_);
         if (lean_finish_) {
+            if (lean_wave_) {
+                const int wg = lean_wave_grid_ > 0 ? (lean_wave_grid_ < U ? lean_wave_grid_ : U) : (fgrid < U ? std::min(U, 4 * fgrid) : U);
+                hipLaunchKernelGGL(ambi_finish_lean_wave_kernel, dim3(wg), dim3(64), lds_finish_lean_, sb, A);
+            } else
             hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A, (const int32_t*)nullptr, 0);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
             // device (an empty list costs one launch of workgroups that exit at once)
@@ -2047,6 +2133,69 @@ class HipBackend : public Backend {
         hipLaunchKernelGGL(ambi_pack_runs_write_kernel, dim3(A_.n_units), dim3(256), 0, s, A_, which, (const int64_t*)d_pack_off_, dev_run_start,
                            dev_run_len, run_cap);
         HIP_CK(hipGetLastError());
+        return 0;
+    }
+    // ---- final paths to the HOST in run-length form (the timed region ends with the "final path buffers on host";
+    // the reference prints every path, LGM.cpp:3684-3689) ----
+    // Slot layout (int32 words, device block and pinned mirror alike):
+    //   [0..3] totals {runs, cells} as two int64 | lengths[U] | run_counts[U] | run_start[cap] | run_len[cap] | (headers: UnitOut[U])
+    // runs_to_host queues, behind everything already on `stream`: the three pack kernels into the slot's device block, then ONE
+    // device-to-host copy of the block on the lease's copy stream (so the caller's stream is free for the next run at once).
+    // runs_wait waits for that copy; a slot whose capacity was too small is packed again with the capacity the totals name.
+    int64_t runs_cap_[2] = {0, 0}; int runs_which_[2] = {0, 0}; bool runs_hdr_[2] = {false, false}, runs_queued_[2] = {false, false};
+    int64_t runs_words(int64_t cap) const { return 4 + 2 * (int64_t)hb().units.size() + 2 * cap; }
+    int runs_queue(int which, int slot, bool headers, void* stream, int64_t cap) {
+        Lease* L = lease_;
+        const int64_t U = (int64_t)hb().units.size();
+        const int64_t words = runs_words(cap), hdr_bytes = headers ? U * (int64_t)sizeof(UnitOut) : 0;
+        const int64_t bytes = ((words * 4 + 15) & ~int64_t(15)) + hdr_bytes;
+        if (int rc = lease_device_block(&L->d_runs[slot], &L->d_runs_bytes[slot], bytes)) return rc;
+        if (int rc = lease_pinned_block(&L->h_runs[slot], nullptr, &L->h_runs_bytes[slot], bytes)) return rc;
+        if (!L->copy_stream) HIP_CK(hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            if (!L->ev_runs_packed[k]) HIP_CK(hipEventCreateWithFlags(&L->ev_runs_packed[k], hipEventDisableTiming));
+            if (!L->ev_runs_done[k]) HIP_CK(hipEventCreateWithFlags(&L->ev_runs_done[k], hipEventDisableTiming));
+        }
+        hipStream_t s = (hipStream_t)stream;
+        int32_t* w = reinterpret_cast<int32_t*>(L->d_runs[slot]);
+        if (int rc = pack_runs(which, w + 4, w + 4 + U, w + 4 + 2 * U, w + 4 + 2 * U + cap, cap, reinterpret_cast<int64_t*>(w), stream)) return rc;
+        HIP_CK(hipEventRecord(L->ev_runs_packed[slot], s));
+        HIP_CK(hipStreamWaitEvent(L->copy_stream, L->ev_runs_packed[slot], 0));
+        HIP_CK(hipMemcpyAsync(L->h_runs[slot], L->d_runs[slot], (size_t)(words * 4), hipMemcpyDeviceToHost, L->copy_stream));
+        if (headers) HIP_CK(hipMemcpyAsync(L->h_runs[slot] + ((words * 4 + 15) & ~int64_t(15)), d_results_, (size_t)hdr_bytes, hipMemcpyDeviceToHost, L->copy_stream));
+        HIP_CK(hipEventRecord(L->ev_runs_done[slot], L->copy_stream));
+        runs_cap_[slot] = cap; runs_which_[slot] = which; runs_hdr_[slot] = headers; runs_queued_[slot] = true;
+        return 0;
+    }
+    int runs_to_host(int which, int slot, int with_headers, void* stream) override {
+        DeviceGuard dg_(device_);
+        if (!ran_ || slot < 0 || slot > 1) return ST_ERR_BAD_INPUT;
+        // capacity: what the last complete pack of this batch needed, else a bound from the breakpoint capacities (a run per
+        // breakpoint pair, a few more where indelBFB edits the path)
+        int64_t cap = std::max(runs_cap_[0], runs_cap_[1]);
+        if (cap <= 0) { for (const UnitIn& un : hb().units) cap += un.bkp_cap / 2 + 8; cap += 64; }
+        return runs_queue(which, slot, with_headers != 0, stream, cap);
+    }
+    int runs_wait(int slot, RunsView* out) override {
+        DeviceGuard dg_(device_);
+        if (slot < 0 || slot > 1 || !runs_queued_[slot] || !out) return ST_ERR_BAD_INPUT;
+        Lease* L = lease_;
+        const int64_t U = (int64_t)hb().units.size();
+        for (int attempt = 0; attempt < 2; attempt++) {
+            HIP_CK(hipEventSynchronize(L->ev_runs_done[slot]));
+            const int64_t* tot = reinterpret_cast<const int64_t*>(L->h_runs[slot]);
+            if (tot[0] <= runs_cap_[slot]) break;
+            if (attempt == 1) return ST_ERR_BAD_INPUT;
+            // more runs than the slot holds (the kernels wrote none beyond it): once more with room for all of them
+            if (int rc = runs_queue(runs_which_[slot], slot, runs_hdr_[slot], stream_, tot[0] + (tot[0] >> 3) + 64)) return rc;
+        }
+        const int32_t* w = reinterpret_cast<const int32_t*>(L->h_runs[slot]);
+        const int64_t cap = runs_cap_[slot], words = runs_words(cap);
+        out->n_runs = reinterpret_cast<const int64_t*>(w)[0]; out->n_cells = reinterpret_cast<const int64_t*>(w)[1];
+        out->lengths = w + 4; out->run_counts = w + 4 + U; out->run_start = w + 4 + 2 * U; out->run_len = w + 4 + 2 * U + cap;
+        out->headers = runs_hdr_[slot] ? L->h_runs[slot] + ((words * 4 + 15) & ~int64_t(15)) : nullptr;
+        out->bytes = (4 + 2 * U + 2 * out->n_runs) * 4 + (runs_hdr_[slot] ? U * (int64_t)sizeof(UnitOut) : 0);   // what the payload needs (the copy moves the slot's capacity)
+        out->copied_bytes = words * 4 + (runs_hdr_[slot] ? U * (int64_t)sizeof(UnitOut) : 0);
         return 0;
     }
     int copy_orders(int unit, int64_t first, int64_t count, uint8_t* out) override {

@@ -66,10 +66,13 @@ static_assert(small_div_exact<12>(), "small_div must be exact over the in-block 
 // header of a unit's image, kept in HBM (BatchArgs::block_hdr, 8 ints per unit)
 struct BlockImageHeader { int32_t fits, nB, suf_words, image_bytes, nI, nC, block_max, pad; };
 
-// Image layout (dwords): directory entries of S = NW + 5 dwords  { row0, soff, pw[NW + 3] }  for b = 0..nB-1, one
+// Image layout (dwords): directory entries of S dwords  { row0, soff, pw[..] }  for b = 0..nB-1, one
 // sentinel dword (= R) in the row0 slot of entry nB, padding to 16 bytes, then the suffix rows.  pw[x] = prefix word
 // x % NW, so that the four words a lane needs, pw[k .. k+3] with k < NW, are consecutive.
-AMBI_HD int dir_stride(int NW) { return NW + 5; }
+// S = NW + 5 with the three wrap copies of the prefix words the 16-byte-group emission reads; rows of up to five dwords leave one
+// row per lane (emit_piece_rows), which reads pw[0 .. NW) only: S = NW + 2 (K = 19: 20 instead of 32 bytes per block, 2.9 KB of
+// a 27.8 KB image -- room on the CU for a second finish workgroup beside five enumerate workgroups).
+AMBI_HD constexpr int dir_stride(int NW) { return (kEmitRows && NW <= 5) ? NW + 2 : NW + 5; }
 AMBI_HD int64_t dir_words(int nB, int NW) { return ((int64_t)nB * dir_stride(NW) + 1 + 3) & ~int64_t(3); }
 
 // automaton copy used while building (group memory)
@@ -213,7 +216,7 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         }
         e[0] = (uint32_t)row;
         e[1] = B.soff[i];
-        for (int x = NW; x < NW + 3; x++) { const int y = x % NW; e[2 + x] = y == 0 ? w0 : (y == 1 ? w1 : w2); }
+        if (S == NW + 5) for (int x = NW; x < NW + 3; x++) { const int y = x % NW; e[2 + x] = y == 0 ? w0 : (y == 1 ? w1 : w2); }   // wrap copies
     }
     if (with_directory && g.tid() == 0) img[nB * S] = (uint32_t)R;
     clk_mark(g, clk, 29);
@@ -339,7 +342,7 @@ template <int NW>
 AMBI_HD void emit_blocks_wave(const uint32_t* img, int nB, uint32_t rlo, uint32_t rhi, uint32_t* table, int lane_lo, int lane_hi,
                               int part = 0, int parts = 1) {
     if (rlo >= rhi || nB <= 0) return;
-    constexpr int S = NW + 5;
+    constexpr int S = dir_stride(NW);
     const uint32_t* suf = img + dir_words(nB, NW);
     int b = 0;
     {   // last block whose first row is <= rlo

@@ -547,9 +547,13 @@ AMBI_HD void expand_runs(const G& g, const cell_t* bkp, int np, const int32_t* o
         const int a = bkp[2 * j], o0 = offs[j], len = offs[j + 1] - o0;
         for (int k = lane; k < len; k += lanes) {
             const int v = a + k;
+#if !defined(AMBI_LEAN_SKIP) || !(AMBI_LEAN_SKIP & 2)
             gpath[o0 + k] = (int16_t)v;   // local id; readers add the base
+#endif
             if (mirror) mirror[o0 + k] = (int16_t)v;   // the caller's copy in pinned host memory (express path), in the same pass
+#if !defined(AMBI_LEAN_SKIP) || !(AMBI_LEAN_SKIP & 1)
             if (first) { atomic_min_i32(&first[v + n], o0 + k); atomic_max_i32(&last[v + n], o0 + k); }
+#endif
         }
     }
     g.sync();

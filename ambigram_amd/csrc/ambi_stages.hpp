@@ -1073,8 +1073,14 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         // it without a workgroup barrier, while the other wavefronts do the SV look-ups, which are independent of it (if the
         // look-ups hand the unit to the full stage, that stage writes the output junctions again)
         int v = 0, stop = 0;
+#if defined(AMBI_LEAN_SKIP) && (AMBI_LEAN_SKIP & 8)
+        if (g.tid() < 64) {}
+#else
         if (g.tid() < 64) { WaveGroup w; v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base); }
+#endif
+#if !defined(AMBI_LEAN_SKIP) || !(AMBI_LEAN_SKIP & 4)
         else if (nsv > 0) stop = indel_lookups_thread(g.tid() - 64, g.size() - 64, n, W.ends, nsv, RP, P, S);
+#endif
         nout = g.bcast_i32(v, 0);
         if (nsv > 0) { printed = g.any(stop != 0) ? 0 : 1; if (!printed) { refinish(); return; } }
         AMBI_MARK(A, g, u, 19);

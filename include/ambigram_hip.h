@@ -201,6 +201,26 @@ int ambi_batch_pack_paths(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, 
  * int64[2]) receives {runs, cells}. */
 int ambi_batch_pack_runs(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, int32_t* dev_run_counts, int32_t* dev_run_start,
                          int32_t* dev_run_len, int64_t run_cap, int64_t* dev_totals, void* hip_stream);
+/* The final paths of every unit ON THE HOST, in that run-length form, without stopping the stream (the reference
+ * ends with its paths in host memory and prints every one, LocalGenomicMap.cpp:3684-3689, localhap.cpp:262).
+ * ambi_batch_runs_to_host queues, behind the work already on hip_stream: the packing kernels into a block the engine owns and
+ * ONE device-to-host copy of {totals, lengths, run counts, runs} into pinned memory on a copy stream of the engine's own -- the
+ * caller's stream is free for the next ambi_batch_run at once.  slot 0 / 1: two blocks, so that the copy of step i travels while
+ * step i+1 computes.  ambi_batch_runs_wait blocks until that copy has arrived and describes it (pointers into the engine's pinned
+ * block, valid until the slot is queued again or the batch is destroyed); bytes = what the payload needs, copied_bytes = what
+ * the copy moved (the slot's capacity).  ambi_batch_runs_unit_path expands one unit's runs into cells (absolute signed ids):
+ * exactly what ambi_batch_unit_path returns after a download. */
+typedef struct {
+    int64_t n_runs, n_cells, bytes, copied_bytes;
+    const int32_t* lengths;      /* [n_units] cells of the path */
+    const int32_t* run_counts;   /* [n_units] runs of the path */
+    const int32_t* run_start;    /* [n_runs] first cell of the run (absolute signed segment id) */
+    const int32_t* run_len;      /* [n_runs] cells of the run, counting up by one */
+} ambi_runs_view_t;
+int ambi_batch_runs_to_host(ambi_batch_t* b, int32_t which, int32_t slot, void* hip_stream);
+int ambi_batch_runs_wait(ambi_batch_t* b, int32_t slot, ambi_runs_view_t* out);
+int ambi_batch_runs_unit_path(ambi_batch_t* b, int32_t slot, int32_t unit, int32_t* out, int32_t cap);
+
 /* Expands runs into cells: run r writes dev_cells[dev_cell_off[r] + k] = dev_run_start[r] + k, k < dev_run_len[r]
  * (dev_cell_off = exclusive prefix sum of the lengths, int64).  All pointers are device memory of the current device. */
 int ambi_expand_runs(const int32_t* dev_run_start, const int32_t* dev_run_len, const int64_t* dev_cell_off, int64_t n_runs,

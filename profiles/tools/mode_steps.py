@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""A few steps of the bench batch in one mode, for a rocprofv3 --kernel-trace timeline (profiles/tools/timeline.py):
+    python3 profiles/tools/mode_steps.py [lazy|plain] [steps] [lib.so] [sv_every]"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+from ambigram_amd import api, synth
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+libp = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+sv_every = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+if libp: api._preload_hip_runtime()
+lib = api.load(libp); lib.ambi_set_device(0); torch.cuda.set_device(0)
+tmp = tempfile.mkdtemp(); B = int(os.environ.get("AMBI_STEPS_BATCH", "4096"))
+b = api.Batch(lib); keep = []
+for i in range(B):
+    edits = sv_every > 0 and i % sv_every == sv_every - 1
+    s = synth.make_sample(256, 512, "wide", 19, seed=2000 + i, n_del=2 if edits else 0, n_dup=1 if edits else 0)
+    lh, sols = s.write(tmp, "s%d" % i)
+    g = api.Graph(lib, lh); keep.append(g); b.add_chromosome_sol(g, 0, sols[0])
+b.upload(); st = torch.cuda.current_stream().cuda_stream
+flags = api.FLAG_LAZY_ORDERS if mode == "lazy" else 0
+b.run(0, st); b.wait()
+for _ in range(3): b.run(flags, st)
+b.wait(); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(steps): b.run(flags, st)
+b.wait(); torch.cuda.synchronize()
+print("%s: %.4f ms per step" % (mode, (time.perf_counter() - t) / steps * 1e3))
