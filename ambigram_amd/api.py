@@ -88,6 +88,7 @@ def _declare(L):
         "ambi_batch_pack_paths": (C.c_int, [vp, i32, vp, vp, i64, vp, vp]),
         "ambi_batch_pack_runs": (C.c_int, [vp, i32, vp, vp, vp, vp, i64, vp, vp]),
         "ambi_expand_runs": (C.c_int, [vp, vp, vp, i64, vp, i64, vp]),
+        "ambi_debug_stream_probe": (C.c_int, [vp, vp, _P(C.c_float)]),
         "ambi_batch_runs_to_host": (C.c_int, [vp, i32, i32, vp]),
         "ambi_batch_runs_wait": (C.c_int, [vp, i32, _P(RunsView)]),
         "ambi_batch_runs_unit_path": (C.c_int, [vp, i32, i32, pi32, i32]),

@@ -76,6 +76,8 @@ class Backend {
 };
 
 Backend* make_backend();   // defined by the linked backend
+// diagnostics: microseconds until a tiny kernel on stream b has run while a kernel with a long backlog of workgroups occupies stream a
+int backend_stream_probe(void* stream_a, void* stream_b, float* us);
 
 // ILP entries (ambi_ilp_rows.hpp) written by the linked backend: the HIP engine launches ambi_ilp_fill_kernel and copies
 // col/val back, the host simulation runs the same entry function on the CPU.  kernel_ms: device time of the fill (0 on the host).

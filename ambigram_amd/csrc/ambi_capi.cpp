@@ -95,6 +95,8 @@ int ambi_set_device(int device) {
     return b->set_device(device);
 }
 
+int ambi_debug_stream_probe(void* stream_a, void* stream_b, float* us) { return us ? backend_stream_probe(stream_a, stream_b, us) : AMBI_ERR_ARG; }
+
 // ---- graph ----
 int ambi_graph_read_lh(const char* lh_path, ambi_graph_t** out) {
     if (!lh_path || !out) return AMBI_ERR_ARG;

@@ -870,6 +870,40 @@ __global__ __launch_bounds__(256) void ambi_expand_runs_kernel(const int32_t* ru
     }
 }
 
+// ---- do two streams dispatch side by side? ----
+// A kernel with a backlog of workgroups on stream a, one tiny workgroup on stream b: if b's workgroup only starts when a's backlog
+// has been handed out, the two streams feed the same dispatch pipe of the command processor (queues of one pipe hand out their
+// workgroups one kernel after the other), and a finish kernel on b would run BEHIND an order-table kernel on a instead of beside
+// it (measured: 1.28 instead of 0.86 ms per step, profiles/r04_notes.md).  The engine asks this question about the caller's
+// stream and its own side streams instead of assuming a mapping of streams to hardware queues.
+__global__ __launch_bounds__(256) void ambi_spin_kernel(int64_t ticks, int32_t* sink) {
+    const int64_t t0 = (int64_t)wall_clock64();
+    while ((int64_t)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 1;
+}
+__global__ void ambi_touch_kernel(int32_t* sink) { if (sink && blockIdx.x == 0x7fffffff) *sink = 1; }
+// microseconds from the start of the backlog kernel on a to the end of the tiny kernel on b (both streams idle before and after)
+static int stream_probe_us(hipStream_t a, hipStream_t b, float* us) {
+    static hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    static int64_t ticks_per_us = 0;
+    if (!e0) { HIP_CK(hipEventCreate(&e0)); HIP_CK(hipEventCreate(&e1)); HIP_CK(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); }
+    if (!ticks_per_us) { int dev = 0, khz = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000; ticks_per_us = khz / 1000 > 0 ? khz / 1000 : 100; }
+    HIP_CK(hipStreamSynchronize(a)); HIP_CK(hipStreamSynchronize(b));
+    // 16 rounds of workgroups that hold a CU slot for ~6 us each: ~100 us of backlog
+    int ncu = 256; { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+    HIP_CK(hipEventRecord(e0, a));
+    hipLaunchKernelGGL(ambi_spin_kernel, dim3(ncu * 8 * 16), dim3(256), 0, a, (int64_t)(6 * ticks_per_us), (int32_t*)nullptr);
+    HIP_CK(hipEventRecord(e2, a));   // (b must not start before a's kernel has been queued: it waits for nothing of a's, only the host order matters)
+    hipLaunchKernelGGL(ambi_touch_kernel, dim3(1), dim3(64), 0, b, (int32_t*)nullptr);
+    HIP_CK(hipEventRecord(e1, b));
+    HIP_CK(hipStreamSynchronize(a)); HIP_CK(hipStreamSynchronize(b));
+    float ms = 0;
+    HIP_CK(hipEventElapsedTime(&ms, e0, e1));
+    *us = ms * 1e3f;
+    return 0;
+}
+int backend_stream_probe(void* a, void* b, float* us) { return stream_probe_us((hipStream_t)a, (hipStream_t)b, us); }
+
 // The dynamic-LDS ceiling of a kernel is a per-function, process-wide attribute: every batch asks for the device limit,
 // so that a second batch with smaller units cannot lower it under a first batch that is still launching (the launches
 // themselves request only what their units need).
@@ -978,6 +1012,81 @@ static int lease_stream(Lease* L, int kind, int prio, hipStream_t* out) {
     *out = L->side[kind][prio];
     return 0;
 }
+// ---- side streams that really run beside the caller's stream ----
+// The command processor hands out workgroups through four dispatch pipes; the streams of a process are spread over them in
+// creation order, and two streams on one pipe hand out their kernels' workgroups one kernel after the other.  Which pipe a stream
+// got cannot be asked, only observed (stream_probe_us), so the pool keeps eight candidate streams per device, sorted into
+// classes of streams that do NOT run side by side, learns the class of every caller's stream when it first sees it, and gives a
+// batch side streams from the other classes.  (Round 3 relied on the creation order: correct for the legacy default stream in a
+// process that creates no other streams first, 1.28 instead of 0.86 ms per step on a stream of torch's pool.)
+struct StreamClasses {
+    std::vector<hipStream_t> cand; std::vector<int> cls;    // candidates and their classes
+    std::vector<hipStream_t> rep;                            // one stream per class (class index = position)
+    std::vector<std::pair<hipStream_t, int>> callers;        // callers' streams seen so far
+    bool built = false;
+};
+constexpr float kProbeSharedUs = 55.f;   // measured: 10-17 us side by side, 105-125 us behind the backlog
+static std::mutex g_classes_mu;
+static StreamClasses g_classes[16];
+static int stream_class_of(StreamClasses& C, hipStream_t s, int* out) {   // -1: runs beside every known class
+    for (size_t c = 0; c < C.rep.size(); c++) {
+        float us = 0;
+        if (int rc = stream_probe_us(C.rep[c], s, &us)) return rc;
+        if (us > kProbeSharedUs) { *out = (int)c; return 0; }
+    }
+    *out = -1;
+    return 0;
+}
+static int build_stream_classes(StreamClasses& C) {
+    if (C.built) return 0;
+    { float us; hipStream_t t0, t1;   // first use of the probe kernels (code loading) outside the measurements
+      HIP_CK(hipStreamCreateWithFlags(&t0, hipStreamNonBlocking)); HIP_CK(hipStreamCreateWithFlags(&t1, hipStreamNonBlocking));
+      C.cand.push_back(t0); C.cand.push_back(t1);
+      if (int rc = stream_probe_us(t0, t1, &us)) return rc; }
+    // eight candidates; up to sixteen while fewer than four classes have shown up (other libraries' streams -- RCCL's -- sit between
+    // the engine's in creation order)
+    for (size_t i = 0; i < 16; i++) {
+        if (i >= 8 && C.rep.size() >= 4) break;
+        if (i >= C.cand.size()) { hipStream_t t; HIP_CK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); C.cand.push_back(t); }
+        int c = -1;
+        if (int rc = stream_class_of(C, C.cand[i], &c)) return rc;
+        if (c < 0) { c = (int)C.rep.size(); C.rep.push_back(C.cand[i]); }
+        C.cls.push_back(c);
+    }
+    C.built = true;
+    if (getenv("AMBI_DEBUG")) { fprintf(stderr, "ambigram_hip: %zu dispatch classes among %zu candidate streams:", C.rep.size(), C.cand.size()); for (int c : C.cls) fprintf(stderr, " %d", c); fprintf(stderr, "\n"); }
+    return 0;
+}
+// side streams for a batch whose kernels start on `caller`: out[k], k = 0 lean finish, 1 direct full finish, 2 scan / lattice -- from
+// classes other than the caller's and, while there are enough classes, from different ones; `set`: which of the candidates of a class
+static int classified_side_streams(int device, hipStream_t caller, int set, hipStream_t out[3]) {
+    if (device < 0 || device >= 16) return -31;
+    std::lock_guard<std::mutex> lk(g_classes_mu);
+    StreamClasses& C = g_classes[device];
+    if (int rc = build_stream_classes(C)) return rc;
+    int cc = -2;
+    for (auto& pr : C.callers) if (pr.first == caller) cc = pr.second;
+    if (cc == -2) {
+        for (size_t i = 0; i < C.cand.size(); i++) if (C.cand[i] == caller) cc = C.cls[i];
+        if (cc == -2) { if (int rc = stream_class_of(C, caller, &cc)) return rc; }
+        C.callers.push_back({caller, cc});
+        if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: caller's stream %p is in dispatch class %d\n", (void*)caller, cc);
+    }
+    const int nc = (int)C.rep.size();
+    int k = 0;
+    for (int step = 1; step <= nc && k < 3; step++) {
+        const int c = ((cc < 0 ? 0 : cc) + step) % nc;
+        if (c == cc) continue;
+        // the set-th candidate of class c (wrapping)
+        std::vector<hipStream_t> of;
+        for (size_t i = 0; i < C.cand.size(); i++) if (C.cls[i] == c) of.push_back(C.cand[i]);
+        if (of.empty()) continue;
+        out[k++] = of[(size_t)set % of.size()];
+    }
+    for (int j = k; j < 3; j++) out[j] = k > 0 ? out[j % k] : nullptr;   // fewer classes than streams: some share
+    return k > 0 ? 0 : -31;
+}
+
 // grow-only block of the lease (device memory, or pinned host memory with its device address)
 static int lease_device_block(uint8_t** p, int64_t* have, int64_t want) {
     if (*have >= want && *p) return 0;
@@ -1088,6 +1197,9 @@ class HipBackend : public Backend {
     uint8_t* d_direct_cells_ = nullptr; int64_t direct_stride_ = 0; int direct_slots_ = 0; int lds_finish_ext_ = 0; bool direct_ext_ = true;   // env AMBI_DIRECT_EXT: the direct launch keeps its path cells in device memory
     int direct_cells_ = 0; bool direct_retry_ = false;   // path area of the direct full-finish launch (0: the batch's capacity bound); env AMBI_DIRECT_CELLS
     int full_threads_ = 1024;  // env AMBI_FULL_THREADS: threads per workgroup of the direct full-finish launch (256 / 512 / 1024)
+    bool classed_ = true;              // env AMBI_STREAM_CLASSES=0: side streams by creation order (rounds 1-3) instead of by observed dispatch class
+    hipStream_t classed_for_ = (hipStream_t)-1; hipStream_t classed_streams_[3] = {nullptr, nullptr, nullptr};
+    bool want_back_ = false, want_full_ = false, want_first_ = false, want_lattice_ = false;
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
@@ -1133,6 +1245,7 @@ class HipBackend : public Backend {
         for (auto& kind : lease_->side) for (hipStream_t s : kind) if (s) (void)hipStreamSynchronize(s);
         for (hipStream_t s : lease_->slice_streams) (void)hipStreamSynchronize(s);
         if (lease_->copy_stream) (void)hipStreamSynchronize(lease_->copy_stream);
+        for (hipStream_t s : classed_streams_) if (s) (void)hipStreamSynchronize(s);
         (void)hipGetLastError();
     }
     // guard words around the pinned words the kernels write through (always) and around the path areas of the direct
@@ -1337,20 +1450,22 @@ class HipBackend : public Backend {
         { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         back_stream_ = nullptr; full_stream_ = nullptr; first_stream_ = nullptr; direct_n_ = 0; d_direct_cells_ = nullptr; direct_slots_ = 0;
+        want_back_ = want_full_ = want_first_ = want_lattice_ = false; classed_for_ = (hipStream_t)-1;
+        { const char* e = getenv("AMBI_STREAM_CLASSES"); classed_ = e ? atoi(e) != 0 : true; }
         std::vector<int32_t> dl;
         if (want_overlap_ && n_slices_ == 1) {
             // the stream of the lean finish kernel: default dispatch priority (AMBI_BACK_PRIORITY=1: lowest, round 1's setting
             // -- with the scan out of the way early the finish kernels have the whole enumerate kernel to hide behind, and
             // holding them back only lengthens the tail after it: 1.185 -> 1.168 ms per step, four interleaved runs)
             { const char* e8 = getenv("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : false;
-              if ((rc = lease_stream(L, 0, low ? 1 : 0, &back_stream_))) return rc; }
+              if ((rc = lease_stream(L, 0, low ? 1 : 0, &back_stream_))) return rc; want_back_ = !low; }
             { const char* e = getenv("AMBI_FIRST_AHEAD"); first_ahead_ = e ? atoi(e) : 3; }
             // (direct full-stage launch: 512 threads with the path cells in device memory, 1024 with the cells in group memory --
             // measured, four interleaved runs: cells in group memory 1.151 ms per step; in device memory 256 / 512 / 1024
             // threads = 1.133 / 1.110 / 1.200)
             { const char* ee = getenv("AMBI_DIRECT_EXT"); direct_ext_ = ee ? atoi(ee) != 0 : true; }
             { const char* e = getenv("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : (direct_ext_ ? 512 : 1024); if (full_threads_ != 256 && full_threads_ != 512 && full_threads_ != 1024) full_threads_ = direct_ext_ ? 512 : 1024; }
-            if (first_ahead_ >= 2) { if ((rc = lease_stream(L, 2, 2, &first_stream_))) return rc; }
+            if (first_ahead_ >= 2) { if ((rc = lease_stream(L, 2, 2, &first_stream_))) return rc; want_first_ = true; }
             {   // units that go straight to the full finish stage (env AMBI_DIRECT_FULL=0: none, they pass through the lean stage first)
                 const char* e7 = getenv("AMBI_DIRECT_FULL"); const bool on = e7 ? atoi(e7) != 0 : true;
                 const char* e8 = getenv("AMBI_DIRECT_GRID"); direct_grid_ = e8 ? atoi(e8) : 1024; if (direct_grid_ < 1) direct_grid_ = 1;   // one workgroup per unit up to 1024 (measured: 64 / 128 / 256 / 512 workgroups for 512 units = 1.63 / 1.37 / 1.25 / 1.23 ms per step; without this launch 1.30)
@@ -1362,6 +1477,7 @@ class HipBackend : public Backend {
                     // this priority stream a long soak showed stray writes into host memory.
                     const char* e9 = getenv("AMBI_FULL_PRIORITY"); const int fp = e9 ? atoi(e9) : 0;   // 0 default, 1 lowest, 2 highest priority
                     if ((rc = lease_stream(L, 1, fp == 1 ? 1 : (fp == 2 ? 2 : 0), &full_stream_))) return rc;
+                    want_full_ = fp == 0;
                     if (direct_ext_) lds_finish_ext_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, 0, H.max_out);
                 }
             }
@@ -1379,6 +1495,7 @@ class HipBackend : public Backend {
             const char* e8 = getenv("AMBI_SIDE_LATTICE");
             side_lattice_ = (e8 ? atoi(e8) != 0 : true) && (int)U <= express_units_ && n_slices_ == 1;
             if (side_lattice_ && (rc = lease_stream(L, 2, 0, &lattice_stream_))) return rc;
+            want_lattice_ = side_lattice_;
         }
         // result mailbox in pinned host memory: batches that can take the express path, while the slots stay small
         mail_off_.assign(U, 0); mail_bytes_ = 0; mail_on_ = false; mail_valid_ = false;
@@ -1706,6 +1823,19 @@ class HipBackend : public Backend {
         if (!uploaded_) return -32;
         if (ran_ && !tuned_ && tables_written_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
+        if (classed_ && stream_ != classed_for_ && (want_back_ || want_full_ || want_first_ || want_lattice_)) {
+            // side streams that dispatch beside THIS caller's stream (learnt once per stream: a few probe launches)
+            static const bool first_prio = [] { const char* e = getenv("AMBI_FIRST_PRIORITY"); return e && atoi(e) != 0; }();
+            sync_all();
+            hipStream_t sd[3];
+            if (int rc = classified_side_streams(device_, stream_, (int)(lease_->uses & 1), sd)) return rc;
+            for (int k = 0; k < 3; k++) classed_streams_[k] = sd[k];
+            if (want_back_) back_stream_ = sd[0];
+            if (want_full_) full_stream_ = sd[1];
+            if (want_first_ && !first_prio) first_stream_ = sd[2];
+            if (want_lattice_) lattice_stream_ = sd[2];
+            classed_for_ = stream_;
+        }
         t_run_ = std::chrono::steady_clock::now();
         flushed_ = upload_pending_;
         if (int rc = flush_upload(stream_)) return rc;

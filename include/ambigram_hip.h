@@ -67,6 +67,11 @@ int ambi_abi_version(void);
 const char* ambi_backend_name(void);
 int ambi_device_count(int* count);
 int ambi_set_device(int device);
+/* Diagnostics: do two HIP streams dispatch side by side?  A kernel with ~100 us of workgroups waiting is put on stream_a and one tiny
+ * workgroup on stream_b; *us = microseconds from the start of the former to the end of the latter -- a few microseconds when the
+ * streams feed different dispatch pipes, ~the whole backlog when they share one (the engine asks the same question about the
+ * caller's stream when it picks its side streams). */
+int ambi_debug_stream_probe(void* stream_a, void* stream_b, float* us);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph: replaces `new Graph(lh)` + calculateHapDepth + calculateCopyNum + readBFBProps

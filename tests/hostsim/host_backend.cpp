@@ -440,6 +440,8 @@ int backend_expand_runs(const int32_t* run_start, const int32_t* run_len, const 
     return 0;
 }
 
+int backend_stream_probe(void*, void*, float* us) { if (us) *us = 0; return 0; }   // one thread: nothing runs side by side
+
 int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_ptr, int s, int e, const int32_t* lit_col, const double* lit_val,
                      int64_t, int32_t* col, double* val, float* kernel_ms) {
     ilp_fill_rows(rows, row_ptr, 0, n_rows, 1, ilp_geom(s, e), lit_col, lit_val, 0, 1, col, val);
