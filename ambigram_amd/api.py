@@ -31,7 +31,7 @@ class UnitResult(C.Structure):
 class RunsView(C.Structure):     # ambi_runs_view_t
     _fields_ = [("n_runs", C.c_int64), ("n_cells", C.c_int64), ("bytes", C.c_int64), ("copied_bytes", C.c_int64),
                 ("lengths", C.POINTER(C.c_int32)), ("run_counts", C.POINTER(C.c_int32)),
-                ("run_start", C.POINTER(C.c_int32)), ("run_len", C.POINTER(C.c_int32))]
+                ("run_start", C.POINTER(C.c_int32)), ("run_len", C.POINTER(C.c_int32)), ("run_off", C.POINTER(C.c_int64))]
 
 
 class AmbiError(RuntimeError):
@@ -104,6 +104,7 @@ def _declare(L):
         "ambi_batch_set_timing_mask": (C.c_int, [vp, C.c_uint32]),
         "ambi_batch_kernel_count": (C.c_int, [vp]),
         "ambi_batch_kernel_time": (C.c_int, [vp, i32, _P(C.c_char_p), _P(C.c_float)]),
+        "ambi_batch_kernel_span": (C.c_int, [vp, i32, _P(C.c_float), _P(C.c_float)]),
         "ambi_batch_slices": (C.c_int, [vp]),
         "ambi_batch_all_count": (C.c_int, [vp, i32, i32, _P(C.c_int64)]),
         "ambi_batch_all_orders": (C.c_int, [vp, i32, i32, i64, i64, _P(C.c_int64)]),
@@ -428,7 +429,8 @@ class Batch:
         view = lambda p, n: np.ctypeslib.as_array(p, shape=(max(int(n), 0),)) if n > 0 else np.zeros(0, np.int32)
         return {"n_runs": v.n_runs, "n_cells": v.n_cells, "bytes": v.bytes, "copied_bytes": v.copied_bytes,
                 "lengths": view(v.lengths, U), "run_counts": view(v.run_counts, U),
-                "run_start": view(v.run_start, v.n_runs), "run_len": view(v.run_len, v.n_runs)}
+                "run_off": np.ctypeslib.as_array(v.run_off, shape=(U + 1,)) if U > 0 else np.zeros(1, np.int64),
+                "_run_start": v.run_start, "_run_len": v.run_len}
 
     def runs_unit_path(self, slot, u):
         """One unit's path expanded on the host from the runs that arrived in `slot` (== unit_path after a download)."""
@@ -499,7 +501,7 @@ class Batch:
         self.lib.ambi_batch_set_timing(self.h, 1 if on else 0)
 
     KERNEL_INDEX = {"ambi_prepare_kernel": 0, "ambi_plan_kernel": 1, "ambi_blocks_build_kernel": 2, "ambi_enumerate_kernel": 3,
-                    "ambi_first_kernel": 4, "ambi_finish_kernel": 5}
+                    "ambi_first_kernel": 4, "ambi_finish_kernel": 5, "ambi_finish_ext_kernel": 6}
 
     def set_timing_only(self, kernel_names):
         """HIP events around the named kernels only (every event pair is a marker in the stream)."""
@@ -552,6 +554,16 @@ class Batch:
             name, ms = C.c_char_p(), C.c_float()
             self.lib.ambi_batch_kernel_time(self.h, i, C.byref(name), C.byref(ms))
             out[name.value.decode()] = ms.value
+        return out
+
+    def kernel_spans(self):
+        """{kernel: (start_ms, end_ms)} from the start of the run's first kernel (ambi_batch_kernel_span)."""
+        out = {}
+        for i in range(self.lib.ambi_batch_kernel_count(self.h)):
+            name, ms, a, b = C.c_char_p(), C.c_float(), C.c_float(), C.c_float()
+            self.lib.ambi_batch_kernel_time(self.h, i, C.byref(name), C.byref(ms))
+            self.lib.ambi_batch_kernel_span(self.h, i, C.byref(a), C.byref(b))
+            out[name.value.decode()] = (a.value, b.value)
         return out
 
     def traffic(self):
@@ -629,6 +641,8 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
             cursor += 1
     flags = (FLAG_REVERSED if reversed_ else 0) | (FLAG_ALL if all_ else 0)
     b.upload(); b.run(flags); b.download()
+    # the final paths a second way: in run-length form as the finish kernels leave them for the host (ambi_batch_runs_to_host)
+    b.runs_to_host(1, 0); b.runs_wait(0)
     res = dict(ok=True, err="", log=log, chr=[], paths=[], out_juncs=[], trx_run=False, trx_path=[])
     out_acc = []
     for c in range(g.n_chr):
@@ -645,7 +659,7 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
         path = b.unit_path(c, 0)
         path_ind = b.unit_path(c, 1)
         prep = b.unit_prepare(c, e - s + 1)
-        st.update(path=path.tolist(), path_indel=path_ind.tolist(), bkp=b.unit_bkp(c).tolist(),
+        st.update(path=path.tolist(), path_indel=path_ind.tolist(), path_indel_from_runs=b.runs_unit_path(0, c).tolist(), bkp=b.unit_bkp(c).tolist(),
                   junc_cn=prep["junc_cn"], seg_cn=prep["seg_cn"], target_cn=prep["target_cn"], inv_junc=prep["inv_junc"],
                   indel_printed=bool(r["indel_printed"]), shortcut=r["status"] == ST_SHORTCUT,
                   infeasible=r["status"] == ST_INFEASIBLE)

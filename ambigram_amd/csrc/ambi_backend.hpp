@@ -20,12 +20,13 @@ struct EngineConfig {
     int32_t slices = 0;              // unit ranges run on separate streams (0: automatic; env AMBI_SLICES overrides)
 };
 
-struct KernelTime { const char* name; float ms; };
+struct KernelTime { const char* name; float ms; float start_ms = -1.f, end_ms = -1.f; };   // start / end: from the start of the run's first kernel (mean over the timed runs; -1: not known)
 // the final paths of a batch in run-length form, in HOST memory (Backend::runs_wait): per unit its cells and runs, then the runs of
 // all units one after the other (start value = absolute signed segment id, length); headers: UnitOut[U] or nullptr
 struct RunsView {
     int64_t n_runs, n_cells;
     const int32_t* lengths; const int32_t* run_counts; const int32_t* run_start; const int32_t* run_len;
+    const int64_t* run_off;      // [U+1] unit u's runs are run_start / run_len [run_off[u] .. run_off[u] + run_counts[u])
     const void* headers;
     int64_t bytes, copied_bytes;
 };

@@ -196,6 +196,15 @@ struct BatchArgs {
     int64_t* lat_sum;            // [2] device: {bytes of the order tables so far, waves done} of the side lattice kernel
     uint64_t* lat_R;             // [U] number of orders
     int32_t* lat_status;         // [U] ST_OK or the status the DAG / lattice stage ends with
+    // The FINAL path of every unit (the path after indelBFB) in run-length form, written by the finish stage that produces the path --
+    // what ambi_batch_runs_to_host copies to the host (a run = a stretch of cells counting up by one: `3+4+5+` = start 3, length 3).
+    // run_cnt[u] = its runs (0: no path; -1: more runs than the unit's slots -- the pack kernels serve such a batch), run_cells[u] its
+    // cells; unit u's runs sit at run_slot[u] .. run_slot[u+1] of run_start (absolute signed ids) / run_len.  nullptr: not collected.
+    int32_t* run_cnt;
+    int32_t* run_cells;
+    int32_t* run_start;
+    int32_t* run_len;
+    const int64_t* run_slot;
 };
 
 // Mailbox slot of one unit: [UnitOut, 128 bytes] [path: path_cap cells] [path after indelBFB: path_cap cells] [output junctions:

@@ -42,7 +42,6 @@ struct ambi_batch {
     }
     std::vector<uint8_t> blob;
     RunsView runs[2] = {};                              // ambi_batch_runs_wait: what arrived in the slot
-    std::vector<int64_t> runs_off[2];                   // ... and the prefix sums of its run counts (filled when a unit is asked for)
     bool uploaded = false, downloaded = false;
     bool mail_view = false;   // header / final paths / output junctions are read from the backend's pinned mailbox (ambi_batch_fetch_paths)
 };
@@ -403,7 +402,7 @@ int ambi_batch_pack_runs(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, i
 int ambi_batch_runs_to_host(ambi_batch_t* b, int32_t which, int32_t slot, void* hip_stream) {
     if (!b || !b->uploaded) return b ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     if (slot < 0 || slot > 1 || which < 0 || which > 1) return AMBI_ERR_ARG;
-    b->runs[slot] = RunsView{}; b->runs_off[slot].clear();
+    b->runs[slot] = RunsView{};
     return b->be->runs_to_host(which, slot, 0, hip_stream);
 }
 int ambi_batch_runs_wait(ambi_batch_t* b, int32_t slot, ambi_runs_view_t* out) {
@@ -412,22 +411,17 @@ int ambi_batch_runs_wait(ambi_batch_t* b, int32_t slot, ambi_runs_view_t* out) {
     RunsView v{};
     int rc = b->be->runs_wait(slot, &v);
     if (rc) return rc;
-    b->runs[slot] = v; b->runs_off[slot].clear();
+    b->runs[slot] = v;
     if (out) { out->n_runs = v.n_runs; out->n_cells = v.n_cells; out->bytes = v.bytes; out->copied_bytes = v.copied_bytes;
-               out->lengths = v.lengths; out->run_counts = v.run_counts; out->run_start = v.run_start; out->run_len = v.run_len; }
+               out->lengths = v.lengths; out->run_counts = v.run_counts; out->run_start = v.run_start; out->run_len = v.run_len; out->run_off = v.run_off; }
     return 0;
 }
 int ambi_batch_runs_unit_path(ambi_batch_t* b, int32_t slot, int32_t unit, int32_t* out, int32_t cap) {
     if (!b || slot < 0 || slot > 1 || unit < 0 || unit >= (int)b->hb.units.size()) return AMBI_ERR_ARG;
     const RunsView& v = b->runs[slot];
     if (!v.lengths) return AMBI_ERR_STATE;
-    std::vector<int64_t>& off = b->runs_off[slot];
-    if (off.empty()) {
-        off.assign(b->hb.units.size() + 1, 0);
-        for (size_t u = 0; u < b->hb.units.size(); u++) off[u + 1] = off[u] + v.run_counts[u];
-    }
     int at = 0;
-    for (int64_t r = off[unit]; r < off[unit + 1]; r++)
+    for (int64_t r = v.run_off[unit]; r < v.run_off[unit] + v.run_counts[unit]; r++)
         for (int k = 0; k < v.run_len[r]; k++, at++) if (out && at < cap) out[at] = v.run_start[r] + k;
     return at;
 }
@@ -620,6 +614,14 @@ int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name
     if (idx < 0 || idx >= (int)kt.size()) return AMBI_ERR_ARG;
     if (name) *name = kt[idx].name;
     if (ms) *ms = kt[idx].ms;
+    return 0;
+}
+int ambi_batch_kernel_span(const ambi_batch_t* b, int32_t idx, float* start_ms, float* end_ms) {
+    if (!b) return AMBI_ERR_ARG;
+    const auto& kt = b->be->kernel_times();
+    if (idx < 0 || idx >= (int)kt.size()) return AMBI_ERR_ARG;
+    if (start_ms) *start_ms = kt[idx].start_ms;
+    if (end_ms) *end_ms = kt[idx].end_ms;
     return 0;
 }
 int ambi_batch_traffic(const ambi_batch_t* b, int64_t* input_bytes, int64_t* order_bytes, int64_t* result_bytes) {

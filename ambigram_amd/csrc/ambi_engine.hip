@@ -1158,6 +1158,7 @@ class HipBackend : public Backend {
     int64_t* d_blk_off_ = nullptr; int32_t* d_rows_ = nullptr; int32_t* d_npending_ = nullptr; int64_t* d_needed_ = nullptr;
     int32_t* d_scratch_ = nullptr; int64_t* d_scratch_off_ = nullptr; int64_t* d_pack_off_ = nullptr;
     int64_t* d_mail_off_ = nullptr; int32_t* d_guard_bad_ = nullptr;
+    int64_t* d_run_slot_ = nullptr; int32_t* d_run_blk_[2] = {nullptr, nullptr}; int64_t run_total_ = 0; int runs_parity_ = -1;   // finish-stage runs: [cnt U][cells U][start total][len total] per run parity
     WideUnit* d_wide_ = nullptr; int32_t* d_wide_index_ = nullptr; int32_t* d_wide_units_ = nullptr; int n_wide_ = 0;   // units with 64..127 nodes (ambi_wide.hpp)
     int32_t* h_npending_ = nullptr; int64_t* h_needed_ = nullptr;   // pinned (words of the lease)
     int32_t* dh_npending_ = nullptr; int64_t* dh_needed_ = nullptr; // the same two, as the device addresses them
@@ -1312,6 +1313,7 @@ class HipBackend : public Backend {
         c.take(&d_elems_, H.elems.size()); c.take(&d_scratch_off_, U); c.take(&d_direct_list_, direct_list.size()); c.take(&d_mail_off_, U);
         c.take(&d_wide_index_, U); c.take(&d_wide_units_, (size_t)H.n_wide);
         c.take(&d_inject_, H.inject.size()); c.take(&d_inject_off_, H.inject.empty() ? 0 : 2 * U);
+        c.take(&d_run_slot_, U + 1);
         in_bytes_ = c.off;
         zero_off_ = c.off;
         c.take(&d_results_, (size_t)H.result_bytes); c.take(&d_blk_hdr_, U * 8); c.take(&d_fallback_, U);
@@ -1328,6 +1330,8 @@ class HipBackend : public Backend {
         const size_t img_stride = (size_t)std::max(block_lds_, ((160 * 1024) / 3) & ~15);   // (the budget per workgroup may be re-chosen after the first run)
         c.take(&d_blk_img_, U * img_stride);
         c.take(&d_wide_, (size_t)H.n_wide);
+        run_total_ = H.run_slot.empty() ? 0 : H.run_slot.back();
+        for (int k = 0; k < 2; k++) c.take(&d_run_blk_[k], 2 * U + 2 * (size_t)run_total_);
         return c.off;
     }
 
@@ -1362,6 +1366,7 @@ class HipBackend : public Backend {
         debug_ = getenv("AMBI_DEBUG") != nullptr;
         if ((rc = DevicePool::get().acquire(&lease_))) return rc;
         Lease* L = lease_;
+        if (device_ != L->device) classed_for_ = (hipStream_t)-1;   // (another device: its own stream classes)
         device_ = L->device;
         h_npending_ = &L->h_words->npending; h_needed_ = L->h_words->needed;
         dh_npending_ = &L->dh_words->npending; dh_needed_ = L->dh_words->needed;
@@ -1450,7 +1455,7 @@ class HipBackend : public Backend {
         { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
         { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         back_stream_ = nullptr; full_stream_ = nullptr; first_stream_ = nullptr; direct_n_ = 0; d_direct_cells_ = nullptr; direct_slots_ = 0;
-        want_back_ = want_full_ = want_first_ = want_lattice_ = false; classed_for_ = (hipStream_t)-1;
+        want_back_ = want_full_ = want_first_ = want_lattice_ = false;
         { const char* e = getenv("AMBI_STREAM_CLASSES"); classed_ = e ? atoi(e) != 0 : true; }
         std::vector<int32_t> dl;
         if (want_overlap_ && n_slices_ == 1) {
@@ -1539,6 +1544,7 @@ class HipBackend : public Backend {
         put(d_scratch_off_, H.scratch_off.data(), U * sizeof(int64_t));
         if (!dl.empty()) put(d_direct_list_, dl.data(), dl.size() * sizeof(int32_t));
         put(d_mail_off_, mail_off_.data(), U * sizeof(int64_t));
+        put(d_run_slot_, H.run_slot.data(), (U + 1) * sizeof(int64_t));
         put(d_wide_index_, H.wide_index.data(), U * sizeof(int32_t));
         {
             std::vector<int32_t> wu;
@@ -1594,6 +1600,11 @@ class HipBackend : public Backend {
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
         A_.wide = n_wide_ > 0 ? d_wide_ : nullptr; A_.wide_index = n_wide_ > 0 ? d_wide_index_ : nullptr;
         A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
+        {   // the finish stages leave the final paths in run-length form in the block of this run's parity (the other one may still be on its way to the host)
+            const int64_t U = (int64_t)hb().units.size();
+            int32_t* blk = d_run_blk_[run_seq_ & 1];
+            A_.run_cnt = blk; A_.run_cells = blk + U; A_.run_start = blk + 2 * U; A_.run_len = blk + 2 * U + run_total_; A_.run_slot = d_run_slot_;
+        }
         A_.lat_R = d_lat_R_; A_.lat_status = d_lat_status_; A_.lat_sum = d_lat_sum_; A_.lat_seq = &lease_->dh_words->lat_seq; A_.lat_unsure = &lease_->dh_words->lat_unsure;
         A_.plan_seq = &lease_->dh_words->plan_seq; A_.late_flag = &lease_->dh_words->late_flag; A_.run_seq = run_seq_;
         A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = getenv("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
@@ -1612,7 +1623,7 @@ class HipBackend : public Backend {
 
     // Per-kernel HIP events on the stream of the slice.  A ring of kTimingSlots event sets lets a timed region of many
     // runs be averaged without a host sync per run: run r records into slot r % kTimingSlots.
-    static constexpr int kTimingSlots = 64, kTimedKernels = 6;
+    static constexpr int kTimingSlots = 64, kTimedKernels = 7;
     void tick(const char* name, int slice, size_t idx, bool begin, hipStream_t on = (hipStream_t)-1) {
         if (!timing_ || !((timing_mask_ >> idx) & 1u)) return;
         const size_t slot = (size_t)(timed_runs_ % kTimingSlots);
@@ -1784,11 +1795,13 @@ class HipBackend : public Backend {
                 lds_direct = (int)finish_work_bytes(hb().max_n, hb().max_m, hb().max_bkp, direct_cells_, hb().max_out);
             }
             direct_retry_ = Ad.finish_retry != 0;
+            tick("ambi_finish_ext_kernel", s, 6, true, full_stream_);
             if (direct_ext_ && d_direct_cells_) {   // path cells in device memory: a 13 KB workgroup that fits where a lean one fits
                 direct_retry_ = false;
                 hipLaunchKernelGGL(ambi_finish_ext_kernel, dim3(dgrid), dim3(full_threads_), lds_finish_ext_, full_stream_, A, (const int32_t*)d_direct_list_, direct_n_, d_direct_cells_, direct_stride_);
             } else
             hipLaunchKernelGGL(ambi_finish_kernel, dim3(dgrid), dim3(full_threads_), lds_direct, full_stream_, Ad, (const int32_t*)d_direct_list_, (const int32_t*)nullptr, direct_n_);
+            tick("ambi_finish_ext_kernel", s, 6, false, full_stream_);
             (void)hipEventRecord(ev_full_, full_stream_);
         }
         tick("ambi_finish_kernel", s, 5, true, sb);
@@ -1823,23 +1836,26 @@ class HipBackend : public Backend {
         if (!uploaded_) return -32;
         if (ran_ && !tuned_ && tables_written_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
-        if (classed_ && stream_ != classed_for_ && (want_back_ || want_full_ || want_first_ || want_lattice_)) {
-            // side streams that dispatch beside THIS caller's stream (learnt once per stream: a few probe launches)
+        if (classed_ && (want_back_ || want_full_ || want_first_ || want_lattice_)) {
+            // side streams that dispatch beside THIS caller's stream (learnt once per stream and device: a few probe launches; a
+            // stream seen before costs a look-up)
             static const bool first_prio = [] { const char* e = getenv("AMBI_FIRST_PRIORITY"); return e && atoi(e) != 0; }();
-            sync_all();
-            hipStream_t sd[3];
-            if (int rc = classified_side_streams(device_, stream_, (int)(lease_->uses & 1), sd)) return rc;
-            for (int k = 0; k < 3; k++) classed_streams_[k] = sd[k];
-            if (want_back_) back_stream_ = sd[0];
-            if (want_full_) full_stream_ = sd[1];
-            if (want_first_ && !first_prio) first_stream_ = sd[2];
-            if (want_lattice_) lattice_stream_ = sd[2];
-            classed_for_ = stream_;
+            if (stream_ != classed_for_) {
+                hipStream_t sd[3];
+                if (int rc = classified_side_streams(device_, stream_, (int)(lease_->uses & 1), sd)) return rc;
+                for (int k = 0; k < 3; k++) classed_streams_[k] = sd[k];
+                classed_for_ = stream_;
+            }
+            if (want_back_) back_stream_ = classed_streams_[0];
+            if (want_full_) full_stream_ = classed_streams_[1];
+            if (want_first_ && !first_prio) first_stream_ = classed_streams_[2];
+            if (want_lattice_) lattice_stream_ = classed_streams_[2];
         }
         t_run_ = std::chrono::steady_clock::now();
         flushed_ = upload_pending_;
         if (int rc = flush_upload(stream_)) return rc;
         run_seq_ = ++lease_->seq;
+        runs_parity_ = run_seq_ & 1;
         mail_valid_ = false;
         bind(flags);
         all_done_ = false;
@@ -2139,9 +2155,9 @@ class HipBackend : public Backend {
             const long filled = timed_runs_ < kTimingSlots ? timed_runs_ : kTimingSlots;
             times_.clear();
             static const char* const kKernelNames[kTimedKernels] = {"ambi_prepare_kernel", "ambi_plan_kernel", "ambi_blocks_build_kernel",
-                                                                    "ambi_enumerate_kernel", "ambi_first_kernel", "ambi_finish_kernel"};
+                                                                    "ambi_enumerate_kernel", "ambi_first_kernel", "ambi_finish_kernel", "ambi_finish_ext_kernel"};
             for (int k = 0; k < kTimedKernels; k++) {
-                double sum = 0; int cnt = 0; const char* nm = kKernelNames[k];
+                double sum = 0, s0 = 0, s1 = 0; int cnt = 0, cnt_span = 0; const char* nm = kKernelNames[k];
                 if (!((timing_mask_ >> k) & 1u)) { times_.push_back({nm, -1.0f}); continue; }
                 for (long sl = 0; sl < filled; sl++) {
                     for (int sc = 0; sc < n_slices_; sc++) {
@@ -2149,9 +2165,17 @@ class HipBackend : public Backend {
                         if (at >= evs().size() || !evs()[at].a) continue;
                         float ms = 0;
                         if (hipEventElapsedTime(&ms, evs()[at].a, evs()[at].b) == hipSuccess) { sum += ms; cnt++; nm = evs()[at].name; }
+                        // where the kernel sits in its run: from the event in front of the run's first kernel (the events of one slot
+                        // belong to one run; they sit on different streams of one device)
+                        const size_t at0 = ((size_t)sl * n_slices_ + sc) * kTimedKernels;
+                        float a = 0, b = 0;
+                        if ((timing_mask_ & 1u) && at0 < evs().size() && evs()[at0].a && hipEventElapsedTime(&a, evs()[at0].a, evs()[at].a) == hipSuccess &&
+                            hipEventElapsedTime(&b, evs()[at0].a, evs()[at].b) == hipSuccess) { s0 += a; s1 += b; cnt_span++; }
                     }
                 }
-                times_.push_back({nm, cnt ? (float)(sum / cnt) : -1.0f});
+                KernelTime kt{nm, cnt ? (float)(sum / cnt) : -1.0f};
+                if (cnt_span) { kt.start_ms = (float)(s0 / cnt_span); kt.end_ms = (float)(s1 / cnt_span); }
+                times_.push_back(kt);
             }
             (void)hipGetLastError();   // an event pair that was never recorded reports an error above: not one of ours
         }
@@ -2297,13 +2321,38 @@ class HipBackend : public Backend {
         runs_cap_[slot] = cap; runs_which_[slot] = which; runs_hdr_[slot] = headers; runs_queued_[slot] = true;
         return 0;
     }
+    // which = 1 (the final path): the finish stages of the last run left the runs in the block of that run's parity (BatchArgs::run_*),
+    // so there is nothing to compute -- ONE copy of that block on the copy stream, behind an event on the caller's stream.  which = 0, or
+    // a batch with a unit whose runs overflowed its slots: the pack kernels (runs_queue).
+    bool runs_direct_[2] = {false, false}; std::vector<int64_t> runs_off_[2];
     int runs_to_host(int which, int slot, int with_headers, void* stream) override {
         DeviceGuard dg_(device_);
         if (!ran_ || slot < 0 || slot > 1) return ST_ERR_BAD_INPUT;
+        static const bool no_direct = getenv("AMBI_RUNS_PACK") != nullptr;   // env AMBI_RUNS_PACK=1: always through the pack kernels
+        if (which == 1 && run_total_ > 0 && runs_parity_ >= 0 && !no_direct) {
+            Lease* L = lease_;
+            const int64_t U = (int64_t)hb().units.size();
+            const int64_t words = 2 * U + 2 * run_total_, hdr_bytes = with_headers ? U * (int64_t)sizeof(UnitOut) : 0;
+            const int64_t bytes = ((words * 4 + 15) & ~int64_t(15)) + hdr_bytes;
+            if (int rc = lease_pinned_block(&L->h_runs[slot], nullptr, &L->h_runs_bytes[slot], bytes)) return rc;
+            if (!L->copy_stream) HIP_CK(hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; k++) {
+                if (!L->ev_runs_packed[k]) HIP_CK(hipEventCreateWithFlags(&L->ev_runs_packed[k], hipEventDisableTiming));
+                if (!L->ev_runs_done[k]) HIP_CK(hipEventCreateWithFlags(&L->ev_runs_done[k], hipEventDisableTiming));
+            }
+            HIP_CK(hipEventRecord(L->ev_runs_packed[slot], (hipStream_t)stream));
+            HIP_CK(hipStreamWaitEvent(L->copy_stream, L->ev_runs_packed[slot], 0));
+            HIP_CK(hipMemcpyAsync(L->h_runs[slot], d_run_blk_[runs_parity_], (size_t)(words * 4), hipMemcpyDeviceToHost, L->copy_stream));
+            if (with_headers) HIP_CK(hipMemcpyAsync(L->h_runs[slot] + ((words * 4 + 15) & ~int64_t(15)), d_results_, (size_t)hdr_bytes, hipMemcpyDeviceToHost, L->copy_stream));
+            HIP_CK(hipEventRecord(L->ev_runs_done[slot], L->copy_stream));
+            runs_which_[slot] = which; runs_hdr_[slot] = with_headers != 0; runs_queued_[slot] = true; runs_direct_[slot] = true;
+            return 0;
+        }
         // capacity: what the last complete pack of this batch needed, else a bound from the breakpoint capacities (a run per
         // breakpoint pair, a few more where indelBFB edits the path)
         int64_t cap = std::max(runs_cap_[0], runs_cap_[1]);
         if (cap <= 0) { for (const UnitIn& un : hb().units) cap += un.bkp_cap / 2 + 8; cap += 64; }
+        runs_direct_[slot] = false;
         return runs_queue(which, slot, with_headers != 0, stream, cap);
     }
     int runs_wait(int slot, RunsView* out) override {
@@ -2311,6 +2360,26 @@ class HipBackend : public Backend {
         if (slot < 0 || slot > 1 || !runs_queued_[slot] || !out) return ST_ERR_BAD_INPUT;
         Lease* L = lease_;
         const int64_t U = (int64_t)hb().units.size();
+        if (runs_direct_[slot]) {
+            HIP_CK(hipEventSynchronize(L->ev_runs_done[slot]));
+            const int32_t* w = reinterpret_cast<const int32_t*>(L->h_runs[slot]);
+            int64_t nr = 0, nc = 0; bool over = false;
+            for (int64_t u = 0; u < U; u++) { if (w[u] < 0) over = true; else nr += w[u]; nc += w[U + u]; }
+            if (!over) {
+                const int64_t words = 2 * U + 2 * run_total_;
+                out->n_runs = nr; out->n_cells = nc;
+                out->run_counts = w; out->lengths = w + U; out->run_start = w + 2 * U; out->run_len = w + 2 * U + run_total_;
+                out->run_off = hb().run_slot.data();
+                out->headers = runs_hdr_[slot] ? L->h_runs[slot] + ((words * 4 + 15) & ~int64_t(15)) : nullptr;
+                out->bytes = (2 * U + 2 * nr) * 4 + (runs_hdr_[slot] ? U * (int64_t)sizeof(UnitOut) : 0);
+                out->copied_bytes = words * 4 + (runs_hdr_[slot] ? U * (int64_t)sizeof(UnitOut) : 0);
+                return 0;
+            }
+            // a unit's runs did not fit its slots: this batch through the pack kernels (results are still those of the last run)
+            runs_direct_[slot] = false;
+            int64_t cap = 0; for (const UnitIn& un : hb().units) cap += un.bkp_cap / 2 + 8; cap += 64;
+            if (int rc = runs_queue(runs_which_[slot], slot, runs_hdr_[slot], stream_, cap)) return rc;
+        }
         for (int attempt = 0; attempt < 2; attempt++) {
             HIP_CK(hipEventSynchronize(L->ev_runs_done[slot]));
             const int64_t* tot = reinterpret_cast<const int64_t*>(L->h_runs[slot]);
@@ -2323,6 +2392,9 @@ class HipBackend : public Backend {
         const int64_t cap = runs_cap_[slot], words = runs_words(cap);
         out->n_runs = reinterpret_cast<const int64_t*>(w)[0]; out->n_cells = reinterpret_cast<const int64_t*>(w)[1];
         out->lengths = w + 4; out->run_counts = w + 4 + U; out->run_start = w + 4 + 2 * U; out->run_len = w + 4 + 2 * U + cap;
+        runs_off_[slot].assign((size_t)U + 1, 0);
+        for (int64_t u = 0; u < U; u++) runs_off_[slot][(size_t)u + 1] = runs_off_[slot][(size_t)u] + out->run_counts[u];
+        out->run_off = runs_off_[slot].data();
         out->headers = runs_hdr_[slot] ? L->h_runs[slot] + ((words * 4 + 15) & ~int64_t(15)) : nullptr;
         out->bytes = (4 + 2 * U + 2 * out->n_runs) * 4 + (runs_hdr_[slot] ? U * (int64_t)sizeof(UnitOut) : 0);   // what the payload needs (the copy moves the slot's capacity)
         out->copied_bytes = words * 4 + (runs_hdr_[slot] ? U * (int64_t)sizeof(UnitOut) : 0);

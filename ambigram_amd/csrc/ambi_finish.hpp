@@ -604,4 +604,64 @@ AMBI_HD int synth_out_juncs_runs(const G& g, const cell_t* bkp, int np, const in
     return synth_classes(g, cand, nc, out, cap, seg_base);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The final path in run-length form (BatchArgs::run_*): a run starts where a cell is not its predecessor + 1.  rs / rl: the
+// unit's slots (cap of them).  Returns the number of runs, or -(number of runs) when they do not fit.  While the starts are
+// being collected rl[r] holds the run's first POSITION; runs_fix_lengths turns positions into lengths.
+// ---------------------------------------------------------------------------------------------------------------
+AMBI_HD int32_t run_abs_cell(int v, int seg_base) { return v > 0 ? v + seg_base : v - seg_base; }   // (= abs_cell of ambi_batch.hpp, which includes this header)
+template <class G>
+AMBI_HD void runs_fix_lengths(const G& g, int32_t* rl, int nr, int P) {
+    for (int base = 0; base < nr; base += g.size()) {
+        const int r = base + g.tid();
+        int len = 0;
+        if (r < nr) len = (r + 1 < nr ? rl[r + 1] : P) - rl[r];   // (the next run's position is read before anyone overwrites it)
+        g.sync();
+        if (r < nr) rl[r] = len;
+        g.sync();
+    }
+}
+// from the breakpoint pairs (lean stage): pair j covers positions [offs[j], offs[j+1]) with the values bkp[2j] + k
+template <class G>
+AMBI_HD int emit_runs_pairs(const G& g, const cell_t* bkp, int np, const int32_t* offs, int P, int seg_base, int32_t* rs, int32_t* rl, int cap) {
+    int nr = 0;
+    for (int base = 0; base < np; base += g.size()) {
+        const int j = base + g.tid();
+        int start = 0, a = 0;
+        if (j < np && offs[j + 1] > offs[j]) {
+            a = bkp[2 * j];
+            int pj = j - 1;
+            while (pj >= 0 && offs[pj + 1] == offs[pj]) pj--;      // previous non-empty pair
+            start = (pj < 0 || (int)bkp[2 * pj] + (offs[pj + 1] - offs[pj]) != a) ? 1 : 0;
+        }
+        int tot;
+        const int ex = g.exscan_i32(start, &tot);
+        if (start && nr + ex < cap) { rs[nr + ex] = run_abs_cell(a, seg_base); rl[nr + ex] = offs[j]; }
+        nr += tot;
+    }
+    g.sync();
+    if (nr > cap) return -nr;
+    runs_fix_lengths(g, rl, nr, P);
+    return nr;
+}
+// from the cells (full stage; the cells in group or device memory): every thread takes a contiguous stretch
+template <class G>
+AMBI_HD int emit_runs_cells(const G& g, const cell_t* path, int P, int seg_base, int32_t* rs, int32_t* rl, int cap) {
+    const int per = (P + g.size() - 1) / g.size();
+    int lo = g.tid() * per, hi = lo + per;
+    if (lo > P) lo = P;
+    if (hi > P) hi = P;
+    int mine = 0;
+    for (int i = lo; i < hi; i++) mine += (i == 0 || (int)path[i] != (int)path[i - 1] + 1) ? 1 : 0;
+    int nr;
+    int at = g.exscan_i32(mine, &nr);
+    if (nr <= cap)
+        for (int i = lo; i < hi; i++)
+            if (i == 0 || (int)path[i] != (int)path[i - 1] + 1) { rs[at] = run_abs_cell(path[i], seg_base); rl[at] = i; at++; }
+    g.sync();
+    if (nr > cap) return -nr;
+    runs_fix_lengths(g, rl, nr, P);
+    return nr;
+}
+
 }  // namespace ambi

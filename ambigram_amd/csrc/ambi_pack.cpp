@@ -162,6 +162,14 @@ void HostBatch::finalize() {
         sints += 3ll * U.n_junc + 8;
     }
     result_bytes = off;
+    // slots for the final paths in run-length form: a run per breakpoint pair at most, twice that where a duplication can copy a
+    // stretch of the path (units that go straight to the full finish stage), a few more for the single cells an insertion adds
+    run_slot.assign(units.size() + 1, 0);
+    for (size_t u = 0; u < units.size(); u++) {
+        const UnitIn& U = units[u];
+        const int64_t base = U.bkp_cap / 2 + 8;
+        run_slot[u + 1] = run_slot[u] + (((U.direct_full ? 2 * base + 32 : base + 8) + 3) & ~int64_t(3));
+    }
     wide_index.assign(units.size(), -1);
     n_wide = 0;
     for (size_t u = 0; u < units.size(); u++) if (units[u].n_elem > kMaxNodes) wide_index[u] = n_wide++;

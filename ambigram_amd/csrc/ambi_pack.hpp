@@ -21,6 +21,7 @@ struct HostBatch {
     std::vector<double> junc_cn;       // juncs[i].cn: ends + copy number (12 bytes) are all the device reads of a junction
     std::vector<Element> elems;
     std::vector<int64_t> scratch_off;       // per unit, ints
+    std::vector<int64_t> run_slot;          // [U+1] slots of the units' final paths in run-length form (BatchArgs::run_slot); filled by finalize()
     std::vector<std::vector<int32_t>> junc_global;   // per unit: local junction index -> index in the sample's graph
     int64_t result_bytes = 0, ideal_slots = 0, scratch_ints = 0;
     int max_n = 0, max_m = 0, max_k = 0, max_bkp = 0, max_path = 0, max_out = 0;

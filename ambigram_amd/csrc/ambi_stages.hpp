@@ -133,6 +133,17 @@ AMBI_HD LatticeWork unit_lattice_work(const BatchArgs& A, int u, const IdealTabl
     return W;
 }
 
+// the unit's final path in run-length form (BatchArgs::run_*): nothing yet / the one run of the reference path 1+ .. P+ / what a
+// finish stage found (nr < 0: more runs than slots)
+AMBI_HD void runs_none(const BatchArgs& A, int u) { if (A.run_cnt) { A.run_cnt[u] = 0; A.run_cells[u] = 0; } }
+AMBI_HD void runs_publish(const BatchArgs& A, int u, int nr, int P) { if (A.run_cnt) { A.run_cnt[u] = nr >= 0 ? nr : -1; A.run_cells[u] = P; } }
+AMBI_HD void runs_identity(const BatchArgs& A, int u, int P, int seg_base) {
+    if (!A.run_cnt) return;
+    if (P > 0 && A.run_slot[u + 1] > A.run_slot[u]) { A.run_start[A.run_slot[u]] = abs_cell(1, seg_base); A.run_len[A.run_slot[u]] = P; A.run_cnt[u] = 1; }
+    else A.run_cnt[u] = P > 0 ? -1 : 0;
+    A.run_cells[u] = P;
+}
+
 // The prepare stage in pieces (stage_prepare runs them one after the other on one group; the express kernel runs the
 // junction piece and the DAG piece on two wavefronts at the same time):
 //   prep_junctions   junction ends + segment CNs staged, getJuncCN, bias, getIndelBias, the no-fold-back test
@@ -267,7 +278,7 @@ AMBI_HD void stage_prepare_wide(const G& g, const BatchArgs& A, int u, uint8_t* 
         status = lattice_wide(g, X, &R);
         if (status == ST_OK && (R >= kCountSat || R > (uint64_t)kWideMaxOrders)) status = ST_ERR_ORDERS_CAPACITY;
     }
-    if (g.tid() == 0) prep_header(out, status, bias, K, R, inv_sum);
+    if (g.tid() == 0) { prep_header(out, status, bias, K, R, inv_sum); runs_none(A, u); }
     g.sync();
 }
 
@@ -297,7 +308,7 @@ AMBI_HD void stage_prepare(const G& g, const BatchArgs& A, int u, uint8_t* work)
     AMBI_MARK(A, g, u, 7);
     uint64_t R = 0;
     if (status == ST_OK) status = prep_lattice(g, A, u, W.dag->pred, K, W.lattice_mem, &R);
-    if (g.tid() == 0) prep_header(out, status, bias, K, R, inv_sum);
+    if (g.tid() == 0) { prep_header(out, status, bias, K, R, inv_sum); runs_none(A, u); }
     g.sync();
     AMBI_MARK(A, g, u, 8);
 }
@@ -927,6 +938,7 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, 
         if (g.tid() == 0) {
             out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
             if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
+            runs_identity(A, u, P, base);
         }
         g.sync();
         return;
@@ -967,10 +979,13 @@ AMBI_HD void stage_finish(const G& g, const BatchArgs& A, int u, uint8_t* work, 
     // output junctions of the final path; records go straight into the blob (absolute ids)
     int nout = synth_out_juncs(g, W.path, P2, gout, U.out_cap, W.cand, finish_cand_cap(U.bkp_cap, U.out_cap), base);
     AMBI_MARK(A, g, u, 20);
+    int nruns = 0;
+    if (A.run_cnt) nruns = emit_runs_cells(g, W.path, P2, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
     if (g.tid() == 0) {
         out->path_len = P; out->path_indel_len = P2; out->indel_printed = printed; out->path_ind_stored = edited ? 1 : 0;
         out->n_out_junc = nout >= 0 ? nout : 0;
         if (nout < 0) out->status = nout;
+        runs_publish(A, u, nruns, P2);
     }
     g.sync();
     AMBI_MARK(A, g, u, 21);
@@ -1036,6 +1051,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         if (g.tid() == 0) {
             out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
             if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
+            runs_identity(A, u, P, base);
         }
         g.sync();
         return;
@@ -1065,7 +1081,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         if (g.tid() == 0) { out->status = ST_REFINISH; if (A.refin_list) A.refin_list[atomic_add_i32(A.refin_count, 1)] = u; }   // (no list: the caller looks at the status itself)
         g.sync();
     };
-    int printed = 0, nout;
+    int printed = 0, nout, nruns = 0;
     const RunPath RP{W.bkp, W.offs, np};
 #if defined(__HIP_DEVICE_COMPILE__)
     if (G::kIsBlock && np <= 256 && g.size() >= 128) {
@@ -1076,12 +1092,17 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
 #if defined(AMBI_LEAN_SKIP) && (AMBI_LEAN_SKIP & 8)
         if (g.tid() < 64) {}
 #else
-        if (g.tid() < 64) { WaveGroup w; v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base); }
+        if (g.tid() < 64) {
+            WaveGroup w;
+            v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+            if (A.run_cnt) nruns = emit_runs_pairs(w, W.bkp, np, W.offs, P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
+        }
 #endif
 #if !defined(AMBI_LEAN_SKIP) || !(AMBI_LEAN_SKIP & 4)
         else if (nsv > 0) stop = indel_lookups_thread(g.tid() - 64, g.size() - 64, n, W.ends, nsv, RP, P, S);
 #endif
         nout = g.bcast_i32(v, 0);
+        nruns = g.bcast_i32(nruns, 0);
         if (nsv > 0) { printed = g.any(stop != 0) ? 0 : 1; if (!printed) { refinish(); return; } }
         AMBI_MARK(A, g, u, 19);
     } else
@@ -1093,12 +1114,14 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
         }
         AMBI_MARK(A, g, u, 19);
         nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+        if (A.run_cnt) nruns = emit_runs_pairs(g, W.bkp, np, W.offs, P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
     }
     AMBI_MARK(A, g, u, 20);
     if (g.tid() == 0) {
         out->path_len = P; out->path_indel_len = P; out->indel_printed = printed; out->path_ind_stored = 0;
         out->n_out_junc = nout >= 0 ? nout : 0;
         if (nout < 0) out->status = nout;
+        runs_publish(A, u, nruns, P);
     }
     g.sync();
     AMBI_MARK(A, g, u, 21);
@@ -1241,7 +1264,7 @@ AMBI_HD bool stage_express(const GW& gw, const GB& gb, int role, const BatchArgs
         W.F.inv_src[i] = (int16_t)(ji >= 0 ? iabs(W.P.ends[ji].s) : 0);
         W.F.inv_tgt[i] = (int16_t)(ji >= 0 ? iabs(W.P.ends[ji].t) : 0);
     }
-    if (gb.tid() == 0) prep_header(out, status, bias, K, 0, *inv_sum_slot);   // R comes from the lattice stage
+    if (gb.tid() == 0) { prep_header(out, status, bias, K, 0, *inv_sum_slot); runs_none(A, u); }   // R comes from the lattice stage
     gb.sync();
     // finish: the lean stage (runs of the breakpoint path; any path length), the full stage when the lean one hands the
     // unit over or would leave it to the direct full-stage launch

@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables it)")
     ap.add_argument("--single-reps", type=int, default=200, help="repetitions of the single-sample latency leg (0 disables it)")
     ap.add_argument("--pipelined", type=int, default=1, help="1: also report the throughput with two resident batches on two streams (N = 1 only)")
+    ap.add_argument("--host-paths", type=int, default=1, help="1: also report the step that ENDS WITH THE PATHS ON THE HOST (packed runs + one D2H per step, double-buffered; SURVEY.md 8d's region)")
+    ap.add_argument("--streams-leg", type=int, default=1, help="1: also report the step on a stream of the caller's own and, in a child process, behind a one-rank RCCL group")
     ap.add_argument("--lazy", type=int, default=1, help="1: also report the step without the order tables (AMBI_FLAG_LAZY_ORDERS); 0: skip that leg")
     ap.add_argument("--target-lanes", type=int, default=0)
     ap.add_argument("--slices", type=int, default=0, help="unit ranges run on separate HIP streams (0: engine default)")
@@ -159,10 +161,17 @@ def main():
     batch.wait()
     torch.cuda.synchronize()
     warm_times = {k: v for k, v in batch.kernel_times().items() if v >= 0 and k != "ambi_all_kernel"}
-    # the roofline kernel: the one that moves the bytes -- the enumerate kernel (4 GB of order table per launch); the
-    # scan / finish kernels run BESIDE it on other streams and their event spans (start of the first to end of the last,
-    # stretched over the whole enumerate kernel they hide behind) say nothing about their own work
-    dom = "ambi_enumerate_kernel" if warm_times.get("ambi_enumerate_kernel", -1) > 0 else (max(warm_times, key=lambda k: warm_times[k]) if warm_times else "ambi_enumerate_kernel")
+    warm_spans = {k: v for k, v in batch.kernel_spans().items() if v[0] >= 0 and v[1] >= 0 and k in warm_times}
+    # The roofline kernel is chosen by measured time, not by name: the largest HIP-event duration among the kernels whose duration is
+    # set by their own work.  Two spans are NOT such durations and are listed (`time_ranking`, `critical_path`) but not candidates:
+    # "ambi_finish_kernel" (lean finish + list kernel on their stream) and "ambi_finish_ext_kernel" (direct full finish) run BESIDE the
+    # order-table kernel as paced side work -- the lean kernel's grid is sized so that its few workgroups work through the batch for
+    # as long as the table is being written (HipBackend::finish_grid_for), the direct launch's workgroups wait for free slots on the
+    # CUs -- so their spans track the table kernel's by construction (0.25 / 0.10 ms when they run alone, profiles/r04_*).
+    paced = ("ambi_finish_kernel", "ambi_finish_ext_kernel")
+    own_work = {k: v for k, v in warm_times.items() if k not in paced}
+    dom = max(own_work, key=lambda k: own_work[k]) if own_work else "ambi_enumerate_kernel"
+    time_ranking = [{"kernel": k, "ms": round(v, 4), "paced_side_work": k in paced} for k, v in sorted(warm_times.items(), key=lambda kv: -kv[1])]
     batch.set_timing_only([dom])
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,6 +189,18 @@ def main():
     ktimes = dict(warm_times)
     ktimes[dom] = batch.kernel_times().get(dom, warm_times.get(dom, float("nan")))   # the dominant kernel: measured over the timed steps
     batch.set_timing(False)
+    # the step's critical path from the HIP-event timeline of the warm-up steps (all kernels timed): the front (everything before
+    # the first workgroup of the order-table kernel), the table kernel, and the tail (what still runs after the table is complete:
+    # the finish kernels on their side streams), all in ms from the start of the step's first kernel
+    critical = None
+    if "ambi_enumerate_kernel" in warm_spans and "ambi_prepare_kernel" in warm_spans:
+        t_a, t_b = warm_spans["ambi_enumerate_kernel"]
+        last = max(warm_spans, key=lambda k: warm_spans[k][1])
+        critical = {"front_ms": t_a, "table_ms": t_b - t_a, "tail_ms": max(0.0, warm_spans[last][1] - t_b), "last_kernel": last,
+                    "end_of_last_kernel_ms": warm_spans[last][1],
+                    "spans_ms": {k: [round(v[0], 4), round(v[1], 4)] for k, v in sorted(warm_spans.items(), key=lambda kv: kv[1][0])},
+                    "note": "HIP events on the streams the kernels run on, warm-up steps (every kernel carries events there: ~4 % slower than the timed steps); "
+                            "ambi_finish_kernel = lean finish + list kernel on their stream, ambi_finish_ext_kernel = direct full finish on its own"}
 
     # sanity (outside the timed region): the exchanged payload, expanded again, equals the downloaded paths
     gather()
@@ -249,6 +270,10 @@ def main():
                 # K = 19 where SURVEY 8d's algorithmic figure, used for `achieved`, counts 19), so `traffic` is BELOW the algorithmic bytes
                 "stored_bytes_per_launch": stored, "stored_GBps": stored_rate, "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
                 "row_layout": "5 bits per node up to 32 nodes, 6 up to 63 (lossless; ambi_batch_unit_orders unpacks), one byte per node above",
+                "algorithmic_frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "dominant_by": "largest HIP-event duration among the kernels whose duration is set by their own work (warm-up steps; re-measured over the timed steps); the paced finish spans are ranked in time_ranking and sit in critical_path",
+                "time_ranking": time_ranking,
+                "critical_path": critical,
                 "all_kernels_ms": ktimes, "all_kernels_note": "%s: HIP events over the timed steps; the other kernels: over the warm-up steps" % dom,
                 "step_hbm_bytes_pmc": step_traffic,
                 "step_hbm_GBps_pmc": (step_traffic / (dt / args.steps) / 1e9) if step_traffic else None}
@@ -295,6 +320,72 @@ def main():
                "sample": "%d of the %d benchmarked samples, stages #7,#8,#11-#16,#20 only (%.2f s); whole oracle run incl. .lh "
                          "parse and the variableIdx map: %.1f /s" % (cnt, B, recon, cnt / whole if whole > 0 else 0),
                "cpu_model": model, "host_cores_available": os.cpu_count(), "compiled": "-O3", "port_at_O0": o0}
+
+    # ---- the step that ends where SURVEY.md 8d's timed region ends: the final paths ON THE HOST (the reference prints every
+    # path, LGM.cpp:3684-3689).  Every step: run -> ambi_batch_runs_to_host (pack kernels + ONE device-to-host copy of {counts, runs}
+    # into pinned memory on a copy stream of the engine's own) -- double-buffered, so the copy of step i travels while step i+1
+    # computes; the host waits for step i-1's slot while step i runs.  A sampled subset is expanded on the host and compared with
+    # the downloaded paths.
+    host_paths = None
+    if world == 1 and args.host_paths:
+        def host_loop(k):
+            for i in range(k):
+                batch.run(0, stream); batch.runs_to_host(1, i % 2, stream)
+                if i >= 1:
+                    batch.runs_wait((i - 1) % 2)
+            return batch.runs_wait((k - 1) % 2)
+        # untimed: the same loop once (the first copies of a process pay for the pinned blocks, the copy stream and the runtime's copy
+        # path: ~8 ms in all, spread over the first dozen calls)
+        host_loop(max(args.steps, 8)); batch.wait(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        view = host_loop(args.steps)
+        batch.wait(); torch.cuda.synchronize()
+        dth = time.perf_counter() - t1
+        assert view["n_cells"] == total_cells and view["n_runs"] == n_runs
+        batch.download()
+        step_ = max(1, B // 64)
+        for u in range(0, B, step_):
+            assert batch.runs_unit_path((args.steps - 1) % 2, u).tolist() == batch.unit_path(u, 1).tolist(), "runs on the host differ from the downloaded path of unit %d" % u
+        host_paths = {"ms_per_step": dth / args.steps * 1e3, "value": B * args.steps / dth, "unit": "reconstructions/s",
+                      "bytes_per_step": int(view["bytes"]), "copied_bytes_per_step": int(view["copied_bytes"]), "runs_per_step": int(view["n_runs"]), "cells_per_step": int(view["n_cells"]),
+                      "vs_step_in_hbm": (dth / args.steps) / (dt / args.steps),
+                      "units_expanded_on_host_and_compared": len(range(0, B, step_)),
+                      "how": "every step: ambi_batch_run, then ambi_batch_runs_to_host: ONE D2H copy of {lengths, run counts, runs} -- which the finish kernels write beside the path cells, into one of two blocks "
+                             "alternating from run to run -- into pinned memory on the engine's copy stream; two pinned slots alternate; the host waits for step i-1's copy while step i runs; the last step's copy is waited for inside the timed region"}
+
+    # ---- the same step on OTHER STREAMS (the engine picks side streams that dispatch beside whatever stream the caller passes:
+    # DESIGN.md section 7): a stream of the caller's own from torch's pool; and, in a child process, the legacy default stream behind
+    # a one-rank RCCL group (init_process_group + one all_reduce first), which is what every rank of an N > 1 job looks like.
+    streams_leg = None
+    if world == 1 and args.streams_leg:
+        own = torch.cuda.Stream()
+        for _ in range(max(args.warmup, 1)):
+            batch.run(0, own.cuda_stream)
+        batch.wait(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            batch.run(0, own.cuda_stream)
+        batch.wait(); torch.cuda.synchronize()
+        own_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        batch.download()
+        assert [batch.unit_result(u)["path_indel_len"] for u in range(B)] == [r["path_indel_len"] for r in res]
+        rccl_ms, rccl_note = None, None
+        try:
+            import subprocess
+            env = dict(os.environ); env.pop("AMBI_BENCH_LIB", None); env["AMBI_STEPS_BATCH"] = str(B)
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "mode_steps.py"), "plain", str(args.steps), os.environ.get("AMBI_BENCH_LIB") or "-", str(args.sv_every), "rccl"],
+                                capture_output=True, text=True, timeout=300, env=env)
+            for line in pr.stdout.splitlines():
+                if "ms per step" in line:
+                    rccl_ms = float(line.split(":")[-1].split()[0])
+            if rccl_ms is None:
+                rccl_note = (pr.stderr or pr.stdout)[-300:]
+        except Exception as e:
+            rccl_note = str(e)
+        streams_leg = {"own_stream_ms_per_step": own_ms, "rccl_one_rank_ms_per_step": rccl_ms, "default_stream_ms_per_step": ms_per_step,
+                       "own_stream_vs_default": own_ms / ms_per_step, "rccl_one_rank_vs_default": (rccl_ms / ms_per_step) if rccl_ms else None,
+                       "note": rccl_note or "rccl_one_rank: a child process (its own synthetic batch of the same seeds + 1000, boxes' run-to-run spread applies)"}
+        batch.run(0, stream); batch.wait(); batch.download()
 
     # ---- the step WITHOUT the order tables (AMBI_FLAG_LAZY_ORDERS: tables written on demand only).  The reference materialises
     # every topological order (LGM.cpp:3380-3409) and so does the headline step; in default mode nothing reads that table
@@ -426,7 +517,9 @@ def main():
                     assert c_probe["path_len"] == len(p_e2e)
         except Exception as e:      # the probe is optional
             c_probe = {"error": str(e)}
-        single = {"gpu_ms": gpu_ms, "gpu_ms_order_table_included": gpu_all_ms, "e2e_ms": e2e_ms, "gpu_ms_with_upload_and_download": e2e_ms,
+        single = {"gpu_ms": gpu_ms, "gpu_ms_order_table_included": gpu_all_ms, "e2e_ms": e2e_ms,
+                  # (rounds 1-2 meaning of this key: upload + run + wait + download of the whole result blob, order table complete)
+                  "gpu_ms_with_upload_and_download": pcie_ms, "e2e_ms_mailbox_path": e2e_ms,
                   "e2e_ms_c_caller": (c_probe["e2e_us_mean"] / 1e3) if c_probe and "e2e_us_mean" in c_probe else None, "c_caller": c_probe,
                   "e2e_ms_blob_download_and_table": pcie_ms, "e2e_ms_new_batch_object_incl_sol_parse": new_ms, "reps": args.single_reps,
                   "what": "e2e_ms: packed unit on the host -> final path on the host (upload, run, fetch_paths, unit_path through ctypes; e2e_ms_c_caller: the same four calls from C; SURVEY 8d's region; the order table "
@@ -441,6 +534,11 @@ def main():
             single["speedup"] = best * 1e3 / e2e_ms
             single["e2e_speedup"] = best * 1e3 / e2e_ms
             single["speedup_inputs_resident"] = best * 1e3 / gpu_ms
+            # the CPU side materialises all R orders (allTopologicalOrders, LGM.cpp:3380-3409) inside its time; the GPU side prints the
+            # same path from order 0 and writes the table BEHIND the published result: with the table waited for the ratio is
+            single["speedup_with_order_table"] = best * 1e3 / gpu_all_ms
+            single["speedup_with_order_table_and_blob_download"] = best * 1e3 / pcie_ms
+            single["speedup_accounting"] = "speedup / e2e_speedup: packed unit on the host -> final path on the host, order table written behind it; speedup_with_order_table: inputs resident, launch -> order table complete (the CPU time includes its order table)"
             if single.get("e2e_ms_c_caller"):
                 single["e2e_speedup_c_caller"] = best * 1e3 / single["e2e_ms_c_caller"]
             single["cpu_kind"] = "port (oracle, 1 core, best of 5)"
@@ -509,6 +607,9 @@ def main():
                                   ("%d-th" % args.sv_every) if args.sv_every > 0 else "no", B),
                    "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths (run-length form, expanded on rank 0) at the end of the timed steps", 2: "; one RCCL gather of the paths (run-length form) to rank 0 at the end of every step"}[gather_mode])},
         "roofline": roofline, "cpu_baseline": cpu, "single_sample": single, "pipelined": pipelined,
+        "paths_on_host": host_paths, "streams": streams_leg,
+        "own_stream_ms_per_step": streams_leg["own_stream_ms_per_step"] if streams_leg else None,
+        "rccl_one_rank_ms_per_step": streams_leg["rccl_one_rank_ms_per_step"] if streams_leg else None,
         "step_without_table_ms": lazy["ms_per_step"] if lazy else None, "step_without_table": lazy,
         "ilp_assembly": ilp, "all_mode": all_mode,
     }

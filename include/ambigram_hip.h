@@ -208,9 +208,10 @@ int ambi_batch_pack_runs(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, i
                          int32_t* dev_run_len, int64_t run_cap, int64_t* dev_totals, void* hip_stream);
 /* The final paths of every unit ON THE HOST, in that run-length form, without stopping the stream (the reference
  * ends with its paths in host memory and prints every one, LocalGenomicMap.cpp:3684-3689, localhap.cpp:262).
- * ambi_batch_runs_to_host queues, behind the work already on hip_stream: the packing kernels into a block the engine owns and
- * ONE device-to-host copy of {totals, lengths, run counts, runs} into pinned memory on a copy stream of the engine's own -- the
- * caller's stream is free for the next ambi_batch_run at once.  slot 0 / 1: two blocks, so that the copy of step i travels while
+ * ambi_batch_runs_to_host queues, behind the work already on hip_stream, ONE device-to-host copy of {lengths, run counts, runs} into
+ * pinned memory on a copy stream of the engine's own -- the caller's stream is free for the next ambi_batch_run at once.  For the
+ * final path (which = 1) nothing is computed for it: the finish kernels write every unit's runs beside its cells, into one of two
+ * blocks that alternate from run to run; which = 0 (the path before indelBFB) goes through the packing kernels first.  slot 0 / 1: two blocks, so that the copy of step i travels while
  * step i+1 computes.  ambi_batch_runs_wait blocks until that copy has arrived and describes it (pointers into the engine's pinned
  * block, valid until the slot is queued again or the batch is destroyed); bytes = what the payload needs, copied_bytes = what
  * the copy moved (the slot's capacity).  ambi_batch_runs_unit_path expands one unit's runs into cells (absolute signed ids):
@@ -219,8 +220,10 @@ typedef struct {
     int64_t n_runs, n_cells, bytes, copied_bytes;
     const int32_t* lengths;      /* [n_units] cells of the path */
     const int32_t* run_counts;   /* [n_units] runs of the path */
-    const int32_t* run_start;    /* [n_runs] first cell of the run (absolute signed segment id) */
-    const int32_t* run_len;      /* [n_runs] cells of the run, counting up by one */
+    const int32_t* run_start;    /* first cell of a run (absolute signed segment id) */
+    const int32_t* run_len;      /* cells of the run, counting up by one */
+    const int64_t* run_off;      /* [n_units + 1] unit u's runs are entries run_off[u] .. run_off[u] + run_counts[u] - 1 of run_start / run_len
+                                  * (the finish kernels leave every unit's runs in slots of its own: the entries are not packed) */
 } ambi_runs_view_t;
 int ambi_batch_runs_to_host(ambi_batch_t* b, int32_t which, int32_t slot, void* hip_stream);
 int ambi_batch_runs_wait(ambi_batch_t* b, int32_t slot, ambi_runs_view_t* out);
@@ -295,12 +298,16 @@ int ambi_batch_unit_orders(ambi_batch_t* b, int32_t unit, int64_t first, int64_t
 int ambi_batch_slices(const ambi_batch_t* b);
 int ambi_batch_set_timing(ambi_batch_t* b, int32_t on);
 /* The same for a subset of the kernels: bit k of `mask` = kernel index k of ambi_batch_kernel_time (0 prepare, 1 plan,
- * 2 image build, 3 enumerate, 4 scan, 5 finish); the others report -1.  Every pair of events is a marker in the
+ * 2 image build, 3 enumerate, 4 scan, 5 finish (lean + list), 6 direct full finish); the others report -1.  Every pair of events is a marker in the
  * stream, and twelve of them per run cost ~4 % on the bench workload -- a timed region that needs one kernel's duration
  * asks for that kernel only. */
 int ambi_batch_set_timing_mask(ambi_batch_t* b, uint32_t mask);
 int ambi_batch_kernel_count(const ambi_batch_t* b);
 int ambi_batch_kernel_time(const ambi_batch_t* b, int32_t idx, const char** name, float* ms);
+/* Where the kernel sits in its run: start / end in ms from the start of the run's first kernel (mean over the timed runs; the
+ * kernels run on several streams side by side, so these spans -- not the durations -- give the step's critical path); -1 when the
+ * first kernel is not among the timed ones. */
+int ambi_batch_kernel_span(const ambi_batch_t* b, int32_t idx, float* start_ms, float* end_ms);
 /* bytes: inputs resident in HBM, order-table bytes written by the last run, result blob bytes */
 int ambi_batch_traffic(const ambi_batch_t* b, int64_t* input_bytes, int64_t* order_bytes, int64_t* result_bytes);
 

@@ -40,6 +40,12 @@ b.run(0, st); b.wait()
 for _ in range(3): b.run(flags, st)
 b.wait(); torch.cuda.synchronize()
 t = time.perf_counter()
-for _ in range(steps): b.run(flags, st)
+if mode == "hostpaths":      # every step ends with its final paths on their way to the host (bench.py's paths_on_host leg)
+    for i in range(steps):
+        b.run(0, st); b.runs_to_host(1, i % 2, st)
+        if i >= 1: b.runs_wait((i - 1) % 2)
+    b.runs_wait((steps - 1) % 2)
+else:
+    for _ in range(steps): b.run(flags, st)
 b.wait(); torch.cuda.synchronize()
 print("%s on %s stream: %.4f ms per step" % (mode, smode, (time.perf_counter() - t) / steps * 1e3))

@@ -32,6 +32,7 @@ class HostSimBackend : public Backend {
     int64_t orders_needed_ = 0;
     std::vector<KernelTime> times_;
     std::vector<WideUnit> wide_;          // working sets of the units with 64..127 nodes (ambi_wide.hpp)
+    std::vector<int32_t> run_blk_;        // final paths in run-length form as the finish stages leave them (BatchArgs::run_*)
     BatchArgs A_{};
 
   public:
@@ -59,6 +60,7 @@ class HostSimBackend : public Backend {
         else first_rows_.clear();
         arena_.assign((size_t)(cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : 0), 0);
         wide_.assign((size_t)hb.n_wide, WideUnit{});
+        run_blk_.assign(2 * U + 2 * (size_t)(hb.run_slot.empty() ? 0 : hb.run_slot.back()) + 1, 0);
         return 0;
     }
 
@@ -83,6 +85,11 @@ class HostSimBackend : public Backend {
         A_.wide = wide_.empty() ? nullptr : wide_.data(); A_.wide_index = wide_.empty() ? nullptr : hb_.wide_index.data();
         A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
         A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
+        {
+            const size_t U = units_.size(); const int64_t tot = hb_.run_slot.empty() ? 0 : hb_.run_slot.back();
+            A_.run_cnt = run_blk_.data(); A_.run_cells = run_blk_.data() + U; A_.run_start = run_blk_.data() + 2 * U; A_.run_len = run_blk_.data() + 2 * U + tot;
+            A_.run_slot = hb_.run_slot.data();
+        }
     }
 
     void enumerate_all() {
@@ -423,6 +430,15 @@ class HostSimBackend : public Backend {
         if (unit < 0 || unit >= (int)units_.size() || hb_.wide_index[unit] < 0) return ST_ERR_BAD_INPUT;
         const WideUnit& X = wide_[(size_t)hb_.wide_index[unit]];
         memcpy(pat, X.dag.pat, sizeof(X.dag.pat)); memcpy(loop, X.dag.loop, sizeof(X.dag.loop)); memcpy(succ2, X.succ, sizeof(X.succ));
+        return 0;
+    }
+    int runs_to_host(int which, int, int, void*) override { return which == 1 ? 0 : ST_ERR_BAD_INPUT; }   // (the host simulation has the runs where the stages wrote them)
+    int runs_wait(int, RunsView* out) override {
+        const int64_t U = (int64_t)units_.size(), tot = hb_.run_slot.empty() ? 0 : hb_.run_slot.back();
+        const int32_t* w = run_blk_.data();
+        int64_t nr = 0, nc = 0;
+        for (int64_t u = 0; u < U; u++) { if (w[u] < 0) return ST_ERR_BAD_INPUT; nr += w[u]; nc += w[U + u]; }
+        *out = RunsView{nr, nc, w + U, w, w + 2 * U, w + 2 * U + tot, hb_.run_slot.data(), nullptr, (2 * U + 2 * nr) * 4, (2 * U + 2 * tot) * 4};
         return 0;
     }
     void set_timing(bool) override {}

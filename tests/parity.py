@@ -35,6 +35,8 @@ def compare(lib, oracle, lh, sols, juncs="", reversed_=False, all_=False, keep_o
         inv_e = {s - 1 + i: int(j) for i, j in enumerate(ec["inv_junc"]) if i >= 1 and j >= 0}
         if inv_o != inv_e:
             diffs.append("chr %d fold-back map differs" % c)
+        if ec.get("path_indel_from_runs") != ec["path_indel"]:
+            diffs.append("chr %d: the final path in run-length form (runs_to_host) expands to %d cells, the path has %d" % (c, len(ec.get("path_indel_from_runs") or []), len(ec["path_indel"])))
         if oc["shortcut"] or oc["infeasible"]:
             if oc["path_indel"] != ec["path_indel"] and oc["path_indel"]:
                 diffs.append("chr %d reference path differs" % c)
