@@ -72,6 +72,9 @@ def _declare(L):
         "ambi_batch_add_chromosome_sol_block": (C.c_int, [vp, vp, i32, C.c_char_p, i32, i32]),
         "ambi_graph_recalculate": (C.c_int, [vp]),
         "ambi_graph_write_lh": (C.c_int, [vp, C.c_char_p]),
+        "ambi_graph_trx_before": (C.c_int, [vp, pi32, i32]),
+        "ambi_graph_trx_original": (C.c_int, [vp, _P(vp)]),
+        "ambi_graph_trx_restore": (C.c_int, [vp, pi32, i32, i32, C.c_char_p, i64, pi64]),
         "ambi_ilp_build_sc": (C.c_int, [vp, i32, i32, pd, pd, _P(vp)]),
         "ambi_batch_add_unit": (C.c_int, [vp, i32, i32, pd, i32, pi32, pi32, pi8, pi8, pd, i32, pi32, pi32, pi32, pi32, i32, i32]),
         "ambi_batch_size": (C.c_int, [vp, pi32]),
@@ -219,6 +222,26 @@ class Graph:
         rc = self.lib.ambi_graph_write_lh(self.h, path.encode())
         if rc != 0:
             raise AmbiError(self.lib, rc, "write_lh")
+
+    def trx_before(self):
+        """PROP I1 / C1 (TRX-BFB): the map rebuilt segment id -> id in the file ([0] unused), or None for an ordinary graph."""
+        n = self.lib.ambi_graph_trx_before(self.h, None, 0)
+        if n <= 0:
+            return None
+        m = np.zeros(n, np.int32)
+        self.lib.ambi_graph_trx_before(self.h, m.ctypes.data_as(_P(C.c_int32)), n)
+        return m
+
+    def trx_restore(self, path):
+        """virusBFB (LGM.cpp:3839-3939): a path over the rebuilt graph -> (path over the segments of the file, lines the reference prints)."""
+        buf = np.zeros(len(path) + 8, np.int32)
+        buf[:len(path)] = path
+        text = C.create_string_buffer(64 + 32 * (len(path) + 8) * 2)
+        tl = C.c_int64()
+        n = self.lib.ambi_graph_trx_restore(self.h, buf.ctypes.data_as(_P(C.c_int32)), len(path), len(buf), text, len(text), C.byref(tl))
+        if n < 0:
+            raise AmbiError(self.lib, n, "trx_restore")
+        return buf[:n].copy(), text.value.decode().splitlines()
 
     def segments(self):
         n = self.n_seg
@@ -614,6 +637,11 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
     """Host-side mirror of `Ambigram --op bfb` (localhap.cpp:49-388) with the external `cbc` call replaced by the given
     .sol files (one per chromosome that reaches the ILP, in order).  Returns a dict shaped like the oracle's dump."""
     g = Graph(lib, lh)
+    trx_before = g.trx_before() is not None
+    if trx_before:   # PROP I1 / C1: the reference leaves the rebuilt graph in ./new.lh (and says "write seg"); here: a scratch file
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            g.write_lh(os.path.join(td, "new.lh"))
     log = ["bfb"] + g.log()
     n_log0 = len(g.log())
     if juncs:
@@ -689,8 +717,20 @@ def reconstruct_sample(lib, lh, sols, juncs="", reversed_=False, all_=False, fir
                 log.append("BFB path with insertion, deletion, or duplication:")
                 log.append(g.format_path(path_ind))
         res["chr"].append(st)
+        if trx_before and r["status"] == ST_OK:   # virusBFB (localhap.cpp:263): back to the segments of the file; junction steps counted there
+            back, lines = g.trx_restore(path_ind)
+            log += lines
+            res["paths"].append(back.tolist())
+            steps = []
+            for i in range(len(back) - 1):
+                u, v = int(back[i]), int(back[i + 1])
+                if not (abs(abs(u) - abs(v)) == 1 and (u > 0) == (v > 0)):
+                    steps.append((u, v, 1))
+            merge_out_juncs(out_acc, steps)
+            continue
         res["paths"].append(path_ind.tolist())
         merge_out_juncs(out_acc, b.unit_out_juncs(c))
+    res["trx_before"] = trx_before
     ins_mode, con_mode, main_chr = g.props()
     if res["ok"] and (ins_mode == 2 or con_mode == 2):
         if not main_chr:

@@ -165,6 +165,34 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
     copy_text(g->g.main_chr, main_chr, cap);
     return 0;
 }
+int ambi_graph_trx_before(const ambi_graph_t* g, int32_t* original_of, int32_t cap) {
+    if (!g) return AMBI_ERR_ARG;
+    if (!g->g.trx) return 0;
+    const auto& m = g->g.trx->original_of;
+    if (original_of) for (size_t i = 0; i < m.size() && (int)i < cap; i++) original_of[i] = m[i];
+    return (int)m.size();
+}
+int ambi_graph_trx_original(const ambi_graph_t* g, ambi_graph_t** out) {
+    if (!g || !out) return AMBI_ERR_ARG;
+    if (!g->g.trx) return AMBI_ERR_STATE;
+    ambi_graph* o = new ambi_graph();
+    o->g = g->g.trx->original;
+    *out = o;
+    return 0;
+}
+int ambi_graph_trx_restore(const ambi_graph_t* g, int32_t* path, int32_t len, int32_t cap, char* text, int64_t text_cap, int64_t* text_len) {
+    if (!g || !path || len < 0) return AMBI_ERR_ARG;
+    std::vector<int32_t> p(path, path + len);
+    std::vector<std::string> lines;
+    int rc = trx_restore_path(g->g, p, lines);
+    if (rc != LH_OK) return rc;
+    std::string s;
+    for (auto& l : lines) { s += l; s += '\n'; }
+    const int64_t n = copy_text(s, text, text_cap);
+    if (text_len) *text_len = n;
+    for (size_t i = 0; i < p.size() && (int)i < cap; i++) path[i] = p[i];
+    return (int)p.size();
+}
 int ambi_graph_write_lh(ambi_graph_t* g, const char* lh_path) {
     if (!g || !lh_path) return AMBI_ERR_ARG;
     return write_lh(g->g, lh_path);

@@ -253,6 +253,8 @@ struct Sample {
     std::vector<std::string> head;       // lines the reference prints before a chromosome's path lines
     std::vector<int> unit;               // chromosome -> unit of the reconstruct batch
     int num_inv = 0;
+    bool trx_before = false;             // PROP I1 / C1: g is the rebuilt graph, g_file the graph of the file (chromosome names / positions of restored paths)
+    ambi_graph_t* g_file = nullptr;
     std::chrono::steady_clock::time_point t_begin;
 };
 
@@ -291,6 +293,9 @@ int run_bfb(Args& A) {
         if (rc != 0) return die(std::string("input error: ") + ambi_error_string(rc));
         ambi_graph_t* g = S.g;
         size_t printed = 0;
+        // PROP I1 / C1 (TRX-BFB, localhap.cpp:79-88): the graph has been rebuilt while loading; the reference leaves it in ./new.lh
+        S.trx_before = ambi_graph_trx_before(g, nullptr, 0) > 0;
+        if (S.trx_before) { (void)ambi_graph_write_lh(g, "./new.lh"); if ((rc = ambi_graph_trx_original(g, &S.g_file)) != 0) return die(ambi_error_string(rc)); }
         print_log(g, &printed);
         if (!juncs.empty()) { if ((rc = ambi_graph_read_juncs(g, juncs.c_str())) != 0) return die(ambi_error_string(rc)); print_log(g, &printed); }
         ambi_graph_sizes(g, &S.n_seg, &S.n_junc, &S.n_chr);
@@ -406,6 +411,24 @@ int run_bfb(Args& A) {
                 std::cout << path_text(g, p) << std::endl;                               // printBFB (LGM.cpp:3411-3429)
             if (r.status == AMBI_ST_INFEASIBLE) std::cout << "ILP is unsolvable.\n";    // localhap.cpp:217
             else if (r.indel_printed) std::cout << "BFB path with insertion, deletion, or duplication:\n" << path_text(g, q) << std::endl;
+            if (S.trx_before && r.status == AMBI_ST_OK) {
+                // virusBFB (localhap.cpp:263): the path goes back to the segments of the file; its junction steps are counted there
+                std::vector<int32_t> back(q);
+                back.resize(q.size() + 8);
+                std::string text(64 + 16 * (q.size() + 8) * 2, '\0');
+                int64_t tl = 0;
+                const int nl = ambi_graph_trx_restore(g, back.data(), (int32_t)q.size(), (int32_t)back.size(), &text[0], (int64_t)text.size(), &tl);
+                if (nl < 0) { std::cout.flush(); std::cerr << "bfb: chromosome " << c << ": " << ambi_error_string(nl) << std::endl; refused++; continue; }
+                back.resize(nl);
+                text.resize((size_t)std::min<int64_t>(tl, (int64_t)text.size() - 1));
+                std::cout << text;
+                paths[c] = back;
+                for (int i = 0; i + 1 < nl; i++) {
+                    const int uu = back[i], vv = back[i + 1];
+                    if (!(std::abs(std::abs(uu) - std::abs(vv)) == 1 && (uu > 0) == (vv > 0))) merge_steps(out_acc, uu, vv, 1, true);   // localhap.cpp:267-289
+                }
+                continue;
+            }
             paths[c] = q;
             std::vector<int32_t> ju(r.n_out_junc), jv(r.n_out_junc), jc(r.n_out_junc);
             ambi_batch_unit_out_juncs(b, u, ju.data(), jv.data(), jc.data(), r.n_out_junc);
@@ -444,10 +467,21 @@ int run_bfb(Args& A) {
             for (int j = 0; j < n_junc; j++)
                 sv << S.lh << "\t" << juncs << "\t" << chrom(js[j]) << "\t" << vend(js[j], jsd[j]) << "\t" << (jsd[j] > 0 ? '+' : '-') << "\t"
                    << chrom(jt[j]) << "\t" << vstart(jt[j], jtd[j]) << "\t" << (jtd[j] > 0 ? '+' : '-') << "\t" << jcn[j] << "\tinput\n";
+            // (PROP I1 / C1: the vertices of the restored paths are segments of the FILE)
+            std::vector<int32_t> fs, fe;
+            if (S.trx_before) {
+                int32_t fn = 0, fj = 0, fc = 0;
+                ambi_graph_sizes(S.g_file, &fn, &fj, &fc);
+                fs.resize(fn); fe.resize(fn);
+                ambi_graph_segments(S.g_file, nullptr, nullptr, fs.data(), fe.data(), nullptr, nullptr);
+            }
+            auto ochrom = [&](int id) { if (!S.trx_before) return chrom(id); char nm[256]; ambi_graph_chrom_name(S.g_file, id, nm, sizeof(nm)); return std::string(nm); };
+            auto ovend = [&](int id, int dir) { return !S.trx_before ? vend(id, dir) : (dir > 0 ? fe[id - 1] : fs[id - 1]); };
+            auto ovstart = [&](int id, int dir) { return !S.trx_before ? vstart(id, dir) : (dir > 0 ? fs[id - 1] : fe[id - 1]); };
             for (auto& j : out_acc) {
                 int a = std::abs(j.u), bb = std::abs(j.v), ad = j.u > 0 ? 1 : -1, bd = j.v > 0 ? 1 : -1;
-                sv << S.lh << "\t" << juncs << "\t" << chrom(a) << "\t" << vend(a, ad) << "\t" << (ad > 0 ? '+' : '-') << "\t"
-                   << chrom(bb) << "\t" << vstart(bb, bd) << "\t" << (bd > 0 ? '+' : '-') << "\t" << j.cn << "\toutput\n";
+                sv << S.lh << "\t" << juncs << "\t" << ochrom(a) << "\t" << ovend(a, ad) << "\t" << (ad > 0 ? '+' : '-') << "\t"
+                   << ochrom(bb) << "\t" << ovstart(bb, bd) << "\t" << (bd > 0 ? '+' : '-') << "\t" << j.cn << "\toutput\n";
             }
             auto t_end = std::chrono::steady_clock::now();
             std::ofstream tf("time.csv", std::ios_base::app);
@@ -456,7 +490,7 @@ int run_bfb(Args& A) {
         }
     }
     ambi_batch_destroy(b);
-    for (Sample& S : samples) ambi_graph_destroy(S.g);
+    for (Sample& S : samples) { ambi_graph_destroy(S.g); if (S.g_file) ambi_graph_destroy(S.g_file); }
     if (refused_total) return die("bfb: " + std::to_string(refused_total) + " chromosome(s) without a path");
     return 0;
 }

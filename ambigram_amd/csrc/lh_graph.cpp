@@ -1,5 +1,7 @@
 // lh_graph.cpp -- host-side readers/writers around the BFB path (see lh_graph.hpp).
 #include "lh_graph.hpp"
+#include <array>
+#include <memory>
 
 #include <algorithm>
 #include <cmath>
@@ -21,7 +23,7 @@ const char* lh_error_string(int code) {
         case LH_ERR_SEG_IDS: return "segment ids must be 1..N in file order";
         case LH_ERR_SOL_OPEN: return "ILP error: cannot open file";
         case LH_ERR_LINE_TOO_LONG: return "line longer than 8191 bytes";
-        case LH_ERR_UNSUPPORTED: return "TRX-BFB modes (PROP I1/C1) are not supported";
+        case LH_ERR_UNSUPPORTED: return "TRX-BFB (PROP I1/C1): the reference reads what nothing has set on this input (no junction between the listed chromosomes, a one-vertex path, or a .juncs file with these modes)";
         default: return "unknown error";
     }
 }
@@ -233,7 +235,7 @@ int read_lh(const std::string& path, LhGraph& g) {
     if (rc != LH_OK) return rc;
     copy_num(g);
     read_props(path, g);
-    if (g.ins_mode == 1 || g.con_mode == 1) return LH_ERR_UNSUPPORTED;
+    if (g.ins_mode == 1 || g.con_mode == 1) { rc = trx_rebuild(g); if (rc != LH_OK) return rc; }   // localhap.cpp:79-88
     set_partitions(g);
     return LH_OK;
 }
@@ -246,6 +248,7 @@ void set_partitions(LhGraph& g) {   // localhap.cpp:94-98
 
 int read_juncs(LhGraph& g, const std::string& path) {   // LGM.cpp:5096-5156
     if (path.empty()) return LH_OK;
+    if (g.trx) return LH_ERR_UNSUPPORTED;   // PROP I1 / C1: readComponents reads the rebuilt graph's mean coverage, which nothing ever sets (Graph.cpp:25-34)
     std::ifstream f(path);
     std::string line;
     auto& res = g.components;
@@ -303,6 +306,229 @@ int write_lh(LhGraph& g, const std::string& path) {
                 num(g.j_cn[j]).c_str(), g.j_inferred[j] ? 'I' : 'U', g.j_bounded[j] ? 'B' : 'U');
     const bool bad = ferror(f) != 0;
     if (fclose(f) != 0 || bad) return LH_ERR_OPEN;
+    return LH_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// TRX-BFB (PROP I1 / C1)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+// The rebuilt graph while it is being put together: segment k (1-based) is a copy of segment from[k-1] of the file on chromosome
+// chr[k-1]; `conv` is the reference's own map (file id -> rebuilt id, 0 = no place) -- std::unordered_map<int,int> with the same
+// sequence of inserts, because the reference PRINTS it in iteration order.
+struct Rebuild {
+    std::vector<int32_t> from, chr;
+    std::unordered_map<int, int> conv;
+    void place(int file_id, int chr_id) { conv.insert({file_id, (int)from.size() + 1}); from.push_back(file_id); chr.push_back(chr_id); }
+    void drop(int file_id) { conv.insert({file_id, 0}); }
+};
+int a_src_of(const LhGraph& g, int j) { return g.j_sdir[j] > 0 ? g.j_src[j] : -g.j_src[j]; }
+int a_tgt_of(const LhGraph& g, int j) { return g.j_tdir[j] > 0 ? g.j_tgt[j] : -g.j_tgt[j]; }
+// the rebuilt graph from the placement + the junctions that found a place (LGM.cpp:4254-4293 / :4356-4393)
+void finish_rebuild(LhGraph& g, Rebuild& R, std::vector<int32_t>& unused, const std::vector<std::array<int32_t, 5>>& kept /* j, id1, id2, dir1, dir2 */) {
+    auto T = std::make_shared<TrxBefore>();
+    T->original = g;
+    T->original.trx.reset();
+    T->unused_sv = unused;
+    T->original_of.assign(R.from.size() + 1, 0);
+    g.log.push_back("Seg conversion:");
+    for (auto it = R.conv.begin(); it != R.conv.end(); ++it) {
+        g.log.push_back(std::to_string(it->first) + "-" + std::to_string(it->second));
+        if (it->second > 0) T->original_of[it->second] = it->first;
+    }
+    const LhGraph& O = T->original;
+    LhGraph N;
+    // Graph(vector...) (Graph.cpp:25-34) sets purity and the two ploidies to -1 and leaves the other header fields alone; the
+    // depths of the file are carried over here so that new.lh has defined numbers where the reference prints whatever was there
+    N.sample_name = O.sample_name; N.ploidy = O.ploidy; N.avg_coverages = O.avg_coverages;
+    N.avg_cov_raw = O.avg_cov_raw; N.avg_virus_dp = O.avg_virus_dp; N.avg_cov_junc = O.avg_cov_junc; N.avg_coverage = O.avg_coverage;
+    N.purity = -1; N.avg_ploidy = -1; N.avg_tumor_ploidy = -1;
+    N.main_chr = O.main_chr; N.ins_mode = O.ins_mode; N.con_mode = O.con_mode; N.ins_chr = O.ins_chr; N.con_chr = O.con_chr; N.start_segs = O.start_segs;
+    for (size_t k = 0; k < R.from.size(); k++) {
+        const int f = R.from[k] - 1;
+        N.seg_id.push_back((int32_t)k + 1); N.seg_chr.push_back(R.chr[k]); N.seg_start.push_back(O.seg_start[f]); N.seg_end.push_back(O.seg_end[f]);
+        N.seg_partition.push_back(0); N.seg_chrom.push_back(O.seg_chrom[f]); N.seg_cov.push_back(O.seg_cov[f]); N.seg_cn.push_back(O.seg_cn[f]);
+    }
+    for (auto& k : kept) {   // plain copies: the reference pushes them without the duplicate test of Graph::addJunction
+        const int j = k[0];
+        N.j_src.push_back(k[1]); N.j_tgt.push_back(k[2]); N.j_sdir.push_back((int8_t)k[3]); N.j_tdir.push_back((int8_t)k[4]);
+        N.j_cov.push_back(O.j_cov[j]); N.j_cn.push_back(O.j_cn[j]); N.j_inferred.push_back(O.j_inferred[j]); N.j_bounded.push_back(O.j_bounded[j]);
+    }
+    N.source_ids.push_back(N.seg_id.front());
+    for (int k = 1; k < N.n_seg(); k++)
+        if (N.seg_chr[k] != N.seg_chr[k - 1]) { N.sink_ids.push_back(N.seg_id[k - 1]); N.source_ids.push_back(N.seg_id[k]); }
+    N.sink_ids.push_back(N.seg_id.back());
+    N.log = g.log;
+    N.trx = T;
+    g = std::move(N);
+}
+}  // namespace
+
+int trx_rebuild(LhGraph& g) {
+    const int n = g.n_seg(), m = g.n_junc();
+    for (int i = 0; i < n; i++) if (g.seg_id[i] != i + 1) return LH_ERR_SEG_IDS;
+    Rebuild R;
+    std::vector<int32_t> unused;
+    std::vector<std::array<int32_t, 5>> kept;
+    auto chrom = [&](int id) -> const std::string& { return g.seg_chrom[id - 1]; };
+    if (g.ins_mode == 1) {
+        // ---- insertBeforeBFB (LGM.cpp:4195-4295): the chain of junctions main -> inserted -> ... -> main gives the segment of the main
+        // chromosome in front of the insertion (sID), the one behind it (eID) and the inserted segments in between
+        const std::vector<std::string>& L = g.ins_chr;
+        std::vector<int> ids;
+        std::vector<char> seen(m, 0);
+        for (size_t i = 1; i < L.size(); i++)
+            for (int j = 0; j < m; j++) {
+                if (seen[j]) continue;
+                const std::string &c1 = chrom(g.j_src[j]), &c2 = chrom(g.j_tgt[j]);
+                const bool fwd = L[i - 1] == c1 && L[i] == c2, back = L[i - 1] == c2 && L[i] == c1;
+                if (!fwd && !back) continue;
+                int id1 = g.j_src[j], id2 = g.j_tgt[j];
+                if (back) std::swap(id1, id2);
+                if (!ids.empty() && ids.back() != id1) {   // the segments between the end of the last junction and the start of this one (:4217-4222)
+                    const int from = ids.back();
+                    if (from < id1) { for (int k = from; k < id1; k++) ids.push_back(k); }
+                    else { for (int k = from; k > id1; k--) ids.push_back(k); }
+                }
+                ids.push_back(id1); ids.push_back(id2);
+                seen[j] = 1;
+                break;
+            }
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        if (ids.size() < 2) return LH_ERR_UNSUPPORTED;      // (the reference reads front() / back() of an empty vector)
+        if (ids.front() > ids.back()) std::reverse(ids.begin(), ids.end());
+        const int sID = ids.front(), eID = ids.back();
+        const std::vector<int> inserted(ids.begin() + 1, ids.end() - 1);
+        for (int id : inserted) if (id < 1 || id > n) return LH_ERR_UNSUPPORTED;
+        std::vector<int> gone_chr;                           // the chromosomes the inserted segments come from disappear as such (:4231-4238)
+        for (int id : inserted) gone_chr.push_back(g.seg_chr[id - 1]);
+        for (int i = 1; i <= n; i++) {
+            if (i < sID || i > eID) {
+                if (std::find(gone_chr.begin(), gone_chr.end(), g.seg_chr[i - 1]) != gone_chr.end()) continue;
+                R.place(i, g.seg_chr[i - 1]);
+            } else {
+                R.place(sID, g.seg_chr[sID - 1]);
+                for (int k = sID + 1; k < eID; k++) R.drop(k);
+                for (int id : inserted) R.place(id, g.seg_chr[sID - 1]);
+                R.place(eID, g.seg_chr[eID - 1]);
+                i = eID;
+            }
+        }
+        for (int j = 0; j < m; j++) {                        // junctions (:4263-4283)
+            if (a_src_of(g, j) == a_tgt_of(g, j)) continue;
+            const int s = g.j_src[j], t = g.j_tgt[j];
+            int id1 = R.conv[s] - 1, id2 = R.conv[t] - 1;   // (operator[]: a segment without an entry gets one, with 0, as in the reference)
+            if (id1 == -1 || id2 == -1) { unused.push_back(j); continue; }
+            int d1 = g.j_sdir[j], d2 = g.j_tdir[j];
+            const bool touches = std::find(inserted.begin(), inserted.end(), s) != inserted.end() || std::find(inserted.begin(), inserted.end(), t) != inserted.end();
+            if (touches) { if (id1 > id2) std::swap(id1, id2); d1 = 1; d2 = 1; }   // the insertion's junctions become plain adjacencies
+            g.log.push_back(std::to_string(s) + "-" + std::to_string(t) + " " + std::to_string(id1 + 1) + "-" + std::to_string(id2 + 1));
+            kept.push_back({j, id1 + 1, id2 + 1, d1, d2});
+        }
+    } else {
+        // ---- concatBeforeBFB (LGM.cpp:4297-4395): the first junction between the two chromosomes; the kept arm of the first one up
+        // to that junction, then the kept arm of the second one from it, both on the first one's chromosome; the other arms have no place
+        if (g.con_chr.size() < 2) return LH_ERR_UNSUPPORTED;
+        int at = -1;
+        for (int j = 0; j < m && at < 0; j++) {
+            const std::string &c1 = chrom(g.j_src[j]), &c2 = chrom(g.j_tgt[j]);
+            if ((c1 == g.con_chr[0] && c2 == g.con_chr[1]) || (c2 == g.con_chr[0] && c1 == g.con_chr[1])) at = j;
+        }
+        if (at < 0) return LH_ERR_UNSUPPORTED;              // (the reference goes on with unset variables)
+        const int sID = g.j_src[at], eID = g.j_tgt[at];
+        const bool s_plus = g.j_sdir[at] > 0, e_plus = g.j_tdir[at] > 0;
+        g.log.push_back("Concat segs: " + std::to_string(sID) + (s_plus ? "+" : "-") + " " + std::to_string(eID) + (e_plus ? "+" : "-"));
+        const int c1 = g.seg_chr[sID - 1], c2 = g.seg_chr[eID - 1], on = g.seg_chr[sID - 1];
+        if (c1 < 0 || c1 >= g.n_chr() || c2 < 0 || c2 >= g.n_chr()) return LH_ERR_UNSUPPORTED;
+        const int lo1 = g.source_ids[c1], hi1 = g.sink_ids[c1], lo2 = g.source_ids[c2], hi2 = g.sink_ids[c2];
+        if (s_plus) { for (int i = lo1; i <= sID; i++) R.place(i, on); for (int i = sID + 1; i <= hi1; i++) R.drop(i); }
+        else { for (int i = hi1; i >= sID; i--) R.place(i, on); for (int i = sID - 1; i >= lo1; i--) R.drop(i); }
+        if (e_plus) { for (int i = eID; i <= hi2; i++) R.place(i, on); for (int i = lo2; i < eID; i++) R.drop(i); }
+        else { for (int i = eID; i >= lo2; i--) R.place(i, on); for (int i = hi2; i > eID; i--) R.drop(i); }
+        for (int i = 1; i <= n; i++) if (g.seg_chr[i - 1] != c1 && g.seg_chr[i - 1] != c2) R.place(i, g.seg_chr[i - 1]);
+        for (int j = 0; j < m; j++) {                        // junctions (:4365-4383)
+            const int s = g.j_src[j], t = g.j_tgt[j];
+            int id1 = R.conv[s] - 1, id2 = R.conv[t] - 1;
+            int d1 = g.j_sdir[j], d2 = g.j_tdir[j];
+            g.log.push_back(std::to_string(s) + (d1 > 0 ? "+" : "-") + " - " + std::to_string(t) + (d2 > 0 ? "+" : "-") + " " + std::to_string(id1 + 1) + "-" + std::to_string(id2 + 1));
+            if (id1 == -1 || id2 == -1) { unused.push_back(j); continue; }
+            if ((s == sID && t == eID) || (s == eID && t == sID)) { if (id1 > id2) std::swap(id1, id2); d1 = 1; d2 = 1; }   // the joint becomes an adjacency
+            kept.push_back({j, id1 + 1, id2 + 1, d1, d2});
+        }
+    }
+    if (R.from.empty()) return LH_ERR_UNSUPPORTED;
+    finish_rebuild(g, R, unused, kept);
+    return LH_OK;
+}
+
+int trx_restore_path(const LhGraph& rebuilt, std::vector<int32_t>& path, std::vector<std::string>& lines) {
+    if (!rebuilt.trx) return LH_ERR_UNSUPPORTED;
+    const TrxBefore& T = *rebuilt.trx;
+    const LhGraph& O = T.original;
+    const int P = (int)path.size();
+    if (P < 2) return LH_ERR_UNSUPPORTED;                   // (path->at(1) throws in the reference)
+    for (int v : path) { const int id = v < 0 ? -v : v; if (id < 1 || id >= (int)T.original_of.size() || T.original_of[id] < 1) return LH_ERR_UNSUPPORTED; }
+    // the vertex a junction of the file leads to from vertex `from` when it is followed to segment `seg`: the FIRST such edge in the
+    // order the reference registered them at `from` (Junction.cpp:95-121: by junction; edge A at its source, edge B at its source,
+    // no edge B for a fold-back of one segment onto itself); 0 if none
+    auto edge_to = [&](int from, int seg) {
+        for (int j = 0; j < O.n_junc(); j++) {
+            const int as = a_src_of(O, j), at = a_tgt_of(O, j);
+            if (as == from && (at < 0 ? -at : at) == seg) return at;
+            const bool self_fold = O.j_sdir[j] != O.j_tdir[j] && O.j_src[j] == O.j_tgt[j];
+            if (!self_fold && -at == from && (as < 0 ? -as : as) == seg) return -as;
+        }
+        return 0;
+    };
+    std::vector<int32_t> out(P);
+    std::vector<char> turn(P, 0);                           // a strand change in front of cell k of the rebuilt path (:3841-3845)
+    for (int k = 1; k < P; k++) turn[k] = (path[k - 1] > 0) != (path[k] > 0);
+    auto file_id = [&](int v) { return T.original_of[v < 0 ? -v : v]; };
+    {   // first vertex (:3847-3875)
+        const int s1 = file_id(path[0]), s2 = file_id(path[1]);
+        if (O.seg_chr[s1 - 1] != O.seg_chr[s2 - 1]) {
+            if (edge_to(s1, s2)) out[0] = s1;
+            else if (edge_to(-s1, s2)) out[0] = -s1;
+            else return LH_ERR_UNSUPPORTED;                  // (the reference keeps the vertex of the rebuilt graph)
+        } else out[0] = path[0] > 0 ? s1 : -s1;
+    }
+    for (int k = 1; k < P; k++) {                           // (:3877-3900)
+        const int seg = file_id(path[k]), prev = out[k - 1];
+        if (O.seg_chr[(prev < 0 ? -prev : prev) - 1] != O.seg_chr[seg - 1]) {   // across the translocation: the strand the junction of the file says
+            const int to = edge_to(prev, seg);
+            if (!to) return LH_ERR_UNSUPPORTED;
+            out[k] = to;
+        } else if (turn[k]) out[k] = prev > 0 ? -seg : seg;
+        else out[k] = prev > 0 ? seg : -seg;
+    }
+    path = out;
+    lines.push_back("TRX-BFB mode: BFB path in the first stage:");
+    lines.push_back(format_path(O, path.data(), (int)path.size()));
+    // second stage (:3904-3938): the first unused junction one of whose edges starts at a vertex of the path cuts it -- either the
+    // head (up to the first occurrence of the other edge's end) or the tail (behind the last occurrence of that start)
+    for (int j : T.unused_sv) {
+        const int as = a_src_of(O, j), at = a_tgt_of(O, j), bs = -at, bt = -as;
+        auto last_of = [&](int v) { for (int i = (int)path.size() - 1; i >= 0; i--) if (path[i] == v) return i; return -1; };
+        auto first_of = [&](int v) { for (int i = 0; i < (int)path.size(); i++) if (path[i] == v) return i; return -1; };
+        bool edge_a = true;
+        int last = last_of(as);
+        if (last < 0) { last = last_of(bs); edge_a = false; }
+        if (last < 0) continue;
+        const int head_end = edge_a ? bt : at, new_head = edge_a ? bs : as, new_tail = edge_a ? at : bt;
+        const int first = first_of(head_end);
+        const int from_back = (int)path.size() - 1 - last;      // pos1 - rbegin()
+        if (first >= 0 && first < from_back) {
+            path.erase(path.begin(), path.begin() + first);
+            path.insert(path.begin(), new_head);
+        } else {
+            path.erase(path.begin() + last + 1, path.end());
+            path.push_back(new_tail);
+        }
+        lines.push_back("TRX-BFB mode: BFB path in the second stage:");
+        lines.push_back(format_path(O, path.data(), (int)path.size()));
+        break;
+    }
     return LH_OK;
 }
 

@@ -4,6 +4,7 @@
 // with SoA vectors: a vertex is a signed segment id, a junction is (src, sdir, tgt, tdir, cn) and its two
 // complementary edges are derived on the fly.
 #pragma once
+#include <memory>
 #include <unordered_map>
 #include <stdint.h>
 #include <string>
@@ -11,7 +12,10 @@
 
 namespace ambi {
 
+struct TrxBefore;
 struct LhGraph {
+    // PROP I1 / C1 (TRX-BFB): this graph is the REBUILT one and `trx` holds what leads back to the graph of the file (below)
+    std::shared_ptr<TrxBefore> trx;
     // header keys (Graph.cpp:140-167)
     std::string sample_name, ploidy;
     std::vector<double> avg_coverages;
@@ -65,7 +69,8 @@ enum LhError {
     LH_ERR_SEG_IDS = -6,       // ids not 1..N in file order (reference indexes segs[id-1])
     LH_ERR_SOL_OPEN = -7,      // reference: "ILP error: cannot open file" + exit(1) (localhap.cpp:187-190)
     LH_ERR_LINE_TOO_LONG = -8, // > 8191 bytes: the reference's getline(line, 8192) never terminates
-    LH_ERR_UNSUPPORTED = -9,   // TRX-BFB modes I1/C1 (reference path is UB)
+    LH_ERR_UNSUPPORTED = -9,   // TRX-BFB (PROP I1 / C1) where the reference reads what nothing has set: no junction between the listed
+                               // chromosomes, a one-vertex path, a .juncs file together with these modes
 };
 const char* lh_error_string(int code);
 
@@ -75,6 +80,25 @@ void copy_num(LhGraph& g);                                        // Graph.cpp:3
 int read_juncs(LhGraph& g, const std::string& path);
 int write_lh(LhGraph& g, const std::string& path);               // Graph.cpp:239-266 Graph::writeGraph              // LGM.cpp:5096-5156 (needs partitions set)
 void set_partitions(LhGraph& g);                                   // localhap.cpp:94-98
+
+// ---- TRX-BFB, PROP I1 / C1 (localhap.cpp:79-88, :263): a translocation that happened BEFORE the BFB cycles -----------------------
+// insertBeforeBFB / concatBeforeBFB (LGM.cpp:4195-4395) rebuild the graph -- the inserted segments spliced into the main
+// chromosome, or the two chromosomes joined at their junction into one -- the BFB stages run on the rebuilt graph, and virusBFB
+// (LGM.cpp:3839-3939) takes every path back to the segments of the file.  The reference ends the rebuild with
+// `new Graph(mSegs, mJuncs, mSources, mSinks)`, a constructor that assigns through pointers it never initialises (Graph.cpp:25-34):
+// its evident intent -- a graph made of copies of the four vectors -- is what is implemented here (the reference holds outputs of
+// both modes: README.md:128-134, :148-157).  read_lh does the rebuild where localhap.cpp does it, between the PROP line and the
+// partitions, so every caller sees the rebuilt graph; g.trx keeps the way back.
+struct TrxBefore {
+    LhGraph original;                    // the graph of the file (after the copy-number maths)
+    std::vector<int32_t> original_of;    // [rebuilt segment id] -> id in the file; [0] unused
+    std::vector<int32_t> unused_sv;      // junctions of the file (indices) whose segments are not both in the rebuilt graph, in file order
+};
+int trx_rebuild(LhGraph& g);             // by g.ins_mode / g.con_mode == 1; the lines the reference prints go to g.log
+// virusBFB: `path` (rebuilt ids) -> ids of the file; lines = what the reference prints (caption + path of the first stage, and of
+// the second stage when one of the unused junctions cuts the path).  LH_ERR_UNSUPPORTED where the reference aborts or leaves a vertex
+// of the rebuilt graph in the path.
+int trx_restore_path(const LhGraph& rebuilt, std::vector<int32_t>& path, std::vector<std::string>& lines);
 
 struct SolFile {                                                   // localhap.cpp:192-212
     bool infeasible = false;

@@ -101,6 +101,24 @@ int ambi_graph_props(const ambi_graph_t* g, int32_t* ins_mode, int32_t* con_mode
 /* calculateHapDepth + calculateCopyNum once more (`--op sc_bfb` does that to its first graph, localhap.cpp:438-439): entries
  * whose copy number is still <= 0 are recomputed and echoed again; new lines are appended to the graph's log. */
 int ambi_graph_recalculate(ambi_graph_t* g);
+/* TRX-BFB, `PROP I1:...` / `PROP C1:...` (a translocation BEFORE the BFB cycles; localhap.cpp:79-88 and :263).  ambi_graph_load does
+ * what the reference does between the PROP line and the chromosome loop: insertBeforeBFB / concatBeforeBFB (LocalGenomicMap.cpp:
+ * 4195-4295 / 4297-4395) rebuild the graph -- so every other entry point (chromosomes, batch units, ILP) sees the REBUILT graph, and
+ * ambi_graph_log holds the lines the reference prints while rebuilding.  The reference's `new Graph(mSegs, mJuncs, mSources, mSinks)`
+ * assigns through pointers it never initialises (Graph.cpp:25-34); its evident meaning -- a graph made of copies of the four
+ * vectors -- is what is implemented.
+ * ambi_graph_trx_before: 0 for an ordinary graph; else the number of entries of the map rebuilt segment id -> id in the file
+ *   (entry 0 unused), copied to original_of.
+ * ambi_graph_trx_restore = LocalGenomicMap::virusBFB (LocalGenomicMap.cpp:3839-3939), called on every reconstructed chromosome's
+ *   path after indelBFB (localhap.cpp:263): path (signed rebuilt ids, `len` cells, room for `cap`) becomes the path over the
+ *   segments of the file; text receives the lines the reference prints (caption + path of the first stage and, when an unused
+ *   junction cuts the path, of the second stage), *text_len its full length.  Returns the new number of cells, or
+ *   AMBI_ERR_UNSUPPORTED where the reference aborts or leaves a vertex of the rebuilt graph in the path.
+ * ambi_graph_trx_original: a handle of its own (ambi_graph_destroy) on the graph of the FILE -- chromosome names and coordinates of
+ *   the vertices of restored paths (the reference's simulation_sv.txt rows, localhap.cpp:326-337). */
+int ambi_graph_trx_before(const ambi_graph_t* g, int32_t* original_of, int32_t cap);
+int ambi_graph_trx_original(const ambi_graph_t* g, ambi_graph_t** out);
+int ambi_graph_trx_restore(const ambi_graph_t* g, int32_t* path, int32_t len, int32_t cap, char* text, int64_t text_cap, int64_t* text_len);
 /* replaces Graph::writeGraph (Graph.cpp:239-266): the graph as it stands -- after the copy-number maths and any junctions
  * ambi_graph_read_juncs added -- as .lh text, byte for byte what the reference writes (fixed SAMPLE_NAME TEST, its seven
  * header keys, numbers in %g form, a 'B' behind every segment); "write seg", which the reference prints to stdout, is

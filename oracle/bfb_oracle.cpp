@@ -862,6 +862,279 @@ void translocationBFB(const Graph& g, std::vector<std::vector<int>>& paths, std:
     log.push_back(formatPath(g, res));
 }
 
+
+// ------------------------------------------------------------------------------------------
+// TRX-BFB: insertBeforeBFB / concatBeforeBFB / virusBFB   (LGM.cpp:4195-4395, 3839-3939)
+// Segment* becomes a segment id of the respective graph, Vertex* a signed id; `new Graph(vectors)` copies the four vectors
+// (see the header).  std::unordered_map<int,int> is the reference's own container: the order of the "Seg conversion" lines is
+// whatever libstdc++ makes of the same sequence of inserts.
+// ------------------------------------------------------------------------------------------
+static Seg copySeg(int newId, int chrId, const Seg& from) {   // Segment::Segment(int, int, Segment*)  Segment.cpp:27-45
+    Seg s;
+    s.id = newId; s.chrId = chrId; s.chrom = from.chrom; s.start = from.start; s.end = from.end;
+    s.cov = from.cov; s.cn = from.cn; s.partition = 0;
+    return s;
+}
+static void rebuiltSourcesSinks(const std::vector<Seg>& mSegs, std::vector<int>& mSources, std::vector<int>& mSinks) {   // LGM.cpp:4254-4262 / :4356-4364
+    mSources.push_back(mSegs[0].id);
+    for (size_t i = 1; i < mSegs.size(); i++)
+        if (mSegs[i].chrId != mSegs[i - 1].chrId) { mSinks.push_back(mSegs[i - 1].id); mSources.push_back(mSegs[i].id); }
+    mSinks.push_back(mSegs.back().id);
+}
+static void finishRebuild(Graph& g, std::vector<Seg>& mSegs, std::vector<Junc>& mJuncs, std::unordered_map<int, int>& segConversion,
+                          TrxMap& map, std::vector<std::string>& log) {
+    std::vector<int> mSources, mSinks;
+    rebuiltSourcesSinks(mSegs, mSources, mSinks);
+    log.push_back("Seg conversion:");                             // LGM.cpp:4285-4291 / :4385-4391
+    map.originalOf.assign(mSegs.size() + 1, 0);
+    for (auto iter = segConversion.begin(); iter != segConversion.end(); iter++) {
+        log.push_back(std::to_string(iter->first) + "-" + std::to_string(iter->second));
+        if (iter->second > 0) map.originalOf[iter->second] = iter->first;
+    }
+    map.original = g;
+    Graph ng;                                                     // Graph(vector...) Graph.cpp:25-34: purity / ploidies -1, the vectors copied
+    ng.purity = -1; ng.avgPloidy = -1; ng.avgTumorPloidy = -1;
+    ng.segs = mSegs; ng.juncs = mJuncs; ng.sourceIds = mSources; ng.sinkIds = mSinks;
+    g = ng;
+    log.push_back("write seg");                                   // g->writeGraph("./new.lh"), Graph.cpp:249
+}
+
+bool insertBeforeBFB(Graph& g, const std::vector<std::string>& insChr, TrxMap& map, std::vector<std::string>& log, std::string& err) {
+    std::unordered_map<int, int> segConversion;
+    const std::vector<Seg>& segs = g.segs;
+    const std::vector<Junc>& juncs = g.juncs;
+    std::vector<Seg> mSegs;
+    std::vector<Junc> mJuncs;
+    auto chromOf = [&](int id) { return segs[id - 1].chrom; };   // junc->getSource()->getChrom()
+    // search for segments and junctions involved in insertion  (:4204-4227)
+    std::vector<int> insertionIDs, deletedChrIDs;
+    std::vector<size_t> visited;
+    for (size_t i = 1; i < insChr.size(); i++) {
+        for (size_t j = 0; j < juncs.size(); j++) {
+            if (std::find(visited.begin(), visited.end(), j) != visited.end()) continue;
+            std::string chr1 = chromOf(juncs[j].src), chr2 = chromOf(juncs[j].tgt);
+            if ((insChr[i - 1] == chr1 && insChr[i] == chr2) || (insChr[i - 1] == chr2 && insChr[i] == chr1)) {
+                int id1 = juncs[j].src, id2 = juncs[j].tgt;
+                if (insChr[i - 1] == chr2 && insChr[i] == chr1) std::swap(id1, id2);
+                if (!insertionIDs.empty() && insertionIDs.back() != id1) {
+                    if (insertionIDs.back() < id1) { for (int k = insertionIDs.back(); k < id1; k++) insertionIDs.push_back(k); }
+                    else { for (int k = insertionIDs.back(); k > id1; k--) insertionIDs.push_back(k); }
+                }
+                insertionIDs.push_back(id1); insertionIDs.push_back(id2);
+                visited.push_back(j);
+                break;
+            }
+        }
+    }
+    insertionIDs.erase(std::unique(insertionIDs.begin(), insertionIDs.end()), insertionIDs.end());
+    if (insertionIDs.size() < 2) { err = "insertBeforeBFB: no junction between the chromosomes of the I1 list (the reference reads an empty vector)"; return false; }
+    if (insertionIDs.front() > insertionIDs.back()) std::reverse(insertionIDs.begin(), insertionIDs.end());
+    const int sID = insertionIDs.front(), eID = insertionIDs.back();
+    insertionIDs.erase(insertionIDs.begin());
+    insertionIDs.pop_back();
+    for (int id : insertionIDs) deletedChrIDs.push_back(segs[id - 1].chrId);
+    // set mSegs  (:4234-4253)
+    for (int i = 1; i <= (int)segs.size(); i++) {
+        if (i < sID || i > eID) {
+            if (std::find(deletedChrIDs.begin(), deletedChrIDs.end(), segs[i - 1].chrId) != deletedChrIDs.end()) continue;
+            segConversion.insert(std::pair<int, int>(i, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[i - 1].chrId, segs[i - 1]));
+        } else {
+            segConversion.insert(std::pair<int, int>(sID, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[sID - 1].chrId, segs[sID - 1]));
+            for (int j = sID + 1; j < eID; j++) segConversion.insert(std::pair<int, int>(j, 0));
+            for (int id : insertionIDs) {
+                segConversion.insert(std::pair<int, int>(id, (int)mSegs.size() + 1));
+                mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[sID - 1].chrId, segs[id - 1]));
+            }
+            segConversion.insert(std::pair<int, int>(eID, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[eID - 1].chrId, segs[eID - 1]));
+            i = eID;
+        }
+    }
+    // set mJuncs  (:4263-4283)
+    for (const Junc& junc : juncs) {
+        if (junc.a_src() == junc.a_tgt()) continue;
+        const int startSegID = junc.src, targetSegID = junc.tgt;
+        int id1 = segConversion[startSegID] - 1, id2 = segConversion[targetSegID] - 1;
+        if (id1 == -1 || id2 == -1) { map.unusedSV.push_back(junc); continue; }
+        char dir1 = junc.sdir, dir2 = junc.tdir;
+        if (std::find(insertionIDs.begin(), insertionIDs.end(), startSegID) != insertionIDs.end() ||
+            std::find(insertionIDs.begin(), insertionIDs.end(), targetSegID) != insertionIDs.end()) {
+            if (id1 > id2) std::swap(id1, id2);
+            dir1 = '+'; dir2 = '+';
+        }
+        log.push_back(std::to_string(startSegID) + "-" + std::to_string(targetSegID) + " " + std::to_string(id1 + 1) + "-" + std::to_string(id2 + 1));
+        Junc nj = junc;
+        nj.src = mSegs[id1].id; nj.tgt = mSegs[id2].id; nj.sdir = dir1; nj.tdir = dir2;
+        mJuncs.push_back(nj);
+    }
+    finishRebuild(g, mSegs, mJuncs, segConversion, map, log);
+    return true;
+}
+
+bool concatBeforeBFB(Graph& g, const std::vector<std::string>& conChr, TrxMap& map, std::vector<std::string>& log, std::string& err) {
+    std::unordered_map<int, int> segConversion;
+    const std::vector<Seg>& segs = g.segs;
+    const std::vector<Junc>& juncs = g.juncs;
+    const std::vector<int>& sources = g.sourceIds; const std::vector<int>& sinks = g.sinkIds;
+    std::vector<Seg> mSegs;
+    std::vector<Junc> mJuncs;
+    if (conChr.size() < 2) { err = "concatBeforeBFB: C1 needs two chromosomes"; return false; }
+    // the junction of the concatenation  (:4305-4323)
+    int sID = 0, eID = 0; char sDir = 0, eDir = 0; bool found = false;
+    for (size_t i = 0; i < juncs.size(); i++) {
+        const Junc& junc = juncs[i];
+        const std::string& c1 = segs[junc.src - 1].chrom; const std::string& c2 = segs[junc.tgt - 1].chrom;
+        if ((c1 == conChr[0] && c2 == conChr[1]) || (c2 == conChr[0] && c1 == conChr[1])) {
+            sID = junc.src; eID = junc.tgt; sDir = junc.sdir; eDir = junc.tdir; found = true;
+            break;
+        }
+    }
+    if (!found) { err = "concatBeforeBFB: no junction between the two chromosomes of the C1 list (the reference reads unset variables)"; return false; }
+    log.push_back("Concat segs: " + std::to_string(sID) + sDir + " " + std::to_string(eID) + eDir);
+    // set mSegs  (:4325-4355)
+    const int chrID1 = segs[sID - 1].chrId;
+    if (sDir == '+') {
+        for (int i = sources[chrID1]; i <= sID; i++) {
+            segConversion.insert(std::pair<int, int>(i, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[sID - 1].chrId, segs[i - 1]));
+        }
+        for (int i = sID + 1; i <= sinks[chrID1]; i++) segConversion.insert(std::pair<int, int>(i, 0));
+    } else {
+        for (int i = sinks[chrID1]; i >= sID; i--) {
+            segConversion.insert(std::pair<int, int>(i, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[sID - 1].chrId, segs[i - 1]));
+        }
+        for (int i = sID - 1; i >= sources[chrID1]; i--) segConversion.insert(std::pair<int, int>(i, 0));
+    }
+    const int chrID2 = segs[eID - 1].chrId;
+    if (eDir == '+') {
+        for (int i = eID; i <= sinks[chrID2]; i++) {
+            segConversion.insert(std::pair<int, int>(i, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[sID - 1].chrId, segs[i - 1]));
+        }
+        for (int i = sources[chrID2]; i < eID; i++) segConversion.insert(std::pair<int, int>(i, 0));
+    } else {
+        for (int i = eID; i >= sources[chrID2]; i--) {
+            segConversion.insert(std::pair<int, int>(i, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[sID - 1].chrId, segs[i - 1]));
+        }
+        for (int i = sinks[chrID2]; i > eID; i--) segConversion.insert(std::pair<int, int>(i, 0));
+    }
+    for (int i = 1; i <= (int)segs.size(); i++) {
+        if (segs[i - 1].chrId != chrID1 && segs[i - 1].chrId != chrID2) {
+            segConversion.insert(std::pair<int, int>(i, (int)mSegs.size() + 1));
+            mSegs.push_back(copySeg((int)mSegs.size() + 1, segs[i - 1].chrId, segs[i - 1]));
+        }
+    }
+    // set mJuncs  (:4365-4383)
+    for (const Junc& junc : juncs) {
+        const int startSegID = junc.src, targetSegID = junc.tgt;
+        int id1 = segConversion[startSegID] - 1, id2 = segConversion[targetSegID] - 1;
+        char dir1 = junc.sdir, dir2 = junc.tdir;
+        log.push_back(std::to_string(startSegID) + dir1 + " - " + std::to_string(targetSegID) + dir2 + " " + std::to_string(id1 + 1) + "-" + std::to_string(id2 + 1));
+        if (id1 == -1 || id2 == -1) { map.unusedSV.push_back(junc); continue; }
+        if ((startSegID == sID && targetSegID == eID) || (startSegID == eID && targetSegID == sID)) {
+            if (id1 > id2) std::swap(id1, id2);
+            dir1 = '+'; dir2 = '+';
+        }
+        Junc nj = junc;
+        nj.src = mSegs[id1].id; nj.tgt = mSegs[id2].id; nj.sdir = dir1; nj.tdir = dir2;
+        mJuncs.push_back(nj);
+    }
+    finishRebuild(g, mSegs, mJuncs, segConversion, map, log);
+    return true;
+}
+
+// edges that leave vertex v of graph g, in the order Junction::insertEdgesToVertices registered them (Junction.cpp:95-121: edge A at
+// its source, edge B at its source -- except for a fold-back of one segment onto itself, whose edge B is never registered): targets
+static std::vector<int> edgeTargetsAsSource(const Graph& g, int v) {
+    std::vector<int> t;
+    for (const Junc& j : g.juncs) {
+        if (j.a_src() == v) t.push_back(j.a_tgt());
+        const bool selfFold = j.sdir != j.tdir && j.src == j.tgt;
+        if (!selfFold && j.b_src() == v) t.push_back(j.b_tgt());
+    }
+    return t;
+}
+
+std::string formatPathMixed(const Graph& original, const Graph& rebuilt, const std::vector<int>& path, const std::vector<char>& rebuiltVertex) {
+    std::string s;
+    auto info = [](int v) { return std::to_string(std::abs(v)) + (v > 0 ? "+" : "-"); };
+    auto chr = [&](size_t i) { const Graph& gg = rebuiltVertex[i] ? rebuilt : original; return gg.segs[std::abs(path[i]) - 1].chrId; };
+    for (size_t i = 1; i < path.size(); i++) {
+        s += info(path[i - 1]);
+        if (chr(i - 1) != chr(i)) s += "||";
+        else if (plus(path[i - 1]) != plus(path[i])) s += "|";
+    }
+    if (!path.empty()) s += info(path.back());
+    return s;
+}
+
+bool virusBFB(const TrxMap& map, const Graph& rebuilt, std::vector<int>& path, std::vector<char>& rebuiltVertex,
+              std::vector<std::string>& log, std::string& err) {
+    const Graph& og = map.original;
+    rebuiltVertex.assign(path.size(), 1);
+    if (path.size() < 2) { err = "virusBFB: a path of one vertex (path->at(1) throws in the reference)"; return false; }
+    auto origSeg = [&](int v) -> const Seg& { return og.segs[map.originalOf[std::abs(v)] - 1]; };   // originalSegs[v->getSegment()]
+    // restore path segment into original segments  (:3841-3845)
+    std::vector<bool> isFBI{false};
+    for (size_t k = 1; k < path.size(); k++) isFBI.push_back(plus(path[k - 1]) != plus(path[k]));
+    // first vertex  (:3847-3875)
+    const Seg& seg1 = origSeg(path[0]); const Seg& seg2 = origSeg(path[1]);
+    if (seg1.chrId != seg2.chrId) {
+        bool found = false;
+        for (int t : edgeTargetsAsSource(og, seg1.id)) if (std::abs(t) == seg2.id) { path[0] = seg1.id; rebuiltVertex[0] = 0; found = true; break; }
+        if (!found) for (int t : edgeTargetsAsSource(og, -seg1.id)) if (std::abs(t) == seg2.id) { path[0] = -seg1.id; rebuiltVertex[0] = 0; break; }
+    } else {
+        path[0] = plus(path[0]) ? seg1.id : -seg1.id; rebuiltVertex[0] = 0;
+    }
+    // remaining vertices  (:3877-3900)
+    for (size_t k = 1; k < path.size(); k++) {
+        const Seg& seg = origSeg(path[k]);
+        const Graph& pg = rebuiltVertex[k - 1] ? rebuilt : og;          // (*(iter-1))->getSegment(): whatever graph that vertex belongs to
+        const int prevChr = pg.segs[std::abs(path[k - 1]) - 1].chrId;
+        if (prevChr != seg.chrId) {
+            // edges of the previous vertex: a vertex of the rebuilt graph has none (its junctions were never registered, LGM.cpp:4281 / :4382)
+            if (!rebuiltVertex[k - 1])
+                for (int t : edgeTargetsAsSource(og, path[k - 1])) if (std::abs(t) == seg.id) { path[k] = t; rebuiltVertex[k] = 0; break; }
+        } else if (isFBI[k]) {
+            path[k] = plus(path[k - 1]) ? -seg.id : seg.id; rebuiltVertex[k] = 0;
+        } else {
+            path[k] = plus(path[k - 1]) ? seg.id : -seg.id; rebuiltVertex[k] = 0;
+        }
+    }
+    log.push_back("TRX-BFB mode: BFB path in the first stage:");
+    log.push_back(formatPathMixed(og, rebuilt, path, rebuiltVertex));
+    // deal with extra SV in the second stage  (:3904-3938); vertex identity = (graph, signed id): the SVs are junctions of the original graph
+    auto findRev = [&](int v) { for (size_t r = 0; r < path.size(); r++) { size_t i = path.size() - 1 - r; if (!rebuiltVertex[i] && path[i] == v) return r; } return path.size(); };   // distance from rbegin()
+    auto findFwd = [&](int v) { for (size_t i = 0; i < path.size(); i++) if (!rebuiltVertex[i] && path[i] == v) return i; return path.size(); };
+    for (size_t i = 0; i < map.unusedSV.size(); i++) {
+        const Junc& sv = map.unusedSV[i];
+        bool isEdgeA = true;
+        size_t pos1 = findRev(sv.a_src());
+        if (pos1 == path.size()) { pos1 = findRev(sv.b_src()); isEdgeA = false; }
+        if (pos1 == path.size()) continue;
+        const int headVertex = isEdgeA ? sv.b_tgt() : sv.a_tgt();         // looked for from the front
+        const int newHead = isEdgeA ? sv.b_src() : sv.a_src();
+        const int newTail = isEdgeA ? sv.a_tgt() : sv.b_tgt();
+        const size_t pos2 = findFwd(headVertex);
+        if (pos2 != path.size() && pos2 < pos1) {
+            path.erase(path.begin(), path.begin() + pos2); rebuiltVertex.erase(rebuiltVertex.begin(), rebuiltVertex.begin() + pos2);
+            path.insert(path.begin(), newHead); rebuiltVertex.insert(rebuiltVertex.begin(), 0);
+        } else {
+            const size_t base = path.size() - pos1;                      // pos1.base(): the element behind the one found
+            path.erase(path.begin() + base, path.end()); rebuiltVertex.erase(rebuiltVertex.begin() + base, rebuiltVertex.end());
+            path.push_back(newTail); rebuiltVertex.push_back(0);
+        }
+        log.push_back("TRX-BFB mode: BFB path in the second stage:");
+        log.push_back(formatPathMixed(og, rebuilt, path, rebuiltVertex));
+        break;
+    }
+    return true;
+}
+
 void synthesizeOutputJuncs(const std::vector<int>& p, std::vector<OutJunc>& out, bool increase) {
     // localhap.cpp:269-289 (increase=true) and :298-315 (BFB-TRX result, increase=false)
     if (p.empty()) return;   // reference: size()-1 underflows on an empty path
@@ -907,7 +1180,16 @@ RunResult runBfb(const RunOptions& opt) {
     g.log.clear();
     Props props;
     readBFBProps(opt.lh, props);
-    if (props.insMode == 1 || props.conMode == 1) { R.err = "TRX-BFB (I1/C1) not supported: reference path is UB (SURVEY 8a-19)"; return R; }
+    TrxMap trx;
+    Graph rebuilt;
+    const bool trxBefore = props.insMode == 1 || props.conMode == 1;     // localhap.cpp:79-88
+    if (trxBefore) {
+        if (!opt.juncs.empty()) { R.err = "TRX-BFB (I1/C1) with a .juncs file: readComponents reads a member of the rebuilt graph that nothing sets"; return R; }
+        if (props.insMode == 1) { if (!insertBeforeBFB(g, props.insChr, trx, R.log, R.err)) return R; }
+        else if (!concatBeforeBFB(g, props.conChr, trx, R.log, R.err)) return R;
+        rebuilt = g;
+        R.trxBefore = true; R.originalOf = trx.originalOf;
+    }
     for (size_t i = 0; i < g.sourceIds.size(); i++)   // localhap.cpp:94-98
         for (int j = g.sourceIds[i]; j <= g.sinkIds[i]; j++) {
             if (j - 1 < 0 || j - 1 >= (int)g.segs.size()) { R.err = "segment ids must be 1..N"; return R; }
@@ -991,6 +1273,11 @@ RunResult runBfb(const RunOptions& opt) {
         st.indelPrinted = indelBFB(g, path, startID, endID, R.log);
         R.reconSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count();
         st.pathAfterIndel = path;
+        if (trxBefore) {                                                 // localhap.cpp:263
+            std::vector<char> rv;
+            if (!virusBFB(trx, rebuilt, path, rv, R.log, R.err)) return R;
+            for (char c : rv) if (c) { R.err = "virusBFB left a vertex of the rebuilt graph in the path (no junction of the original graph leads to its segment)"; return R; }
+        }
         R.paths.push_back(path);
         R.chr.push_back(st);
     }

@@ -144,6 +144,30 @@ std::string formatPath(const Graph& g, const std::vector<int>& path);
 void translocationBFB(const Graph& g, std::vector<std::vector<int>>& paths, std::vector<int>& res,
                       const std::string& mainChr, std::vector<std::string>& log, std::vector<std::string>* trace = nullptr);
 
+// ---- TRX-BFB (PROP I1 / C1): the graph is rebuilt BEFORE the BFB stages and the path mapped back afterwards --------------
+// insertBeforeBFB / concatBeforeBFB end in `new Graph(mSegs, mJuncs, mSources, mSinks)` (LGM.cpp:4293, 4393), a constructor that
+// assigns through pointers it never initialises (Graph.cpp:25-34): undefined behaviour as written.  Its INTENT is unambiguous --
+// a graph whose four vectors are copies of the arguments, every other member as that constructor sets or leaves it -- and the
+// reference holds outputs of both modes (README.md:128-134, :148-157), so the restatement gives the constructor that meaning
+// and says so here.  What stays undefined and is refused: a `.juncs` file together with these modes (readComponents reads the
+// rebuilt graph's mAvgCoverage, which nothing ever sets).
+struct TrxMap {
+    Graph original;                      // the graph as read: its vertices are what virusBFB puts into the path
+    std::vector<int> originalOf;         // [new segment id] -> original id (`originalSegs`, LGM.cpp:4286-4291 / :4386-4391); [0] unused
+    std::vector<Junc> unusedSV;          // junctions of the original graph without a place in the rebuilt one (:4267-4270 / :4372-4375)
+};
+// LGM.cpp:4195-4295 / :4297-4395.  g is replaced by the rebuilt graph; the lines the reference prints go to log.
+// false (+ err): the reference reads an empty vector / an unset variable there.
+bool insertBeforeBFB(Graph& g, const std::vector<std::string>& insChr, TrxMap& map, std::vector<std::string>& log, std::string& err);
+bool concatBeforeBFB(Graph& g, const std::vector<std::string>& conChr, TrxMap& map, std::vector<std::string>& log, std::string& err);
+// LGM.cpp:3839-3939: path holds vertices of the rebuilt graph on entry and (mostly) of the original graph on return; a vertex the
+// reference leaves untouched (no junction of the original graph leads to its segment) stays a vertex of the REBUILT graph:
+// rebuiltVertex[i] tells which graph path[i] belongs to.  false (+ err): path->at(1) on a one-vertex path (the reference aborts).
+bool virusBFB(const TrxMap& map, const Graph& rebuilt, std::vector<int>& path, std::vector<char>& rebuiltVertex,
+              std::vector<std::string>& log, std::string& err);
+// printBFB over such a mixed path
+std::string formatPathMixed(const Graph& original, const Graph& rebuilt, const std::vector<int>& path, const std::vector<char>& rebuiltVertex);
+
 struct OutJunc { int u, v; int count; };           // localhap.cpp:267-293
 void synthesizeOutputJuncs(const std::vector<int>& path, std::vector<OutJunc>& out, bool increase);
 
@@ -178,6 +202,8 @@ struct RunResult {
     std::vector<ChrStage> chr;
     std::vector<std::vector<int>> paths;
     std::vector<int> trxPath; bool trxRun = false; std::vector<std::string> trxTrace;
+    bool trxBefore = false;                        // PROP I1 / C1: `paths` hold ORIGINAL segment ids (after virusBFB), `chr` the stages on the rebuilt graph
+    std::vector<int> originalOf;                   // [rebuilt id] -> original id
     std::vector<OutJunc> outJuncs;
     std::vector<int> targetCN;
     int pathLen = 0, cnSum = 0, maxCN = 0, numInv = 0;

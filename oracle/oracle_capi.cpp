@@ -75,6 +75,7 @@ char* oracle_run_bfb(const char* lh, const char* juncs, const char* sols, int fl
     o << "],\"paths\":"; jarr2(o, R.paths);
     o << ",\"trx_run\":" << (R.trxRun ? "true" : "false") << ",\"trx_path\":"; jarr(o, R.trxPath);
     o << ",\"trx_trace\":["; for (size_t i = 0; i < R.trxTrace.size(); i++) { if (i) o << ','; jstr(o, R.trxTrace[i]); } o << "]";
+    o << ",\"trx_before\":" << (R.trxBefore ? "true" : "false") << ",\"original_of\":"; jarr(o, R.originalOf);
     o << ",\"target_cn\":"; jarr(o, R.targetCN);
     o << ",\"recon_seconds\":" << R.reconSeconds << ",\"path_len\":" << R.pathLen << ",\"cn_sum\":" << R.cnSum << ",\"max_cn\":" << R.maxCN << ",\"num_inv\":" << R.numInv;
     o << ",\"out_juncs\":[";

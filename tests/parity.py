@@ -61,6 +61,9 @@ def compare(lib, oracle, lh, sols, juncs="", reversed_=False, all_=False, keep_o
             diffs.append("chr %d indel_printed differs" % c)
     if [tuple(x) for x in o["out_juncs"]] != e["out_juncs"]:
         diffs.append("output junctions differ")
+    if o.get("trx_before") or e.get("trx_before"):   # PROP I1 / C1: the paths after virusBFB, over the segments of the file
+        if o.get("trx_before") != e.get("trx_before") or o["paths"] != e["paths"]:
+            diffs.append("TRX-BFB: paths after virusBFB differ")
     if o["trx_path"] != e["trx_path"]:
         diffs.append("BFB-TRX path differs")
     return diffs

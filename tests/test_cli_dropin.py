@@ -99,6 +99,39 @@ def check_trx(exe, cwd, oracle):
     assert got[-2:] == ["BFB with translocation:", "1+2+3+4+|4-3-2-|2+3+||6+7+|7-6-|6+7+|7-6-"]
 
 
+def check_trx_before(exe, cwd, oracle):
+    """PROP I1 / C1 (TRX-BFB): stdout line for line as the oracle's -- incl. the lines of the rebuild -- the reference-held README lines, ./new.lh
+    (LGM.cpp:4294 / :4394) and the side-file rows: `input` rows are the REBUILT graph's junctions, `output` rows name segments of the FILE."""
+    import json
+    known = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))
+    for key in ("readme_i1", "readme_c1"):
+        d = known[key]
+        lh, sols = os.path.join(ROOT, d["lh"]), [os.path.join(ROOT, x) for x in d["sols"]]
+        sub = os.path.join(cwd, key)
+        os.makedirs(sub, exist_ok=True)
+        bindir = os.path.join(sub, "bin")
+        fake_cbc(bindir, sols)
+        r = run_cli(exe, sub, bindir, "--op", "bfb", "--in_lh", lh, "--lp_prefix", key)
+        assert r.returncode == 0, r.stderr
+        got = [l for l in r.stdout.splitlines() if not l.startswith("fake cbc")]
+        assert got == oracle.run_bfb(lh, sols)["log"]
+        for line in d["reference_held_lines"]:
+            assert line in got
+        new_lh = open(os.path.join(sub, "new.lh")).read().splitlines()
+        n_seg = sum(l.startswith("SEG ") for l in new_lh)
+        assert n_seg == {"readme_i1": 6, "readme_c1": 7}[key] and new_lh[0] == "SAMPLE_NAME TEST"
+        sv = open(os.path.join(sub, "simulation_sv.txt")).read().strip().splitlines()
+        ins = [l.split("\t") for l in sv if l.endswith("input")]
+        outs = [l.split("\t") for l in sv if l.endswith("output")]
+        assert len(ins) == sum(l.startswith("JUNC ") for l in new_lh)
+        if key == "readme_i1":
+            # the restored path 1+2+3+||6+||4+|4-||6-||3-2-|2+3+||6+... : its first junction step is 3+ -> 6+ (chr8 -> virus), counted with
+            # its complement 6- -> 3-: four times in all
+            assert outs[0][2:9] == ["chr8", "4000", "+", "virus", "1", "+", "4"]
+        row = open(os.path.join(sub, "time.csv")).read().strip().split(",")
+        assert row[1] == str(n_seg)
+
+
 def check_errors(exe, cwd):
     bindir = os.path.join(cwd, "nobin")
     os.makedirs(bindir, exist_ok=True)
@@ -116,6 +149,10 @@ def test_cli_readme(cli, oracle, tmp_path):
 
 def test_cli_two_chromosome_trx(cli, oracle, tmp_path):
     check_trx(cli, str(tmp_path), oracle)
+
+
+def test_cli_trx_before(cli, oracle, tmp_path):
+    check_trx_before(cli, str(tmp_path), oracle)
 
 
 def test_cli_errors(cli, tmp_path):

@@ -160,6 +160,9 @@ def test_cli_on_gpu(hip_lib, oracle, tmp_path):
         d.mkdir()
     t.check_readme(exe, str(d1), oracle)
     t.check_trx(exe, str(d2), oracle)
+    d2b = tmp_path / "b2"
+    d2b.mkdir()
+    t.check_trx_before(exe, str(d2b), oracle)                    # PROP I1 / C1 (README.md:134, :154-157)
     t.check_errors(exe, str(d3))
     t.test_cli_many_chromosomes_one_batch(exe, oracle, d4)       # 8 chromosomes: one probe batch + one reconstruct batch
     t.test_cli_with_a_solver_that_reads_the_lp(exe, d5)          # the written .lp solved for real (HiGHS stand-in for cbc)

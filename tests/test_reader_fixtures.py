@@ -101,7 +101,8 @@ def test_props_hand_derived(hostsim_lib, workdir):
              ("PROP I:chr1:chr9 C:chr1:chr4 M:chr1 S:3:9", (2, 2, "chr1")),
              ("PROP M:chrX", (0, 0, "chrX")),
              ("", (0, 0, "")),
-             # TRX-BFB (modes 1) is the reference's undefined-behaviour path (Graph.cpp:25-34): parsed, then refused
+             # TRX-BFB (modes 1): the graph is rebuilt at once (tests/test_trx_before.py); here no junction joins the listed chromosomes --
+             # the reference reads an empty vector / unset variables there (LGM.cpp:4229, :4324): refused
              ("PROP I1:chr3:chr5 M:chr3", -9),
              ("PROP I:chr1:chr9 C1:chr1:chr4 M:chr1", -9)]
     base = open(os.path.join(ROOT, "tests/data/readme6.lh")).read()
