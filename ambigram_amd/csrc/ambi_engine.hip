@@ -1084,7 +1084,7 @@ static int classified_side_streams(int device, hipStream_t caller, int set, hipS
         out[k++] = of[(size_t)set % of.size()];
     }
     for (int j = k; j < 3; j++) out[j] = k > 0 ? out[j % k] : nullptr;   // fewer classes than streams: some share
-    return k > 0 ? 0 : -31;
+    return k > 0 ? 0 : 1;   // 1: every stream behaves like the caller's (a profiler that serialises the kernels): nothing to choose
 }
 
 // grow-only block of the lease (device memory, or pinned host memory with its device address)
@@ -1841,15 +1841,16 @@ class HipBackend : public Backend {
             // stream seen before costs a look-up)
             static const bool first_prio = [] { const char* e = getenv("AMBI_FIRST_PRIORITY"); return e && atoi(e) != 0; }();
             if (stream_ != classed_for_) {
-                hipStream_t sd[3];
-                if (int rc = classified_side_streams(device_, stream_, (int)(lease_->uses & 1), sd)) return rc;
-                for (int k = 0; k < 3; k++) classed_streams_[k] = sd[k];
+                hipStream_t sd[3] = {nullptr, nullptr, nullptr};
+                const int rc = classified_side_streams(device_, stream_, (int)(lease_->uses & 1), sd);
+                if (rc < 0) return rc;
+                for (int k = 0; k < 3; k++) classed_streams_[k] = rc == 0 ? sd[k] : nullptr;   // (rc 1: keep the lease's streams, rounds 1-3's choice)
                 classed_for_ = stream_;
             }
-            if (want_back_) back_stream_ = classed_streams_[0];
-            if (want_full_) full_stream_ = classed_streams_[1];
-            if (want_first_ && !first_prio) first_stream_ = classed_streams_[2];
-            if (want_lattice_) lattice_stream_ = classed_streams_[2];
+            if (want_back_ && classed_streams_[0]) back_stream_ = classed_streams_[0];
+            if (want_full_ && classed_streams_[1]) full_stream_ = classed_streams_[1];
+            if (want_first_ && !first_prio && classed_streams_[2]) first_stream_ = classed_streams_[2];
+            if (want_lattice_ && classed_streams_[2]) lattice_stream_ = classed_streams_[2];
         }
         t_run_ = std::chrono::steady_clock::now();
         flushed_ = upload_pending_;
@@ -2596,27 +2597,68 @@ class HipBackend : public Backend {
 
 Backend* make_backend() { return new HipBackend(); }
 
-// ILP entries on the device.  Work item = a row, or a 256-entry piece of a long row (rows differ in length by three
-// orders of magnitude: 2 n^2 / 3 entries for a segment row, 2 n for a nesting row).  A wavefront loads 64 items with ONE
-// coalesced 32-byte-per-lane read, then walks them with lane broadcasts -- no dependent global read per row -- and
-// writes consecutive entries to consecutive addresses (coalesced int32 and f64 stores).  12 bytes written per
-// non-zero; 32 bytes read per item.
-struct IlpItem { IlpRowDesc d; int64_t p0; int32_t j0, j1; };
-__global__ __launch_bounds__(256) void ambi_ilp_fill_kernel(const IlpItem* items, int64_t n_items, IlpGeom G, const int32_t* lit_col,
-                                                            const double* lit_val, int32_t* col, double* val) {
-    const int lane = threadIdx.x & 63;
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t mine = w * 64 + lane;
-    IlpItem it;
-    it.d.family = ILP_BIAS; it.d.a = it.d.b = it.d.rep = 0; it.p0 = 0; it.j0 = it.j1 = 0;
-    if (mine < n_items) it = items[mine];
-    for (int k = 0; k < 64; k++) {
-        IlpRowDesc d;
-        d.family = __builtin_amdgcn_readlane(it.d.family, k); d.a = __builtin_amdgcn_readlane(it.d.a, k);
-        d.b = __builtin_amdgcn_readlane(it.d.b, k); d.rep = __builtin_amdgcn_readlane(it.d.rep, k);
-        const int j0 = __builtin_amdgcn_readlane(it.j0, k), j1 = __builtin_amdgcn_readlane(it.j1, k);
-        const int64_t p0 = ((int64_t)__builtin_amdgcn_readlane((int)(it.p0 >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)it.p0, k);
-        for (int j = j0 + lane; j < j1; j += 64) ilp_row_entry(d, G, j, lit_col, lit_val, col + p0 + j, val + p0 + j);
+// ILP entries on the device (LocalGenomicMap::BFB_ILP, LGM.cpp:4397-4752: int32 column + f64 coefficient per non-zero, 56.5 M
+// non-zeros = 0.68 GB at 256 segments).  The non-zero space is cut into chunks of 1024 consecutive positions, one workgroup each, and
+// every thread owns FOUR consecutive positions: one 16-byte store of columns and two of coefficients per thread, 1 KB + 2 KB
+// contiguous per wavefront, every lane busy.  Rows differ in length by three orders of magnitude (2 n^2 / 3 entries for a segment row,
+// one for the innermost nesting rows), so positions, not rows, are dealt out: the host names the first row of every chunk (a merge
+// walk, O(rows + chunks)), the workgroup stages the offsets and descriptors of the rows that reach into its chunk in group memory
+// (at most 1025), a thread finds its row by bisection there; when its four positions lie in one row (almost always) the row family is
+// decided once and the four entries share the piece bounds and the triangle arithmetic (ilp_row_entries<4>), else entry by entry.
+// What bounds it (profiles/r04_notes.md): NOT the stores -- a plain two-array store stream of this very shape runs at 5.76 TB/s
+// (profiles/tools/hbm_write_two_streams.hip), this kernel at 3.4-3.6 -- but instructions per entry: 65.7 M vector instructions in the
+// entry-by-entry form = 122 us of issue time alone.  Rounds 1-3 (one entry per thread, 4- / 8-byte stores) and a form with one
+// wavefront-uniform row piece per step (scalar family dispatch, half the lanes idle on the short pieces) measure 0.190-0.199 and 0.22 ms.
+#ifndef AMBI_ILP_PER
+#define AMBI_ILP_PER 4
+#endif
+constexpr int kIlpChunk = 1024, kIlpStage = kIlpChunk + 4, kIlpPer = AMBI_ILP_PER, kIlpThreads = kIlpChunk / kIlpPer;   // entries per thread (4 or 8), threads per workgroup
+__global__ __launch_bounds__(kIlpThreads) void ambi_ilp_fill_kernel(const IlpRowDesc* rows, const int64_t* row_ptr, const int32_t* chunk_row, int64_t nnz, IlpGeom G,
+                                                            const int32_t* lit_col, const double* lit_val, int32_t* col, double* val) {
+    __shared__ int32_t rel[kIlpStage];          // row offsets relative to the chunk's first position (rows are far shorter than 2^31)
+    __shared__ IlpRowDesc desc[kIlpStage];
+    const int64_t P0 = (int64_t)blockIdx.x * kIlpChunk;
+    const int r_lo = chunk_row[blockIdx.x], R = chunk_row[blockIdx.x + 1] - r_lo + 1;   // rows r_lo .. r_lo + R - 1 reach into the chunk
+    for (int i = threadIdx.x; i <= R; i += blockDim.x) {
+        const int64_t d = row_ptr[r_lo + i] - P0;
+        rel[i] = (int32_t)(d > (int64_t)0x3fffffff ? (int64_t)0x3fffffff : d);
+    }
+    for (int i = threadIdx.x; i < R; i += blockDim.x) desc[i] = rows[r_lo + i];
+    __syncthreads();
+    const int p = kIlpPer * (int)threadIdx.x;
+    const int64_t left = nnz - P0;
+    const int lim = left < (int64_t)kIlpChunk ? (int)left : kIlpChunk;   // positions of this chunk that exist
+    if (p >= lim) return;
+    int lo = 0, hi = R;                         // last staged row that starts at or before p
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rel[mid] <= p) lo = mid; else hi = mid; }
+    int r = lo;
+    while (p >= rel[r + 1]) r++;                // (empty rows are stepped over)
+    int32_t c4[kIlpPer]; double v4[kIlpPer];
+#pragma unroll
+    for (int k = 0; k < kIlpPer; k++) { c4[k] = 0; v4[k] = 0; }
+    const int want = lim - p < kIlpPer ? lim - p : kIlpPer;
+#if defined(AMBI_ILP_NOCOMPUTE)   // timing experiment: the stores without the entries
+    if (true) { for (int k = 0; k < kIlpPer; k++) { c4[k] = p + k + r; v4[k] = 1.0; } }
+#else
+    if (want == kIlpPer && rel[r + 1] - p >= kIlpPer) ilp_row_entries<kIlpPer>(desc[r], G, p - rel[r], kIlpPer, lit_col, lit_val, c4, v4);
+#endif
+    else {
+#pragma unroll
+        for (int k = 0; k < kIlpPer; k++) {
+            const int q = p + k;
+            if (k < want) {
+                while (q >= rel[r + 1]) r++;
+                ilp_row_entry(desc[r], G, (int64_t)(q - rel[r]), lit_col, lit_val, &c4[k], &v4[k]);
+            }
+        }
+    }
+    if (want == kIlpPer) {
+#pragma unroll
+        for (int k = 0; k < kIlpPer; k += 4) *reinterpret_cast<int4*>(col + P0 + p + k) = make_int4(c4[k], c4[k + 1], c4[k + 2], c4[k + 3]);
+#pragma unroll
+        for (int k = 0; k < kIlpPer; k += 2) *reinterpret_cast<double2*>(val + P0 + p + k) = make_double2(v4[k], v4[k + 1]);
+    } else {
+        for (int k = 0; k < want; k++) { col[P0 + p + k] = c4[k]; val[P0 + p + k] = v4[k]; }
     }
 }
 
@@ -2636,15 +2678,22 @@ int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -30;   // AMBI_ERR_NO_DEVICE: no CPU fallback
     const int64_t nnz = row_ptr[n_rows];
-    // work items: rows, long rows in pieces of 256 entries
-    std::vector<IlpItem> items;
-    items.reserve((size_t)n_rows + (size_t)(nnz / 256) + 8);
-    for (int64_t r = 0; r < n_rows; r++) {
-        const int64_t len = row_ptr[r + 1] - row_ptr[r];
-        for (int64_t j = 0; j < len; j += 256) items.push_back(IlpItem{rows[r], row_ptr[r], (int32_t)j, (int32_t)(j + 256 < len ? j + 256 : len)});
+    // the first row of every chunk of kIlpChunk positions (last row that starts at or before the chunk's first position), and the
+    // last row behind the last chunk
+    const int64_t n_chunks = (nnz + kIlpChunk - 1) / kIlpChunk;
+    std::vector<int32_t> chunk_row((size_t)n_chunks + 1, 0);
+    {
+        int64_t r = 0;
+        for (int64_t c = 0; c < n_chunks; c++) {
+            const int64_t pos = c * kIlpChunk;
+            while (r + 1 < n_rows && row_ptr[r + 1] <= pos) r++;
+            chunk_row[(size_t)c] = (int32_t)r;
+        }
+        chunk_row[(size_t)n_chunks] = (int32_t)(n_rows > 0 ? n_rows - 1 : 0);
+        for (int64_t c = 0; c < n_chunks; c++)
+            if (chunk_row[(size_t)c + 1] - chunk_row[(size_t)c] + 2 > kIlpStage) return ST_ERR_BAD_INPUT;   // (more than 1024 rows inside 1024 positions: rows are not empty)
     }
-    const int64_t n_items = (int64_t)items.size();
-    IlpItem* d_items = nullptr;
+    int32_t* d_chunk = nullptr;
     IlpRowDesc* d_rows = nullptr; int64_t* d_ptr = nullptr; int32_t* d_lc = nullptr; double* d_lv = nullptr; int32_t* d_col = nullptr; double* d_val = nullptr;
     HIP_CK(hipMalloc((void**)&d_rows, (size_t)(n_rows > 0 ? n_rows : 1) * sizeof(IlpRowDesc)));
     HIP_CK(hipMalloc((void**)&d_ptr, (size_t)(n_rows + 1) * sizeof(int64_t)));
@@ -2652,21 +2701,21 @@ int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_
     HIP_CK(hipMalloc((void**)&d_lv, (size_t)(n_lit > 0 ? n_lit : 1) * sizeof(double)));
     HIP_CK(hipMalloc((void**)&d_col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
     HIP_CK(hipMalloc((void**)&d_val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double)));
-    HIP_CK(hipMalloc((void**)&d_items, (size_t)(n_items > 0 ? n_items : 1) * sizeof(IlpItem)));
-    HIP_CK(hipMemcpy(d_items, items.data(), (size_t)n_items * sizeof(IlpItem), hipMemcpyHostToDevice));
+    HIP_CK(hipMalloc((void**)&d_chunk, chunk_row.size() * sizeof(int32_t)));
+    HIP_CK(hipMemcpy(d_chunk, chunk_row.data(), chunk_row.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CK(hipMemcpy(d_rows, rows, (size_t)n_rows * sizeof(IlpRowDesc), hipMemcpyHostToDevice));
     HIP_CK(hipMemcpy(d_ptr, row_ptr, (size_t)(n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     if (n_lit > 0) { HIP_CK(hipMemcpy(d_lc, lit_col, (size_t)n_lit * sizeof(int32_t), hipMemcpyHostToDevice)); HIP_CK(hipMemcpy(d_lv, lit_val, (size_t)n_lit * sizeof(double), hipMemcpyHostToDevice)); }
     hipEvent_t ea, eb;
     HIP_CK(hipEventCreate(&ea)); HIP_CK(hipEventCreate(&eb));
-    int64_t grid = ((n_items + 63) / 64 + 3) / 4;   // 64 items per wavefront, 4 wavefronts per workgroup
-    if (grid < 1) grid = 1;
+    const int64_t grid = n_chunks > 0 ? n_chunks : 1;
     const int reps = kernel_ms ? 5 : 1;   // the timed figure is the mean of the last 4 of 5 launches
     float total = 0;
     for (int r = 0; r < reps; r++) {
         HIP_CK(hipEventRecord(ea, nullptr));
-        hipLaunchKernelGGL(ambi_ilp_fill_kernel, dim3((unsigned)grid), dim3(256), 0, nullptr, (const IlpItem*)d_items, n_items, ilp_geom(s, e),
-                           (const int32_t*)d_lc, (const double*)d_lv, d_col, d_val);
+        if (n_chunks > 0)
+            hipLaunchKernelGGL(ambi_ilp_fill_kernel, dim3((unsigned)grid), dim3(256), 0, nullptr, (const IlpRowDesc*)d_rows, (const int64_t*)d_ptr, (const int32_t*)d_chunk, nnz,
+                               ilp_geom(s, e), (const int32_t*)d_lc, (const double*)d_lv, d_col, d_val);
         HIP_CK(hipEventRecord(eb, nullptr));
         HIP_CK(hipEventSynchronize(eb));
         float ms = 0;
@@ -2678,7 +2727,7 @@ int backend_ilp_fill(const IlpRowDesc* rows, int64_t n_rows, const int64_t* row_
     HIP_CK(hipMemcpy(col, d_col, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_CK(hipMemcpy(val, d_val, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
-    (void)hipFree(d_items); (void)hipFree(d_rows); (void)hipFree(d_ptr); (void)hipFree(d_lc); (void)hipFree(d_lv); (void)hipFree(d_col); (void)hipFree(d_val);
+    (void)hipFree(d_chunk); (void)hipFree(d_rows); (void)hipFree(d_ptr); (void)hipFree(d_lc); (void)hipFree(d_lv); (void)hipFree(d_col); (void)hipFree(d_val);
     return 0;
 }
 

@@ -8,6 +8,9 @@
 // Column numbering (localhap.cpp:117-133, LGM.cpp:4409-4410): P(a,b) = rank of (a,b) in the lexicographic list of
 // s <= a <= b <= e; L(a,b) = numPat + P(a,b); then 2n epsilons; then the bias column.
 #pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
 #include "ambi_common.hpp"
 
 namespace ambi {
@@ -25,9 +28,18 @@ enum IlpFamily : int32_t {
 };
 struct IlpRowDesc { int32_t family, a, b, rep; };
 
+// 24-bit multiply: full rate on the GPU where the 32-bit one is quarter rate; every product here stays far below 2^31 and every
+// factor below 2^24 (segment counts are <= 32767)
+AMBI_HD int32_t ilp_mul(int32_t x, int32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(x, y);
+#else
+    return x * y;
+#endif
+}
 struct IlpGeom {   // index arithmetic of the (a,b) triangle
     int32_t s, e, n, num_pat, num_el;
-    AMBI_HD int32_t P(int a, int b) const { const int da = a - s; return da * n - da * (da - 1) / 2 + (b - a); }
+    AMBI_HD int32_t P(int a, int b) const { const int da = a - s; return ilp_mul(da, n) - (ilp_mul(da, da - 1) >> 1) + (b - a); }
     AMBI_HD int32_t L(int a, int b) const { return num_pat + P(a, b); }
 };
 AMBI_HD IlpGeom ilp_geom(int s, int e) {
@@ -114,6 +126,87 @@ AMBI_HD void ilp_row_entry(const IlpRowDesc& d, const IlpGeom& G, int64_t j64, c
             return;
         }
         default: *col = lit_col[d.a + j]; *val = lit_val[d.a + j]; return;
+    }
+}
+
+
+#define AMBI_UNROLL_FIXED _Pragma("unroll")
+// `cnt` (1..4) CONSECUTIVE entries j0 .. j0 + cnt - 1 of one row: the family is decided once, the pieces of the row (runs of entries
+// whose column follows one formula) are walked with the piece bounds and the triangle arithmetic shared between the entries, and the
+// one division of the CN rows (j / w, j % w) is done for the first entry only -- the others step (q, r) forward.  Same values as
+// ilp_row_entry, entry for entry (tests/test_ilp_model.py compares both with the host generator and the oracle).
+template <int FIXED = 0>
+AMBI_HD void ilp_row_entries(const IlpRowDesc& d, const IlpGeom& G, int j0, int cnt_rt, const int32_t* lit_col, const double* lit_val,
+                             int32_t* col, double* val) {
+    const int s = G.s, e = G.e, a = d.a, b = d.b;
+    const int cnt = FIXED > 0 ? FIXED : cnt_rt;   // FIXED: the loops below unroll
+    switch (d.family) {
+        case ILP_CN: {
+            const int w = e - a + 1, c = (a - s + 1) * w;
+            int t = j0 < c ? j0 : (j0 < 2 * c ? j0 - c : 0);
+            int q = t / w, r = t - q * w;
+            AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) {
+                const int j = j0 + k;
+                if (j == c) { q = 0; r = 0; }                      // from the pattern columns to the loop columns
+                if (j < 2 * c) {
+                    const int pa = G.P(s + q, a + r);
+                    col[k] = j < c ? pa : G.num_pat + pa; val[k] = j < c ? 1.0 : 2.0;
+                    if (++r == w) { r = 0; q++; }
+                } else { col[k] = G.num_el + 2 * (a - s); val[k] = d.rep == 0 ? 1.0 : -1.0; }
+            }
+            return;
+        }
+        case ILP_FB: {
+            const int n1 = a - s, n2 = a < e ? e - a + 1 : (a > s ? 1 : 0), n3 = a - s, n4 = e - a + 1;
+            const int e1 = n1, e2 = e1 + n2, e3 = e2 + n3, e4 = e3 + n4;
+            AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) {
+                const int j = j0 + k;
+                if (j < e1) { col[k] = G.P(s + j, a); val[k] = 0.5; }
+                else if (j < e2) { col[k] = G.P(a, a + (j - e1)); val[k] = 0.5; }
+                else if (j < e3) { col[k] = G.L(s + (j - e2), a); val[k] = 1.0; }
+                else if (j < e4) { col[k] = G.L(a, a + (j - e3)); val[k] = 1.0; }
+                else { col[k] = G.num_el + 2 * (a - s) + 1; val[k] = d.rep == 0 ? 1.0 : -1.0; }
+            }
+            return;
+        }
+        case ILP_BIAS: AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) { col[k] = G.num_el + 2 * G.n; val[k] = 1.0; } return;
+        case ILP_PA: {
+            const int n1 = a - s, n2 = e - b, pab = G.P(a, b);
+            AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) {
+                const int j = j0 + k;
+                if (j < n1) { col[k] = G.P(s + j, b); val[k] = 1.0; }
+                else if (j < n1 + n2) { col[k] = pab + 1 + (j - n1); val[k] = 1.0; }   // P(a, b + 1 + t) = P(a, b) + 1 + t
+                else { col[k] = pab; val[k] = -1.0; }
+            }
+            return;
+        }
+        case ILP_LA: {
+            const int n1 = 2 * (a - s), n2 = 2 * (e - b), pab = G.P(a, b);
+            AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) {
+                const int j = j0 + k;
+                if (j < n1) { const int q = j >> 1; col[k] = ((j & 1) ? G.num_pat : 0) + G.P(s + q, b); val[k] = 1.0; }
+                else if (j < n1 + n2) { const int t = j - n1; col[k] = ((t & 1) ? G.num_pat : 0) + pab + 1 + (t >> 1); val[k] = 1.0; }
+                else { col[k] = G.num_pat + pab; val[k] = -1.0; }
+            }
+            return;
+        }
+        case ILP_PB: case ILP_LL: case ILP_PC: {
+            // children of (a,b) that share its start, then those that share its end, then the element itself: the three families differ
+            // in which of the two column halves (patterns / loops) each piece lives in
+            const int w = b - a, paa = G.P(a, a), pab = G.P(a, b);
+            const int off1 = d.family == ILP_PB ? 0 : (d.family == ILP_LL ? G.num_pat : (d.rep == 0 ? G.num_pat : 0));
+            const int off2 = d.family == ILP_PB ? 0 : (d.family == ILP_LL ? G.num_pat : (d.rep == 0 ? 0 : G.num_pat));
+            const int off3 = d.family == ILP_LL && d.rep == 0 ? G.num_pat : 0;
+            AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) {
+                const int j = j0 + k;
+                if (j < w) col[k] = off1 + paa + j;                       // P(a, a + j) = P(a, a) + j
+                else if (j < 2 * w) col[k] = off2 + G.P(a + 1 + (j - w), b);
+                else col[k] = off3 + pab;
+                val[k] = 1.0;
+            }
+            return;
+        }
+        default: AMBI_UNROLL_FIXED for (int k = 0; k < cnt; k++) { col[k] = lit_col[d.a + j0 + k]; val[k] = lit_val[d.a + j0 + k]; } return;
     }
 }
 
