@@ -39,6 +39,11 @@ class Backend {
     virtual int set_device(int d) = 0;
     virtual int upload(const HostBatch& hb, const EngineConfig& cfg) = 0;
     virtual int run(uint32_t flags, void* stream) = 0;
+    // a stream of the backend's own on its device (process lifetime), for callers that have none to pass: nullptr = none (the host
+    // simulation); and a counter that moves whenever the results on the device change after run() has returned (the first run of a
+    // batch done again with a larger arena, units finished by the parallel search at wait())
+    virtual void* own_stream() { return nullptr; }
+    virtual int64_t results_epoch() const { return 0; }
     virtual int wait() = 0;
     virtual int wait_results() { return wait(); }   // results complete; order tables may still be in flight (express path)
     virtual int download(std::vector<uint8_t>& blob) = 0;

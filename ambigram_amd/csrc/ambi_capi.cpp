@@ -4,6 +4,10 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -18,14 +22,80 @@ using namespace ambi;
 
 struct ambi_graph { LhGraph g; };
 
-// one device's share of a batch (ambi_batch_run_sharded): its own packed inputs, backend and result blob
+// One device's share of a batch (ambi_batch_run_sharded): its own packed inputs and backend, RESIDENT on its device from the first
+// call on, and a host thread of its own that lives as long as the share (parked between calls).  What comes back from the device
+// after a run is what a caller of many units wants first -- every unit's header and its final path in run-length form, in pinned
+// memory (Backend::runs_to_host) -- the whole result blob of a share only when a getter asks for something else.
 struct Shard {
     HostBatch hb;
     std::unique_ptr<Backend> be;
-    std::vector<uint8_t> blob;
+    std::vector<uint8_t> blob; bool blob_there = false;    // downloaded on demand
+    RunsView view{}; bool view_there = false;
     std::vector<int> units;     // local unit -> unit of the batch
     int device = 0, rc = 0;
     bool uploaded = false;
+    // the worker: go / done are counted, flags / cfg belong to the call in flight
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::atomic<long> go{0}, done{0}; std::atomic<bool> quit{false}; uint32_t flags = 0; const EngineConfig* cfg = nullptr;
+    // (both sides spin for a moment before they block: a parked thread takes 50-100 us to wake, a call takes ~1 ms)
+    template <class F> static bool spin_for(F&& cond, int us) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!cond()) { if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us)) return false; __builtin_ia32_pause(); }
+        return true;
+    }
+    void work() {
+        rc = 0; view_there = false; blob_there = false;
+        if (units.empty()) return;
+        if ((rc = be->set_device(device))) return;
+        if (!uploaded) { if ((rc = be->upload(hb, *cfg))) return; uploaded = true; }
+        void* st = be->own_stream();
+        if ((rc = be->run(flags, st))) return;
+        // headers + run-length final paths follow the run's kernels to the host; ONE blocking wait (for that copy: the kernels are
+        // complete when it is), then wait() on an idle stream for what the host still has to look at (the first run of a batch done
+        // again with a larger arena, units finished by the parallel search, --all) -- if that changed results, their copy once more
+        for (int attempt = 0; attempt < 3; attempt++) {
+            const int64_t e0 = be->results_epoch();
+            if ((rc = be->runs_to_host(1, 0, 1, st))) return;
+            if ((rc = be->runs_wait(0, &view))) return;
+            if ((rc = be->wait())) return;
+            if (be->results_epoch() == e0) break;
+        }
+        view_there = view.headers != nullptr;
+        if (!view_there) { rc = be->download(blob); blob_there = rc == 0; }   // (a backend without the pinned view: the blob at once)
+    }
+    void loop() {
+        for (;;) {
+            if (!spin_for([&] { return quit || go.load() > done.load(); }, 2000)) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || go.load() > done.load(); });
+            }
+            if (quit) return;
+            work();
+            { std::lock_guard<std::mutex> lk(mu); done++; }
+            cv.notify_all();
+        }
+    }
+    void start(uint32_t f, const EngineConfig* c) {
+        { std::lock_guard<std::mutex> lk(mu); flags = f; cfg = c; go++; }
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        cv.notify_all();
+    }
+    void finish() {
+        if (spin_for([&] { return done.load() >= go.load(); }, 5000)) return;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done.load() >= go.load(); });
+    }
+    int fetch_blob() {   // the share's whole result blob, once per run
+        if (blob_there) return 0;
+        const int r = be->download(blob);   // (the backend selects its own device for the call)
+        blob_there = r == 0;
+        return r;
+    }
+    ~Shard() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
 };
 
 struct ambi_batch {
@@ -43,6 +113,7 @@ struct ambi_batch {
     std::vector<uint8_t> blob;
     RunsView runs[2] = {};                              // ambi_batch_runs_wait: what arrived in the slot
     bool uploaded = false, downloaded = false;
+    bool sharded_ready = false;   // ambi_batch_run_sharded has run: results are read where the shares left them (headers + run-length paths; a share's blob on demand)
     bool mail_view = false;   // header / final paths / output junctions are read from the backend's pinned mailbox (ambi_batch_fetch_paths)
 };
 
@@ -388,32 +459,14 @@ int ambi_batch_run_sharded(ambi_batch_t* b, uint32_t flags, const int32_t* devic
         for (auto& s : b->shards) s->hb.finalize();
     }
     b->hb.finalize();
-    b->downloaded = false; b->mail_view = false;
-    auto work = [&](Shard* s) {
-        s->rc = 0;
-        if (s->units.empty()) return;
-        if ((s->rc = s->be->set_device(s->device))) return;
-        if (!s->uploaded) { if ((s->rc = s->be->upload(s->hb, b->cfg))) return; s->uploaded = true; }
-        if ((s->rc = s->be->run(flags, nullptr))) return;
-        s->rc = s->be->download(s->blob);
-    };
-    // every share on a thread of its own, the first one too: set_device changes the current device of the thread that calls
-    // it, and the caller's thread keeps the device it had
-    std::vector<std::thread> threads;
-    for (int k = 0; k < N; k++) threads.emplace_back(work, b->shards[k].get());
-    for (auto& t : threads) t.join();
+    b->downloaded = false; b->mail_view = false; b->sharded_ready = false;
+    // every share on its own (resident) thread, the first one too: set_device changes the current device of the thread that calls it,
+    // and the caller's thread keeps the device it had.  Nothing is merged: the getters read a unit where its share left it.
+    for (auto& s : b->shards) s->start(flags, &b->cfg);
+    for (auto& s : b->shards) s->finish();
     for (auto& s : b->shards) if (s->rc) return s->rc;
-    // merge: the header and the variable part of every unit go where a single-device download would have put them
-    b->blob.assign((size_t)b->hb.result_bytes, 0);
-    for (int u = 0; u < U; u++) {
-        const Shard& s = *b->shards[b->where[u].first];
-        const int l = b->where[u].second;
-        const UnitIn& P = b->hb.units[u];
-        const UnitIn& Q = s.hb.units[l];
-        memcpy(b->blob.data() + sizeof(UnitOut) * (size_t)u, s.blob.data() + sizeof(UnitOut) * (size_t)l, sizeof(UnitOut));
-        const UnitLayout L = unit_layout(P.n_seg, P.bkp_cap, P.path_cap, P.out_cap);
-        memcpy(b->blob.data() + P.res_off, s.blob.data() + Q.res_off, (size_t)L.total);
-    }
+    b->blob.clear();
+    b->sharded_ready = true;
     b->downloaded = true;
     return 0;
 }
@@ -465,9 +518,25 @@ int ambi_batch_pack_paths(ambi_batch_t* b, int32_t which, int32_t* dev_lengths, 
     return b->be->pack_paths(which, dev_lengths, dev_cells, cell_cap, dev_total_cells, hip_stream);
 }
 
+// Where a unit's results are: the batch's downloaded blob, or -- after ambi_batch_run_sharded -- its share's (the header from the pinned
+// view that came back with the run, the blob itself fetched from the share's device the first time something else is asked for).
+struct UnitRef { const UnitOut* h; const uint8_t* blob; const UnitIn* U; Shard* shard; int local; };
+static bool unit_ref(const ambi_batch_t* b, int unit, UnitRef& r, bool need_blob) {
+    if (!b || !b->downloaded || unit < 0 || unit >= (int)b->hb.units.size()) return false;
+    if (!b->sharded_ready) {
+        r = UnitRef{reinterpret_cast<const UnitOut*>(b->blob.data()) + unit, b->blob.data(), &b->hb.units[unit], nullptr, unit};
+        return true;
+    }
+    Shard* S = b->shards[b->where[unit].first].get();
+    const int l = b->where[unit].second;
+    if ((need_blob || !S->view_there) && S->fetch_blob() != 0) return false;
+    const UnitOut* h = S->view_there ? reinterpret_cast<const UnitOut*>(S->view.headers) + l : reinterpret_cast<const UnitOut*>(S->blob.data()) + l;
+    r = UnitRef{h, S->blob_there ? S->blob.data() : nullptr, &S->hb.units[l], S, l};
+    return true;
+}
 static const UnitOut* header(const ambi_batch_t* b, int unit) {
-    if (!b || !b->downloaded || unit < 0 || unit >= (int)b->hb.units.size()) return nullptr;
-    return reinterpret_cast<const UnitOut*>(b->blob.data()) + unit;
+    UnitRef r;
+    return unit_ref(b, unit, r, false) ? r.h : nullptr;
 }
 // The parts of a unit's results that ambi_batch_fetch_paths makes available: from the downloaded blob, or straight from the
 // backend's pinned mailbox (MailLayout) when the batch took the express path.
@@ -476,9 +545,12 @@ static bool path_view(const ambi_batch_t* b, int unit, PathView& v) {
     if (!b || unit < 0 || unit >= (int)b->hb.units.size()) return false;
     const UnitIn& U = b->hb.units[unit];
     if (b->downloaded) {
-        const UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-        const uint8_t* r = b->blob.data() + U.res_off;
-        v = PathView{reinterpret_cast<const UnitOut*>(b->blob.data()) + unit, reinterpret_cast<const rcell_t*>(r + L.path),
+        UnitRef R;
+        if (!unit_ref(b, unit, R, true)) return false;
+        const UnitIn& Q = *R.U;
+        const UnitLayout L = unit_layout(Q.n_seg, Q.bkp_cap, Q.path_cap, Q.out_cap);
+        const uint8_t* r = R.blob + Q.res_off;
+        v = PathView{R.h, reinterpret_cast<const rcell_t*>(r + L.path),
                      reinterpret_cast<const rcell_t*>(r + L.path_ind), reinterpret_cast<const OutJunc*>(r + L.out_junc), false};
         return true;
     }
@@ -493,6 +565,11 @@ static bool path_view(const ambi_batch_t* b, int unit, PathView& v) {
 
 int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result_t* out) {
     PathView pv;
+    pv.mail = false;
+    if (b && b->sharded_ready) {   // the header came back with the run: no blob needed
+        pv.h = header(b, unit);
+        if (!pv.h || !out) return AMBI_ERR_ARG;
+    } else
     if (!path_view(b, unit, pv) || !out) return b && !b->downloaded && !b->mail_view ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     const UnitOut* h = pv.h;
     out->status = h->status; out->bias = h->bias; out->n_nodes = h->K; out->bkp_len = h->bkp_len;
@@ -504,6 +581,18 @@ int ambi_batch_unit_result(const ambi_batch_t* b, int32_t unit, ambi_unit_result
     return 0;
 }
 int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int32_t* out, int32_t cap) {
+    if (b && b->sharded_ready) {
+        // the final path came back in run-length form with the run; it is also the path before indelBFB unless that stage edited it
+        UnitRef R;
+        if (!unit_ref(b, unit, R, false)) return AMBI_ERR_ARG;
+        if (R.shard->view_there && (which || !R.h->path_ind_stored)) {
+            const RunsView& v = R.shard->view;
+            int at = 0;
+            for (int64_t r = v.run_off[R.local]; r < v.run_off[R.local] + v.run_counts[R.local]; r++)
+                for (int k = 0; k < v.run_len[r]; k++, at++) if (out && at < cap) out[at] = v.run_start[r] + k;
+            return at;
+        }
+    }
     PathView pv;
     if (!path_view(b, unit, pv)) return b && !b->downloaded && !b->mail_view ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     const UnitOut* h = pv.h;
@@ -517,9 +606,11 @@ int ambi_batch_unit_path(const ambi_batch_t* b, int32_t unit, int32_t which, int
 int ambi_batch_unit_bkp(const ambi_batch_t* b, int32_t unit, int32_t* out, int32_t cap) {
     const UnitOut* h = header(b, unit);
     if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
-    const UnitIn& U = b->hb.units[unit];
+    UnitRef R;
+    if (!unit_ref(b, unit, R, true)) return AMBI_ERR_STATE;
+    const UnitIn& U = *R.U;
     UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-    const int16_t* src = reinterpret_cast<const int16_t*>(b->blob.data() + U.res_off + L.bkp);
+    const int16_t* src = reinterpret_cast<const int16_t*>(R.blob + U.res_off + L.bkp);
     if (out) for (int i = 0; i < h->bkp_len && i < cap; i++) { int v = src[i]; out[i] = v > 0 ? v + U.seg_base : v - U.seg_base; }
     return h->bkp_len;
 }
@@ -527,9 +618,11 @@ int ambi_batch_unit_prepare(const ambi_batch_t* b, int32_t unit, double* junc_cn
                             int32_t* inv_junc_global) {
     const UnitOut* h = header(b, unit);
     if (!h) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
-    const UnitIn& U = b->hb.units[unit];
+    UnitRef R;
+    if (!unit_ref(b, unit, R, true)) return AMBI_ERR_STATE;
+    const UnitIn& U = *R.U;
     UnitLayout L = unit_layout(U.n_seg, U.bkp_cap, U.path_cap, U.out_cap);
-    const uint8_t* r = b->blob.data() + U.res_off;
+    const uint8_t* r = R.blob + U.res_off;
     const int n = U.n_seg;
     if (junc_cn) memcpy(junc_cn, r + L.junc_cn, sizeof(double) * 2 * (n + 1));
     if (seg_cn) memcpy(seg_cn, r + L.seg_cn, sizeof(double) * (n + 1));

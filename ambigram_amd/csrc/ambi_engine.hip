@@ -940,6 +940,7 @@ struct Lease {
     // a copy stream of the lease's own and two events per slot (packed / arrived)
     uint8_t* d_runs[2] = {nullptr, nullptr}; int64_t d_runs_bytes[2] = {0, 0};
     uint8_t* h_runs[2] = {nullptr, nullptr}; int64_t h_runs_bytes[2] = {0, 0};
+    hipStream_t run_stream = nullptr;   // own_stream(): for callers without a stream (ambi_batch_run_sharded's shares)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_runs_packed[2] = {nullptr, nullptr}, ev_runs_done[2] = {nullptr, nullptr};
     std::vector<TimingEvents> evs;
     std::vector<hipStream_t> slice_streams; std::vector<hipEvent_t> slice_events;     // AMBI_SLICES experiments
@@ -1246,6 +1247,7 @@ class HipBackend : public Backend {
         for (auto& kind : lease_->side) for (hipStream_t s : kind) if (s) (void)hipStreamSynchronize(s);
         for (hipStream_t s : lease_->slice_streams) (void)hipStreamSynchronize(s);
         if (lease_->copy_stream) (void)hipStreamSynchronize(lease_->copy_stream);
+        if (lease_->run_stream) (void)hipStreamSynchronize(lease_->run_stream);
         for (hipStream_t s : classed_streams_) if (s) (void)hipStreamSynchronize(s);
         (void)hipGetLastError();
     }
@@ -1831,8 +1833,17 @@ class HipBackend : public Backend {
     // arena the lease has: the plan kernel reports what the tables need, and wait() grows the arena and runs the batch again
     // if that was not enough (round 2 ran prepare + plan, synchronised, sized the arena and only then queued the run --
     // two host round trips in front of every fresh batch).  AMBI_SLICES > 1 (an experiment) keeps the sizing pass.
+    int64_t epoch_ = 0;
+    int64_t results_epoch() const override { return epoch_; }
+    void* own_stream() override {
+        DeviceGuard dg_(device_);
+        if (!lease_) return nullptr;
+        if (!lease_->run_stream && hipStreamCreateWithFlags(&lease_->run_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return lease_->run_stream;
+    }
     int run(uint32_t flags, void* stream) override {
         DeviceGuard dg_(device_);
+        epoch_++;
         if (!uploaded_) return -32;
         if (ran_ && !tuned_ && tables_written_) { if (int rc = tune_after_first_run()) return rc; }
         stream_ = (hipStream_t)stream;
@@ -2060,6 +2071,7 @@ class HipBackend : public Backend {
 
     // parallel search for units whose sequential scan ran out of budget (rare)
     int slow_path() {
+        epoch_++;
         const int U = A_.n_units;
         std::vector<UnitOut> hdr(U);
         HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));
@@ -2445,6 +2457,7 @@ class HipBackend : public Backend {
     // and unit stay in HBM, the host reads the per-unit counts (one copy) and a unit's bitmap only when its indices are
     // asked for; the paths are produced on demand by all_paths().
     int compute_all() {
+        epoch_++;   // (the finalize kernel rewrites `evaluated` and the statuses of units with an undefined order)
         const int U = (int)hb().units.size();
         std::vector<UnitOut> hdr(U);
         HIP_CK(hipMemcpy(hdr.data(), d_results_, U * sizeof(UnitOut), hipMemcpyDeviceToHost));

@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--pipelined", type=int, default=1, help="1: also report the throughput with two resident batches on two streams (N = 1 only)")
     ap.add_argument("--host-paths", type=int, default=1, help="1: also report the step that ENDS WITH THE PATHS ON THE HOST (packed runs + one D2H per step, double-buffered; SURVEY.md 8d's region)")
     ap.add_argument("--streams-leg", type=int, default=1, help="1: also report the step on a stream of the caller's own and, in a child process, behind a one-rank RCCL group")
+    ap.add_argument("--sharded-leg", type=int, default=1, help="1: also report ambi_batch_run_sharded (the C-level multi-device driver) with 1 / 2 / 4 shares of the batch on the ONE GPU")
     ap.add_argument("--lazy", type=int, default=1, help="1: also report the step without the order tables (AMBI_FLAG_LAZY_ORDERS); 0: skip that leg")
     ap.add_argument("--target-lanes", type=int, default=0)
     ap.add_argument("--slices", type=int, default=0, help="unit ranges run on separate HIP streams (0: engine default)")
@@ -387,6 +388,36 @@ def main():
                        "note": rccl_note or "rccl_one_rank: a child process (its own synthetic batch of the same seeds + 1000, boxes' run-to-run spread applies)"}
         batch.run(0, stream); batch.wait(); batch.download()
 
+    # ---- ambi_batch_run_sharded, the multi-device driver below Python (north star: "samples shard across the 8 GPUs of one node"), with
+    # 1 / 2 / 4 SHARES of the same 4096 samples on the ONE GPU of this box: every share has its own resident inputs, backend, stream and
+    # host thread; what comes back per call is every unit's header and final path in run-length form (pinned memory), nothing is merged.
+    # The host-side cost per call and the loss against one share are the figures that carry over to N devices (where the shares do not
+    # compete for one GPU); no scaling curve is claimed from this.
+    sharded = None
+    if world == 1 and args.sharded_leg:
+        sharded = {}
+        for k in (1, 2, 4):
+            sb = api.Batch(lib)
+            sb.configure(target_lanes=args.target_lanes)
+            for g, (lh, sols) in zip(graphs, files):
+                sb.add_chromosome_sol(g, 0, sols[0])
+            devs = [local_rank] * k
+            for _ in range(max(args.warmup, 2)):
+                sb.run_sharded(0, devs)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sb.run_sharded(0, devs)
+            dts = time.perf_counter() - t1
+            for u in range(0, B, max(1, B // 32)):
+                assert sb.unit_path(u, 1).tolist() == batch.unit_path(u, 1).tolist(), "sharded run: path of unit %d differs" % u
+            sharded["%d_shares" % k] = {"ms_per_call": dts / args.steps * 1e3, "value": B * args.steps / dts}
+            sb.close()
+        sharded["unit"] = "reconstructions/s"
+        sharded["four_shares_vs_one"] = sharded["4_shares"]["value"] / sharded["1_shares"]["value"]
+        sharded["one_share_vs_step_in_hbm"] = sharded["1_shares"]["ms_per_call"] / ms_per_step
+        sharded["how"] = ("ambi_batch_run_sharded(flags, [0] * k): per call every share runs its resident units on a stream of its own and copies headers + run-length "
+                          "final paths to pinned memory (ONE D2H per share); the call returns when all shares have; k shares on ONE GPU compete for it")
+
     # ---- the step WITHOUT the order tables (AMBI_FLAG_LAZY_ORDERS: tables written on demand only).  The reference materialises
     # every topological order (LGM.cpp:3380-3409) and so does the headline step; in default mode nothing reads that table
     # (the scan reads the first orders the lattice stage unranks), so this is what the reconstructions alone cost.
@@ -607,7 +638,7 @@ def main():
                                   ("%d-th" % args.sv_every) if args.sv_every > 0 else "no", B),
                    "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths (run-length form, expanded on rank 0) at the end of the timed steps", 2: "; one RCCL gather of the paths (run-length form) to rank 0 at the end of every step"}[gather_mode])},
         "roofline": roofline, "cpu_baseline": cpu, "single_sample": single, "pipelined": pipelined,
-        "paths_on_host": host_paths, "streams": streams_leg,
+        "paths_on_host": host_paths, "streams": streams_leg, "sharded_on_one_gpu": sharded,
         "own_stream_ms_per_step": streams_leg["own_stream_ms_per_step"] if streams_leg else None,
         "rccl_one_rank_ms_per_step": streams_leg["rccl_one_rank_ms_per_step"] if streams_leg else None,
         "step_without_table_ms": lazy["ms_per_step"] if lazy else None, "step_without_table": lazy,

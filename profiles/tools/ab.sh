@@ -7,7 +7,7 @@ for r in $(seq 1 $reps); do
   i=0
   for cfg in "$@"; do
     i=$((i+1))
-    env $cfg timeout -k 10 300 python3 bench.py --cpu-seconds 0 --single-reps 0 --all-steps 0 --pipelined 0 --host-paths 0 --streams-leg 0 $AB_ARGS > gpurun_out/ab_${i}_${r}.log 2>&1
+    env $cfg timeout -k 10 300 python3 bench.py --cpu-seconds 0 --single-reps 0 --all-steps 0 --pipelined 0 --host-paths 0 --streams-leg 0 --sharded-leg 0 $AB_ARGS > gpurun_out/ab_${i}_${r}.log 2>&1
     python3 - "$cfg" gpurun_out/ab_${i}_${r}.log <<'EOF'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

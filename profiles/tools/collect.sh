@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --all-steps 0 --lazy 0 --host-paths 0 --streams-leg 0 --steps 10 --warmup 3"   # batch leg only: the single-sample and two-batch legs would mix other launches into the per-kernel means
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --all-steps 0 --lazy 0 --host-paths 0 --streams-leg 0 --sharded-leg 0 --steps 10 --warmup 3"   # batch leg only: the single-sample and two-batch legs would mix other launches into the per-kernel means
 
 pass() {   # name, rocprofv3 flags ...
     local name=$1; shift
@@ -32,7 +32,7 @@ python3 profiles/summarize_rocpd.py traffic "$wr" "$rd" "$SUM/traffic_${TAG}.jso
 db=$(pass pmc_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS)
 python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_bench_b4096_pmc_sq.csv" > /dev/null
 # the --all leg (fused unrank + evaluate kernel) and the ILP fill kernel: their own kernel-trace passes
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --lazy 0 --host-paths 0 --streams-leg 0 --all-steps 2 --steps 2 --warmup 1 --batch 1024"
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --lazy 0 --host-paths 0 --streams-leg 0 --sharded-leg 0 --all-steps 2 --steps 2 --warmup 1 --batch 1024"
 db=$(pass all_mode --kernel-trace --stats)
 python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_bench_b1024_allmode_kernel_stats.csv"
 # group-memory side of the --all kernel (one thread per order): instruction counts and bank conflicts

@@ -438,7 +438,7 @@ class HostSimBackend : public Backend {
         const int32_t* w = run_blk_.data();
         int64_t nr = 0, nc = 0;
         for (int64_t u = 0; u < U; u++) { if (w[u] < 0) return ST_ERR_BAD_INPUT; nr += w[u]; nc += w[U + u]; }
-        *out = RunsView{nr, nc, w + U, w, w + 2 * U, w + 2 * U + tot, hb_.run_slot.data(), nullptr, (2 * U + 2 * nr) * 4, (2 * U + 2 * tot) * 4};
+        *out = RunsView{nr, nc, w + U, w, w + 2 * U, w + 2 * U + tot, hb_.run_slot.data(), results_.data(), (2 * U + 2 * nr) * 4, (2 * U + 2 * tot) * 4};
         return 0;
     }
     void set_timing(bool) override {}
