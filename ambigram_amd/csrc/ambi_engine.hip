@@ -1169,6 +1169,7 @@ class HipBackend : public Backend {
     BatchArgs A_{};
     int lds_prepare_ = 0, lds_first_ = 0, lds_finish_ = 0, lds_finish_lean_ = 0, lds_enum_ = 0;
     bool lean_finish_ = true;   // env AMBI_LEAN_FINISH=0: every unit through the full finish stage
+    int lean_threads_ = 256;   // env AMBI_LEAN_THREADS (128 / 256): threads per workgroup of the lean finish kernel
     int lean_wave_ = 0, lean_wave_grid_ = 0;   // env AMBI_LEAN_WAVE=1: the lean stage on one wavefront per unit; AMBI_LEAN_WAVE_GRID: its wavefronts
     int finish_grid_ = 0;       // workgroups of the lean finish kernel; 0 = sized per run (env AMBI_FINISH_GRID overrides)
     int32_t* d_blocks_done_ = nullptr; int32_t* d_refin_list_ = nullptr; int32_t* d_refin_count_ = nullptr;
@@ -1391,6 +1392,7 @@ class HipBackend : public Backend {
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
         { const char* e = getenv("AMBI_LEAN_WAVE"); lean_wave_ = e ? atoi(e) : 0; }
+        { const char* e = getenv("AMBI_LEAN_THREADS"); lean_threads_ = e ? atoi(e) : 256; if (lean_threads_ != 128) lean_threads_ = 256;   // (measured, lean grid re-tuned for each: 128 threads 0.94-1.00, 256 threads 0.90 ms per step on one box) }
         { const char* e = getenv("AMBI_LEAN_WAVE_GRID"); lean_wave_grid_ = e ? atoi(e) : 0; if (lean_wave_grid_ < 0) lean_wave_grid_ = 0; }
         enum_stack_lds_ = (int)enum_stack_bytes(H.max_k > 0 ? H.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
@@ -1814,7 +1816,7 @@ class HipBackend : public Backend {
                 const int wg = lean_wave_grid_ > 0 ? (lean_wave_grid_ < U ? lean_wave_grid_ : U) : (fgrid < U ? std::min(U, 4 * fgrid) : U);
                 hipLaunchKernelGGL(ambi_finish_lean_wave_kernel, dim3(wg), dim3(64), lds_finish_lean_, sb, A);
             } else
-            hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(256), lds_finish_lean_, sb, A, (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(ambi_finish_lean_kernel, dim3(fgrid), dim3(lean_threads_), lds_finish_lean_, sb, A, (const int32_t*)nullptr, 0);
             // units whose SVs chain or edit the path: the full stage right behind, over the list the lean kernel left on the
             // device (an empty list costs one launch of workgroups that exit at once)
             if (hb().any_sv) {
