@@ -1392,7 +1392,8 @@ class HipBackend : public Backend {
         { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
         { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
         { const char* e = getenv("AMBI_LEAN_WAVE"); lean_wave_ = e ? atoi(e) : 0; }
-        { const char* e = getenv("AMBI_LEAN_THREADS"); lean_threads_ = e ? atoi(e) : 256; if (lean_threads_ != 128) lean_threads_ = 256;   // (measured, lean grid re-tuned for each: 128 threads 0.94-1.00, 256 threads 0.90 ms per step on one box) }
+        // (measured, lean grid re-tuned for each: 128 threads 0.94-1.00, 256 threads 0.90 ms per step on one box)
+        { const char* e = getenv("AMBI_LEAN_THREADS"); lean_threads_ = e ? atoi(e) : 256; if (lean_threads_ != 128) lean_threads_ = 256; }
         { const char* e = getenv("AMBI_LEAN_WAVE_GRID"); lean_wave_grid_ = e ? atoi(e) : 0; if (lean_wave_grid_ < 0) lean_wave_grid_ = 0; }
         enum_stack_lds_ = (int)enum_stack_bytes(H.max_k > 0 ? H.max_k : 1);
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
