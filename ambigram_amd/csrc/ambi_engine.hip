@@ -1863,7 +1863,8 @@ class HipBackend : public Backend {
             }
             if (want_back_ && classed_streams_[0]) back_stream_ = classed_streams_[0];
             if (want_full_ && classed_streams_[1]) full_stream_ = classed_streams_[1];
-            if (want_first_ && !first_prio && classed_streams_[2]) first_stream_ = classed_streams_[2];
+            static const bool first_on_back = [] { const char* e = getenv("AMBI_FIRST_ON_BACK"); return e && atoi(e) != 0; }();   // experiment: the scan on the lean finish kernel's stream (no event between the two)
+            if (want_first_ && !first_prio && classed_streams_[2]) first_stream_ = first_on_back ? classed_streams_[0] : classed_streams_[2];
             if (want_lattice_ && classed_streams_[2]) lattice_stream_ = classed_streams_[2];
         }
         t_run_ = std::chrono::steady_clock::now();

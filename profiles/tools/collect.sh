@@ -5,7 +5,7 @@
 # databases go to gpurun_out/prof_<tag>/, the summaries (CSV / JSON) to gpurun_out/profiles_<tag>/ for copying into
 # profiles/.
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -41,5 +41,23 @@ python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_bench_b1024_allmode_p
 BENCH="python3 $ROOT/profiles/tools/express_latency.py"
 db=$(pass express --kernel-trace --stats)
 python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_single_sample_express_kernel_stats.csv"
+# timeline of a step (start / end of every kernel from the step's first one) from the kernel-trace pass
+python3 profiles/tools/timeline.py "$(find "$OUT/stats" -name '*_results.db' | head -1)" 2 > "$SUM/${TAG}_timeline.txt" || true
+# the same step on a stream of the caller's own (torch pool) and behind a one-rank RCCL group: timelines
+BENCH="python3 $ROOT/profiles/tools/mode_steps.py plain 6 - 8 own"
+db=$(pass own_stream --kernel-trace)
+python3 profiles/tools/timeline.py "$db" 1 > "$SUM/${TAG}_timeline_own_stream.txt" || true
+# the ILP fill kernel alone: duration, WRITE_SIZE, instruction counts
+BENCH="python3 $ROOT/profiles/tools/ilp_fill_probe.py 2"
+db=$(pass ilp_stats --kernel-trace --stats)
+python3 profiles/summarize_rocpd.py stats "$db" "$SUM/${TAG}_ilp_fill_kernel_stats.csv" > /dev/null
+db=$(pass ilp_write --kernel-trace --pmc WRITE_SIZE)
+python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_ilp_fill_pmc_write.csv" > /dev/null
+db=$(pass ilp_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY)
+python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_ilp_fill_pmc_sq.csv" > /dev/null
+# the lean finish kernel alone at full residency (lazy steps, one workgroup per unit): what bounds it
+BENCH="python3 $ROOT/profiles/tools/mode_steps.py lazy 4 - 0"
+db=$(AMBI_FINISH_GRID=4096 pass lean_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_LDS_ATOMIC SQ_WAIT_INST_ANY SQ_WAIT_ANY)
+python3 profiles/summarize_rocpd.py pmc "$db" "$SUM/${TAG}_lean_full_grid_pmc_sq.csv" > /dev/null
 tail -2 "$OUT/stats.log"
 ls -la "$SUM"
