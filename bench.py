@@ -250,10 +250,10 @@ def main():
     dom_bytes = per_kernel.get(dom, 0) / slices
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
     # HBM traffic by the PMC counters (rocprofv3 --pmc passes of this very command, corrected as MI355X_MICROARCH.md
-    # prescribes; profiles/traffic_r03.json, written by profiles/tools/collect.sh + summarize): per launch of the dominant
+    # prescribes; profiles/traffic_r04.json, written by profiles/tools/collect.sh + summarize): per launch of the dominant
     # kernel, and summed over every kernel of a step
     traffic, step_traffic = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic_r04.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
