@@ -77,6 +77,14 @@ extern __shared__ __align__(16) uint8_t ambi_lds[];
 #else
 #define AMBI_LEAN_ATTR
 #endif
+#ifndef AMBI_EDIT_WAVES
+#define AMBI_EDIT_WAVES 6
+#endif
+#if AMBI_EDIT_WAVES > 0
+#define AMBI_EDIT_ATTR AMBI_WAVES_ATTR(AMBI_EDIT_WAVES)
+#else
+#define AMBI_EDIT_ATTR
+#endif
 #if AMBI_EXT_WAVES > 0
 #define AMBI_EXT_ATTR AMBI_WAVES_ATTR(AMBI_EXT_WAVES)
 #else
@@ -138,7 +146,7 @@ __global__ void ambi_guard_check_kernel(const uint8_t* cells, int64_t stride, in
 
 __global__ __launch_bounds__(64) AMBI_PREP_ATTR void ambi_prepare_kernel(BatchArgs A) {
     WaveGroup g;
-    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { *A.n_pending = 0; *A.refin_count = 0; }   // nothing counts pending / handed-over units before the scan
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { *A.n_pending = 0; A.refin_count[0] = 0; A.refin_count[1] = 0; }   // nothing counts pending / handed-over units before the scan
     stage_prepare(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(1024) void ambi_express_kernel(BatchArgs A) {
 }
 __global__ __launch_bounds__(64) void ambi_lattice_kernel(BatchArgs A) {
     WaveGroup g;
-    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.refin_count = 0;   // the lean finish kernel behind fills the list
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { A.refin_count[0] = 0; A.refin_count[1] = 0; }   // the lean finish kernel behind fills the list ([1]: the edit kernel's hand-over list)
     stage_lattice(g, A, A.unit_base + (int)blockIdx.x, ambi_lds);
 }
 
@@ -196,7 +204,7 @@ __device__ inline int64_t block_exscan_i64(int64_t v, int64_t* total, int64_t* s
 
 __global__ __launch_bounds__(64) void ambi_lattice_own_kernel(BatchArgs A) {
     WaveGroup g;
-    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) *A.refin_count = 0;   // (as ambi_lattice_kernel)
+    if (A.zero_pending && blockIdx.x == 0 && threadIdx.x == 0) { A.refin_count[0] = 0; A.refin_count[1] = 0; }   // (as ambi_lattice_kernel)
     const int u = A.unit_base + (int)blockIdx.x;
     stage_lattice_own(g, A, u, ambi_lds);
     // the verdict the host waits for on a fresh batch: no lattice failed and the tables of ALL units fit the arena together
@@ -703,12 +711,25 @@ __global__ __launch_bounds__(1024) void ambi_finish_kernel(BatchArgs A, const in
 }
 // The direct full-stage launch with the path cells in device memory (stage_finish<true>): a workgroup works in its own
 // slot of `cells` (stride bytes apart; gridDim.x slots) for every unit it takes.
-__global__ __launch_bounds__(1024) AMBI_EXT_ATTR void ambi_finish_ext_kernel(BatchArgs A, const int32_t* unit_list, int count, uint8_t* cells, int64_t stride) {
+__global__ __launch_bounds__(1024) AMBI_EXT_ATTR void ambi_finish_ext_kernel(BatchArgs A, const int32_t* unit_list, int count, uint8_t* cells, int64_t stride,
+                                                                             const int32_t* count_ptr = nullptr) {
     __shared__ int scratch[40];
     BlockGroup g(scratch);
+    if (count_ptr) count = *count_ptr;   // a list the kernel in front of this one filled on the device (ambi_finish_edit_kernel)
     for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
         if (!plan_refused(g, unit_out(A.results, unit_list[i])) && !unit_out(A.results, unit_list[i])->reserved)
             stage_finish<true>(g, A, unit_list[i], ambi_lds, reinterpret_cast<cell_t*>(cells + (int64_t)blockIdx.x * stride + kCellGuardBytes));
+        __syncthreads();
+    }
+}
+
+// The direct launch for units whose SVs may edit the path, on the runs of the path (stage_finish_edit); what it hands on goes
+// to `hand_list` for an ambi_finish_ext_kernel launch behind it.
+__global__ __launch_bounds__(256) AMBI_EDIT_ATTR void ambi_finish_edit_kernel(BatchArgs A, const int32_t* unit_list, int count, int32_t* hand_list, int32_t* hand_count) {
+    __shared__ int scratch[40];
+    BlockGroup g(scratch);
+    for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
+        stage_finish_edit(g, A, unit_list[i], ambi_lds, hand_list, hand_count);
         __syncthreads();
     }
 }
@@ -1205,6 +1226,7 @@ class HipBackend : public Backend {
     bool want_back_ = false, want_full_ = false, want_first_ = false, want_lattice_ = false;
     hipStream_t first_stream_ = nullptr; int first_ahead_ = 3;   // env AMBI_FIRST_AHEAD: 1 the enumerate kernel waits for the scan, 2 the scan on a highest-priority stream beside it
     int32_t* d_direct_list_ = nullptr; int direct_n_ = 0, direct_grid_ = 1024;
+    int32_t* d_edit_list_ = nullptr; bool direct_edit_ = true; int lds_finish_edit_ = 0, edit_grid_ = 1024;   // env AMBI_DIRECT_EDIT: these units through stage_finish_edit first (ambi_finish_edit_kernel), the ext launch behind it for what that hands on
     // express path (small batches): one kernel reconstructs every unit whose first order assembles; results are complete at ev_express_
     int express_threads_ = 512;   // env AMBI_EXPRESS_THREADS (256 / 512 / 1024): the serial stages use three wavefronts, the finish stage and the mailbox copy all of them
     int express_units_ = 32, lds_express_ = 0, lds_lattice_ = 0, lds_lattice_own_ = 0;
@@ -1320,14 +1342,14 @@ class HipBackend : public Backend {
         in_bytes_ = c.off;
         zero_off_ = c.off;
         c.take(&d_results_, (size_t)H.result_bytes); c.take(&d_blk_hdr_, U * 8); c.take(&d_fallback_, U);
-        c.take(&d_refin_count_, 1); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1); c.take(&d_lat_sum_, 2);
+        c.take(&d_refin_count_, 2); c.take(&d_blocks_done_, 1); c.take(&d_npending_, 1); c.take(&d_guard_bad_, 1); c.take(&d_lat_sum_, 2);
         zero_bytes_ = c.off - zero_off_;
         c.take(&d_dags_, U);
         c.take(&d_ikeys_, (size_t)H.ideal_slots); c.take(&d_icnt_, (size_t)H.ideal_slots); c.take(&d_ilink_, (size_t)H.ideal_slots * 4 + 8);
         c.take(&d_ilvl_off_, U * (kMaxNodes + 3)); c.take(&d_icounter_, 2 * U); c.take(&d_ipos_, (size_t)H.ideal_slots);
         c.take(&d_aavail_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_acnt_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_acbase_, (size_t)H.ideal_slots / 2 + U + 1);
         c.take(&d_achild_, (size_t)H.ideal_slots * 4 + 8); c.take(&d_anblk_, (size_t)H.ideal_slots / 2 + 1); c.take(&d_adepth_, (size_t)H.ideal_slots / 2 + 8);
-        c.take(&d_blk_off_, U + kMaxSlices + 1); c.take(&d_rows_, U); c.take(&d_needed_, kMaxSlices); c.take(&d_lat_R_, U); c.take(&d_lat_status_, U);
+        c.take(&d_edit_list_, direct_list.size()); c.take(&d_blk_off_, U + kMaxSlices + 1); c.take(&d_rows_, U); c.take(&d_needed_, kMaxSlices); c.take(&d_lat_R_, U); c.take(&d_lat_status_, U);
         c.take(&d_scratch_, (size_t)H.scratch_ints + 8); c.take(&d_pack_off_, U + 1); c.take(&d_refin_list_, U);
         c.take(&d_first_rows_, U * (size_t)(cfg_.first_budget > 0 ? cfg_.first_budget : 1) * kFirstRowStride);
         const size_t img_stride = (size_t)std::max(block_lds_, ((160 * 1024) / 3) & ~15);   // (the budget per workgroup may be re-chosen after the first run)
@@ -1416,7 +1438,7 @@ class HipBackend : public Backend {
             std::lock_guard<std::mutex> lk(mu);
             if (!((done >> (L->device & 63)) & 1ull)) {
                 const void* fns[] = {(const void*)ambi_blocks_build_kernel, (const void*)ambi_prepare_kernel, (const void*)ambi_first_kernel, (const void*)ambi_resolve_kernel,
-                                     (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_lean_kernel, (const void*)ambi_finish_lean_wave_kernel,
+                                     (const void*)ambi_finish_kernel, (const void*)ambi_finish_ext_kernel, (const void*)ambi_finish_edit_kernel, (const void*)ambi_finish_lean_kernel, (const void*)ambi_finish_lean_wave_kernel,
                                      (const void*)ambi_enumerate_kernel<0>, (const void*)ambi_enumerate_kernel<1>, (const void*)ambi_enumerate_kernel<2>,
                                      (const void*)ambi_enumerate_blocks_kernel<0>, (const void*)ambi_enumerate_blocks_kernel<1>, (const void*)ambi_enumerate_blocks_kernel<2>,
                                      (const void*)ambi_express_kernel, (const void*)ambi_lattice_kernel, (const void*)ambi_lattice_own_kernel, (const void*)ambi_search_kernel, (const void*)ambi_all_kernel,
@@ -1489,6 +1511,10 @@ class HipBackend : public Backend {
                     if ((rc = lease_stream(L, 1, fp == 1 ? 1 : (fp == 2 ? 2 : 0), &full_stream_))) return rc;
                     want_full_ = fp == 0;
                     if (direct_ext_) lds_finish_ext_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, 0, H.max_out);
+                    { const char* ed = getenv("AMBI_DIRECT_EDIT"); direct_edit_ = (ed ? atoi(ed) != 0 : true) && direct_ext_; }
+                    { const char* eg = getenv("AMBI_EDIT_GRID"); edit_grid_ = eg ? atoi(eg) : 1024; if (edit_grid_ < 1) edit_grid_ = 1; }
+                    lds_finish_edit_ = (int)finish_edit_work_bytes(H.max_n, H.max_m, H.max_bkp);
+                    if (lds_finish_edit_ > kLdsLimit) direct_edit_ = false;
                 }
             }
             // AMBI_ENUM_LDS_FLOOR (experiments): make the enumerate kernel ask for more LDS than its image needs, i.e. fewer
@@ -1743,7 +1769,12 @@ class HipBackend : public Backend {
         // per step in round 2, profiles/r02_notes.md; with round 3's shorter lean stage 128 / 144 / 160 / 176 / 192 / 224 / 288 =
         // 1.16 / 1.14 / 1.09-1.11 / 1.087-1.091 / 1.10-1.13 / 1.10-1.14 / 1.13-1.15, profiles/r03_notes.md: the rule gives 164 there,
         // rounded up to a multiple of 16 = 176; round 2 rounded to 32 = 192)
-        int64_t grid = (int64_t)((double)U * unit_us / enum_us) + 1;
+        // (with the direct launch's units edited on their runs -- ambi_finish_edit_kernel, done well before the table -- the lean kernel
+        // gets the room the full-stage workgroups used to take: 224 (this rule) / 256 / 288 / 320 / 352 / 384 workgroups = 0.877 / 0.836 /
+        // 0.802 / 0.792 / -- / 0.813 ms per step on one box, 288 / 304 / 320 / 336 / 352 = 0.866 / 0.853 / 0.842 / 0.848 / 0.843 on another,
+        // against 0.844-0.855 and 0.880-0.886 with the full-stage launch: half as many again)
+        const double room = (direct_edit_ && direct_n_ > 0 && direct_ext_ && d_direct_cells_) ? 1.5 : 1.0;
+        int64_t grid = (int64_t)((double)U * unit_us * room / enum_us) + 1;
         grid = (grid + 15) & ~int64_t(15);
         if (grid < 32) grid = 32;
         return grid < U ? (int)grid : U;
@@ -1801,6 +1832,15 @@ class HipBackend : public Backend {
             }
             direct_retry_ = Ad.finish_retry != 0;
             tick("ambi_finish_ext_kernel", s, 6, true, full_stream_);
+            if (direct_ext_ && d_direct_cells_ && direct_edit_) {
+                // the edits of lone SVs on the runs of the path; what that stage hands on (chaining SVs, lists that outgrow their room)
+                // to the launch with the path cells in device memory, over the list the first one leaves on the device
+                direct_retry_ = false;
+                const int egrid = direct_n_ < edit_grid_ ? direct_n_ : edit_grid_;
+                hipLaunchKernelGGL(ambi_finish_edit_kernel, dim3(egrid), dim3(256), lds_finish_edit_, full_stream_, A, (const int32_t*)d_direct_list_, direct_n_, d_edit_list_, d_refin_count_ + 1);
+                hipLaunchKernelGGL(ambi_finish_ext_kernel, dim3(dgrid < 64 ? dgrid : 64), dim3(full_threads_), lds_finish_ext_, full_stream_, A, (const int32_t*)d_edit_list_, 0, d_direct_cells_, direct_stride_,
+                                   (const int32_t*)(d_refin_count_ + 1));
+            } else
             if (direct_ext_ && d_direct_cells_) {   // path cells in device memory: a 13 KB workgroup that fits where a lean one fits
                 direct_retry_ = false;
                 hipLaunchKernelGGL(ambi_finish_ext_kernel, dim3(dgrid), dim3(full_threads_), lds_finish_ext_, full_stream_, A, (const int32_t*)d_direct_list_, direct_n_, d_direct_cells_, direct_stride_);
@@ -1879,7 +1919,7 @@ class HipBackend : public Backend {
         lazy_ = (flags & FLAG_LAZY_ORDERS) != 0 && n_slices_ == 1;
         // one slice: no copy commands around the kernels (see BatchArgs::zero_pending)
         const bool direct = n_slices_ == 1 && dh_npending_ && dh_needed_;
-        if (!direct) { HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_)); HIP_CK(hipMemsetAsync(d_refin_count_, 0, sizeof(int32_t), stream_)); }
+        if (!direct) { HIP_CK(hipMemsetAsync(d_npending_, 0, sizeof(int32_t), stream_)); HIP_CK(hipMemsetAsync(d_refin_count_, 0, 2 * sizeof(int32_t), stream_)); }
         if (!arena_checked_ && n_slices_ > 1) {
             // first run of a sliced batch: size the arena regions of the slices from what their order tables need
             for (int s = 0; s < n_slices_; s++) launch_front(0, slice_args(s));   // all on the caller's stream

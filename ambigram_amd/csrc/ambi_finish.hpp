@@ -95,12 +95,12 @@ struct RunPath {
     }
 };
 
-struct SingleEdit { int kind, a, b; };   // kind 0: none, 1: erase [a,b), 2: duplicate [a,b) after b-1... (see apply)
+struct SingleEdit { int kind, a, b, empty; };   // kind 0: none, 1: erase [a,b), 2: duplicate [a,b) after b-1... (see apply); empty: kind 0 because the range to erase is empty (both ends found)
 
 // Decision of LGM.cpp:3779-3818 for a two-vertex group (g0,g1), answered from the occurrence tables.
 template <class PATH>
 AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const PATH& path, int P, const int32_t* first, const int32_t* last) {
-    SingleEdit E{0, 0, 0};
+    SingleEdit E{0, 0, 0, 0};
     const bool same = (g0 > 0) == (g1 > 0);
     const bool deletion = same && ((g0 > 0 && iabs(g0) < iabs(g1)) || (g0 < 0 && iabs(g0) > iabs(g1)));
     if (!same || deletion) {
@@ -120,7 +120,7 @@ AMBI_HD SingleEdit eval_single(int g0, int g1, int n, const PATH& path, int P, c
             break;
         }
         if (pos1 == P || pos2 == P || pos2 < 0) return E;
-        if (pos2 - (pos1 + 1) <= 0) return E;   // erase of an empty range: no state change
+        if (pos2 - (pos1 + 1) <= 0) { E.empty = 1; return E; }   // erase of an empty range: no state change
         E.kind = 1; E.a = pos1 + 1; E.b = pos2;
         return E;
     }
@@ -662,6 +662,303 @@ AMBI_HD int emit_runs_cells(const G& g, const cell_t* path, int P, int seg_base,
     if (nr > cap) return -nr;
     runs_fix_lengths(g, rl, nr, P);
     return nr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// indelBFB on the RUNS of the path (stage_finish_edit).  indel_bfb above moves the cells of the path for every edit and fills the
+// occurrence tables again behind it -- two sweeps over ~14 000 cells per applied group for the bench unit, with the cells in device
+// memory when the workgroup is to fit beside the order-table kernel.  Here the path stays what the lean stage works on, a list of
+// runs (run r = the values val[2r] + k at the positions [off[r], off[r+1])), and nothing is ever moved:
+//   * erase [a, b)                  = the runs of [0, a) followed by the runs of [b, P)
+//   * duplicate [a, b) at b         = the runs of [0, b), of [a, b) again and of [b, P)
+//   * insert cells c.. at q         = the runs of [0, q), one run per cell, the runs of [q, P)
+//     -- a slice of the list is a contiguous range of runs with the first and the last one cut, so a new list is written by one
+//     thread per run into the other of two buffers;
+//   * the occurrence tables come from the runs, one thread per vertex: a run holds a value at most once, at a position that follows
+//     from its first value (2n+1 vertices x ~100-250 runs of broadcast reads instead of two atomics per cell);
+//   * "next occurrence behind pos1" is a minimum over the runs.
+// Decisions, their order and the deque of chaining SVs are indel_bfb's, statement by statement.  The cells of the edited path are
+// written once, at the end, from the final list (stage_finish_edit).
+// ---------------------------------------------------------------------------------------------------------------
+struct RunList {
+    cell_t* val;     // [2 * cap]  first value of run r at val[2r] (the layout of the breakpoint pairs; odd entries unused)
+    int32_t* off;    // [cap + 1]  first position of every run, off[n] = P
+    int n, P;
+};
+constexpr int kRunsNoRoom = -1000;   // indel_bfb_runs: the run list outgrew its room (the caller hands the unit to the full stage)
+
+// D = up to three slices [x[k], y[k]) of S in this order, with `nlit` one-cell runs (values lit[0 .. nlit)) behind the first
+// `lit_at` slices.  Returns the number of runs of D, -1 when they do not fit `cap`.  loc: 8 ints of group memory.  D.n / D.P are
+// set; ends with a barrier.  Empty slices are allowed.
+template <class G>
+AMBI_HD int runs_build(const G& g, const RunList& S, RunList& D, int cap, int32_t* loc, int ns, const int* x, const int* y,
+                       int lit_at = 0, const int32_t* lit = nullptr, int nlit = 0) {
+    // the (non-empty) runs that hold the first and the last position of every slice
+    for (int r = g.tid(); r < S.n; r += g.size()) {
+        const int o0 = S.off[r], o1 = S.off[r + 1];
+        for (int k = 0; k < ns; k++) {
+            if (y[k] <= x[k]) continue;
+            if (o0 <= x[k] && x[k] < o1) loc[2 * k] = r;
+            if (o0 <= y[k] - 1 && y[k] - 1 < o1) loc[2 * k + 1] = r;
+        }
+    }
+    g.sync();
+    int total = 0, newP = 0, r0[3] = {0, 0, 0}, cnt[3] = {0, 0, 0}, dn[3] = {0, 0, 0}, db[3] = {0, 0, 0}, ln = 0, lb = 0;
+    for (int k = 0; k < ns; k++) {
+        if (k == lit_at) { ln = total; lb = newP; total += nlit; newP += nlit; }
+        if (y[k] > x[k]) { r0[k] = loc[2 * k]; cnt[k] = loc[2 * k + 1] - r0[k] + 1; }
+        dn[k] = total; db[k] = newP;
+        total += cnt[k]; newP += y[k] > x[k] ? y[k] - x[k] : 0;
+    }
+    if (lit_at >= ns) { ln = total; lb = newP; total += nlit; newP += nlit; }
+    D.n = total; D.P = newP;
+    if (total > cap) { g.sync(); return -1; }
+    for (int k = 0; k < ns; k++) {
+        for (int i = g.tid(); i < cnt[k]; i += g.size()) {
+            const int r = r0[k] + i;
+            const int o0 = S.off[r];
+            const int lo = o0 > x[k] ? o0 : x[k];           // (a run in the middle of the slice may be empty: it stays an empty run)
+            D.val[2 * (dn[k] + i)] = (cell_t)((int)S.val[2 * r] + (lo - o0));
+            D.off[dn[k] + i] = db[k] + (lo - x[k]);
+        }
+    }
+    for (int i = g.tid(); i < nlit; i += g.size()) { D.val[2 * (ln + i)] = (cell_t)lit[i]; D.off[ln + i] = lb + i; }
+    if (g.tid() == 0) D.off[total] = newP;
+    g.sync();
+    return total;
+}
+
+// occurrence tables of the path from its runs: one thread per vertex (up to kTabV vertices per thread and pass over the runs), the
+// runs in position order, eight runs per round -- their words are read together (one latency per round, not per run), and a vertex
+// keeps the first and the last RUN that holds it (branch-free), its positions follow at the end.  Ends with a barrier.
+constexpr int kTabV = 4;
+template <int NK, class G>
+AMBI_HD void tables_from_runs_pass(const G& g, int n, const RunList& R, int32_t* first, int32_t* last, int vb) {
+    const int nv = 2 * n + 1;
+    int v[NK], rf[NK], rl[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) { v[k] = vb + k * g.size() + g.tid() - n; rf[k] = 0x7fffffff; rl[k] = -1; }
+    for (int r0 = 0; r0 < R.n; r0 += 8) {
+        int o[9], a[8];
+#pragma unroll
+        for (int j = 0; j < 9; j++) { const int r = r0 + j < R.n ? r0 + j : R.n; o[j] = R.off[r]; }       // (runs behind the list: length 0)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int r = r0 + j < R.n ? r0 + j : R.n - 1; a[j] = R.val[2 * r]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned len = (unsigned)(o[j + 1] - o[j]);
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const bool hit = (unsigned)(v[k] - a[j]) < len;
+                const int rr = r0 + j;
+                rl[k] = hit ? rr : rl[k];
+                rf[k] = hit && rr < rf[k] ? rr : rf[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int i = vb + k * g.size() + g.tid();
+        if (i >= nv) continue;
+        first[i] = rl[k] < 0 ? 0x7fffffff : R.off[rf[k]] + (v[k] - (int)R.val[2 * rf[k]]);
+        last[i] = rl[k] < 0 ? -1 : R.off[rl[k]] + (v[k] - (int)R.val[2 * rl[k]]);
+    }
+}
+template <class G>
+AMBI_HD void tables_from_runs(const G& g, int n, const RunList& R, int32_t* first, int32_t* last) {
+    const int nv = 2 * n + 1;
+    for (int vb = 0; vb < nv; vb += kTabV * g.size()) {
+        const int nk = (nv - vb + g.size() - 1) / g.size();
+        if (nk >= 4) tables_from_runs_pass<4>(g, n, R, first, last, vb);
+        else if (nk == 3) tables_from_runs_pass<3>(g, n, R, first, last, vb);
+        else if (nk == 2) tables_from_runs_pass<2>(g, n, R, first, last, vb);
+        else tables_from_runs_pass<1>(g, n, R, first, last, vb);
+    }
+    g.sync();
+}
+
+// first position in [from, P) that holds val, P if none (find_first on the runs)
+template <class G>
+AMBI_HD int runs_find_first(const G& g, const RunList& R, int from, int val) {
+    int best = 0x7fffffff;
+    for (int r = g.tid(); r < R.n; r += g.size()) {
+        const int o0 = R.off[r], d = val - (int)R.val[2 * r];
+        if (d >= 0 && d < R.off[r + 1] - o0 && o0 + d >= from && o0 + d < best) best = o0 + d;
+    }
+    best = g.min_i32(best);
+    return best == 0x7fffffff ? R.P : best;
+}
+
+// indel_bfb on the run list `cur` (buf: the two other lists an edit alternates between, `cap` runs each; loc: 8 ints of group
+// memory).  Same return values as indel_bfb, or kRunsNoRoom.  *edited as there.  The occurrence tables need not be filled.
+#if defined(AMBI_EDIT_TRACE_ON) && !defined(__HIP_DEVICE_COMPILE__)
+static long g_edit_count[4];
+#define EDIT_COUNT(x) (g_edit_count[x]++)
+#else
+#define EDIT_COUNT(x) ((void)0)
+#endif
+template <class G>
+AMBI_HD int indel_bfb_runs(const G& g, int n, const JuncEnds* ends, int m, RunList& cur, RunList* buf, int cap, int pcap,
+                           const IndelScratch& S, int32_t* loc, bool* edited) {
+    *edited = false;
+    const int nsv = indel_collect(g, n, ends, m, S);
+    if (nsv == 0) return 0;
+    int which = 0;
+    // the edit: slices of cur (and literal cells) -> the other buffer, which becomes cur
+    auto rebuild = [&](int ns, const int* x, const int* y, int lit_at, const int32_t* lit, int nlit) -> bool {
+        RunList nxt{buf[which].val, buf[which].off, 0, 0};
+        if (runs_build(g, cur, nxt, cap, loc, ns, x, y, lit_at, lit, nlit) < 0) return false;
+        cur = nxt;
+        which ^= 1;
+        return true;
+    };
+    auto erase = [&](int a, int b) -> bool { const int x[2] = {0, b}, y[2] = {a, cur.P}; return rebuild(2, x, y, 0, nullptr, 0); };
+    auto duplicate = [&](int a, int b) -> bool { const int x[3] = {0, a, b}, y[3] = {b, b, cur.P}; return rebuild(3, x, y, 0, nullptr, 0); };
+
+    bool tables_ok = false;
+    int f = 0;
+    while (f < nsv) {
+        if (!tables_ok) { tables_from_runs(g, n, cur, S.first, S.last); tables_ok = true; EDIT_COUNT(0); }
+        EDIT_COUNT(1);
+        const RunPath RP{cur.val, cur.off, cur.n};
+        const int P = cur.P;
+        // parallel sweep: first SV at or after f that is not a no-op
+        int stop = 0x7fffffff;
+        for (int i = f + g.tid(); i < nsv; i += g.size()) {
+            if (S.taken[i]) continue;
+            if (S.has_ext[i]) { stop = i; break; }
+            const JuncEnds J = ends[S.sv[i]];
+            if (eval_single(J.s, J.t, n, RP, P, S.first, S.last).kind != 0) { stop = i; break; }
+        }
+        stop = g.min_i32(stop);
+        if (stop == 0x7fffffff) break;
+        if (!S.has_ext[stop]) {
+            const JuncEnds J = ends[S.sv[stop]];
+            const SingleEdit E = eval_single(J.s, J.t, n, RP, P, S.first, S.last);   // uniform re-evaluation
+            g.sync();
+            if (E.kind == 2 && P + (E.b - E.a) > pcap) return ST_ERR_PATH_CAPACITY;
+            if (!(E.kind == 1 ? erase(E.a, E.b) : duplicate(E.a, E.b))) return kRunsNoRoom;
+            *edited = true;
+            tables_ok = false;
+            f = stop + 1;
+            continue;
+        }
+        // ---- general path: deque chaining from SV `stop` (LGM.cpp:3762-3776) ----
+        const int first = stop;
+        int head = m + 2, tail = m + 2;
+        {
+            const JuncEnds J = ends[S.sv[first]];
+            g.sync();
+            if (g.tid() == 0) { S.grp[tail] = J.s; S.grp[tail + 1] = J.t; S.taken[first] = 1; }
+            tail += 2;
+            g.sync();
+        }
+        int cursor = first + 1;
+        while (true) {
+            int front = S.grp[head], back = S.grp[tail - 1];
+            int cand = 0x7fffffff;
+            for (int i = cursor + g.tid(); i < nsv; i += g.size()) {
+                if (S.taken[i]) continue;
+                const JuncEnds J = ends[S.sv[i]];
+                if (J.t == front || -J.s == front || back == J.s || back == -J.t) { cand = i; break; }
+            }
+            EDIT_COUNT(2);
+            cand = g.min_i32(cand);
+            if (cand == 0x7fffffff) break;
+            const JuncEnds J = ends[S.sv[cand]];
+            int nf = head, nt = tail;
+            int wpos = -1, wval = 0;
+            if (J.t == front) { nf = head - 1; wpos = nf; wval = J.s; }
+            else if (-J.s == front) { nf = head - 1; wpos = nf; wval = -J.t; }
+            else if (back == J.s) { wpos = tail; wval = J.t; nt = tail + 1; }
+            else { wpos = tail; wval = -J.s; nt = tail + 1; }
+            g.sync();
+            if (g.tid() == 0) { S.grp[wpos] = wval; S.taken[cand] = 1; }
+            head = nf; tail = nt;
+            g.sync();
+            cursor = cand + 1;
+        }
+        f = stop + 1;
+        // -- apply the group (LGM.cpp:3779-3832), the std::finds answered from the occurrence tables as in indel_bfb
+        auto t_find = [&](int val) -> int { int f0 = S.first[val + n]; return f0 == 0x7fffffff ? P : f0; };
+        auto t_find_before = [&](int pos1, int val) -> int { int f0 = S.first[val + n]; return (f0 != 0x7fffffff && f0 < pos1) ? f0 : pos1; };
+        auto t_find_after = [&](int pos1, int val) -> int {
+            if (pos1 >= P) return P;
+            int f0 = S.first[val + n];
+            if (f0 != 0x7fffffff && f0 > pos1) return f0;
+            if (S.last[val + n] <= pos1) return P;
+            return runs_find_first(g, cur, pos1 + 1, val);
+        };
+        tables_ok = false;   // cleared up front; restored below when the group turns out to be a no-op
+        int gs = tail - head;
+        auto complement_all = [&]() {
+            g.sync();
+            if (g.tid() == 0) {
+                for (int a = head, b = tail - 1; a < b; a++, b--) { int t = S.grp[a]; S.grp[a] = S.grp[b]; S.grp[b] = t; }
+                for (int a = head; a < tail; a++) S.grp[a] = -S.grp[a];
+            }
+            g.sync();
+        };
+        if (gs == 2) {
+            int g0 = S.grp[head], g1 = S.grp[head + 1];
+            if ((g0 > 0) == (g1 > 0)) {
+                bool deletion = (g0 > 0 && iabs(g0) < iabs(g1)) || (g0 < 0 && iabs(g0) > iabs(g1));
+                if (deletion) {
+                    int pos1 = t_find(g0);
+                    int pos2 = t_find_after(pos1, g1);
+                    if (pos1 == P || pos2 == P) {
+                        complement_all();
+                        g0 = S.grp[head]; g1 = S.grp[head + 1];
+                        pos1 = t_find(g0);
+                        pos2 = t_find_after(pos1, g1);
+                    }
+                    if (pos1 == P || pos2 == P || pos2 - pos1 > 3) { tables_ok = true; continue; }
+                    if (pos2 - (pos1 + 1) > 0) { if (!erase(pos1 + 1, pos2)) return kRunsNoRoom; } else tables_ok = true;
+                } else {   // duplication
+                    int pos1 = t_find(g0);
+                    int pos2 = t_find_before(pos1, g1);
+                    if (pos1 == P || pos2 == pos1) {
+                        complement_all();
+                        g0 = S.grp[head]; g1 = S.grp[head + 1];
+                        pos1 = t_find(g0);
+                        pos2 = t_find_before(pos1, g1);
+                    }
+                    if (pos1 == P || pos2 == pos1) { tables_ok = true; continue; }
+                    if (P + (pos1 + 1 - pos2) > pcap) return ST_ERR_PATH_CAPACITY;
+                    if (!duplicate(pos2, pos1 + 1)) return kRunsNoRoom;
+                }
+            } else {   // inversion
+                int pos1 = t_find(g0);
+                int pos2 = t_find_after(pos1, g1);
+                if (pos1 == P || pos2 == P) {
+                    complement_all();
+                    g0 = S.grp[head]; g1 = S.grp[head + 1];
+                    pos1 = t_find(g0);
+                    pos2 = t_find_after(pos1, g1);
+                }
+                if (pos1 == P || pos2 == P || pos2 - pos1 > 5) { tables_ok = true; continue; }
+                if (pos2 - (pos1 + 1) > 0) { if (!erase(pos1 + 1, pos2)) return kRunsNoRoom; } else tables_ok = true;
+            }
+        } else {   // insertion
+            int gf = S.grp[head], gb = S.grp[tail - 1];
+            int pos1 = t_find(gf);
+            int pos2 = t_find_after(pos1, gb);
+            if (pos1 == P || pos2 == P) {
+                complement_all();
+                gf = S.grp[head]; gb = S.grp[tail - 1];
+                pos1 = t_find(gf);
+                pos2 = t_find_after(pos1, gb);
+            }
+            if (pos1 == P || pos2 == P) { tables_ok = true; continue; }
+            const int cnt = pos2 - (pos1 + 1) > 0 ? pos2 - (pos1 + 1) : 0;
+            const int ins = gs - 2;
+            if (P - cnt + ins > pcap) return ST_ERR_PATH_CAPACITY;
+            const int x[2] = {0, pos2}, y[2] = {pos1 + 1, P};
+            if (!rebuild(2, x, y, 1, S.grp + head + 1, ins)) return kRunsNoRoom;
+        }
+        *edited = true;   // reached only when the group was applied (the no-op exits `continue` above)
+    }
+    return 1;
 }
 
 }  // namespace ambi

@@ -1128,6 +1128,138 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage_finish_edit: units whose SVs may EDIT the path (UnitIn::direct_full) without the cells of the path in any memory of
+// the workgroup -- the lean stage's runs, indelBFB on the run list (ambi_finish.hpp: indel_bfb_runs), the edited path written
+// once from the final list.  Same results as stage_finish.  What this stage does not do -- run lists or paths that outgrow
+// their room -- is handed on with ST_REFINISH: the caller runs stage_finish on the unit (`hand_list` / `hand_count`: the device list of the
+// direct full-stage launch behind this one; nullptr: the caller looks at the status).
+// Measured (profiles/r04_notes.md): 195 k shader cycles per bench unit with two deletions and a duplication in stage_finish with
+// the cells in device memory (125 k of them inside indelBFB: three shifts of 14 000 cells and three table fills).
+// ---------------------------------------------------------------------------------------------
+struct FinishEditWork {
+    FinishLeanWork L;       // (cand is not used: the lists below can be longer than the breakpoint path)
+    cell_t* val[2];         // [2 * cap2] two run lists: an edit reads one and writes the other
+    int32_t* off[2];        // [cap2 + 2]
+    int32_t* cand;          // [3 * (cap2 + 1)]
+    int32_t* misc;          // [16]  loc[8] of runs_build
+    int32_t* grp;           // [2m + 4]  the deque of chaining SVs (stage_finish keeps it in device memory: there it is touched rarely
+                            //           compared with the cells; here every access would be the longest wait of its step)
+};
+AMBI_HD int edit_run_cap(int bkp_cap) { return 2 * (bkp_cap / 2) + 32; }
+AMBI_HD int64_t finish_edit_work_bytes(int n, int m, int bkp_cap) {
+    const int64_t c = edit_run_cap(bkp_cap);
+    return pad8(finish_lean_work_bytes(n, m, bkp_cap)) + 2 * pad8(4 * c) + 2 * pad8(4 * (c + 2)) + pad8(12 * (c + 1)) + 64 + pad8(4ll * (2 * m + 4));
+}
+AMBI_HD FinishEditWork carve_finish_edit(uint8_t* base, int n, int m, int bkp_cap) {
+    FinishEditWork W;
+    W.L = carve_finish_lean(base, n, m, bkp_cap);
+    const int64_t c = edit_run_cap(bkp_cap);
+    int64_t o = pad8(finish_lean_work_bytes(n, m, bkp_cap));
+    for (int k = 0; k < 2; k++) { W.val[k] = reinterpret_cast<cell_t*>(base + o); o += pad8(4 * c); }
+    for (int k = 0; k < 2; k++) { W.off[k] = reinterpret_cast<int32_t*>(base + o); o += pad8(4 * (c + 2)); }
+    W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(12 * (c + 1));
+    W.misc = reinterpret_cast<int32_t*>(base + o); o += 64;
+    W.grp = reinterpret_cast<int32_t*>(base + o);
+    return W;
+}
+
+template <class G>
+AMBI_HD void stage_finish_edit(const G& g, const BatchArgs& A, int u, uint8_t* work, int32_t* hand_list = nullptr, int32_t* hand_count = nullptr) {
+    UnitOut* out = unit_out(A.results, u);
+    const UnitIn U = A.units[u];
+    const int n = U.n_seg, m = U.n_junc;
+    const UnitLayout Lay = unit_layout(n, U.bkp_cap, U.path_cap, U.out_cap);
+    uint8_t* res = A.results + U.res_off;
+    rcell_t* gpath = reinterpret_cast<rcell_t*>(res + Lay.path);
+    rcell_t* gpath2 = reinterpret_cast<rcell_t*>(res + Lay.path_ind);
+    OutJunc* gout = reinterpret_cast<OutJunc*>(res + Lay.out_junc);
+    const int base = U.seg_base;
+    if (plan_refused(g, out)) return;
+    int status = out->status;
+    if (out->reserved) return;                        // reconstructed by the express stage already
+    if (status == ST_REFINISH) {   // handed over by the lean stage (host simulation): an ordinary reconstructed unit
+        status = ST_OK;
+        g.sync();
+        if (g.tid() == 0) out->status = ST_OK;
+    }
+    auto hand_on = [&]() {
+        g.sync();
+        if (g.tid() == 0) { out->status = ST_REFINISH; if (hand_list) hand_list[atomic_add_i32(hand_count, 1)] = u; }
+        g.sync();
+    };
+    if (status != ST_OK) {   // shortcut / infeasible units and errors: the full stage's own branches (rare among these units)
+        if (status == ST_SHORTCUT || status == ST_INFEASIBLE) {
+            int P = n <= U.path_cap ? n : U.path_cap;
+            for (int i = g.tid(); i < P; i += g.size()) gpath[i] = (rcell_t)(i + 1);
+            if (g.tid() == 0) {
+                out->path_len = P; out->path_indel_len = P; out->indel_printed = 0; out->n_out_junc = 0; out->path_ind_stored = 0;
+                if (n > U.path_cap) out->status = ST_ERR_PATH_CAPACITY;
+                runs_identity(A, u, P, base);
+            }
+            g.sync();
+        }
+        return;
+    }
+    FinishEditWork W = carve_finish_edit(work, n, m, U.bkp_cap);
+    const int cap2 = edit_run_cap(U.bkp_cap);
+    const int L = out->bkp_len, np = L / 2;
+    AMBI_MARK(A, g, u, 16);
+    copy_words(g, W.L.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));
+    {
+        const JuncEnds* ge = A.junc_ends + U.junc_off;
+        for (int j = g.tid(); j < m; j += g.size()) W.L.ends[j] = ge[j];
+    }
+    g.sync();
+    AMBI_MARK(A, g, u, 17);
+    const int P = run_offsets(g, W.L.bkp, L, W.L.offs);
+    if (P > U.path_cap) { hand_on(); return; }        // (the full stage reports it)
+    expand_runs(g, W.L.bkp, np, W.L.offs, gpath, base, n, (int32_t*)nullptr, (int32_t*)nullptr);
+    AMBI_MARK(A, g, u, 18);
+    IndelScratch S{W.L.sv, W.L.taken, W.L.has_ext, W.grp, W.L.first, W.L.last};
+    RunList cur{W.L.bkp, W.L.offs, np, P};
+    RunList buf[2] = {{W.val[0], W.off[0], 0, 0}, {W.val[1], W.off[1], 0, 0}};
+    bool edited = false;
+    const int printed = indel_bfb_runs(g, n, W.L.ends, m, cur, buf, cap2, U.path_cap, S, W.misc, &edited);
+    if (printed < 0) { hand_on(); return; }           // no room for the runs, or an error the full stage reports
+    AMBI_MARK(A, g, u, 19);
+    int nout = 0, nruns = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (G::kIsBlock && cur.n <= 256 && g.size() >= 128) {
+        // as in the lean stage: ONE wavefront goes through the chain of short phases of the output-junction synthesis and the run
+        // emission without a workgroup barrier, the other wavefronts write the cells of the edited path meanwhile
+        if (g.tid() < 64) {
+            WaveGroup w;
+            nout = synth_out_juncs_runs(w, cur.val, cur.n, cur.off, gout, U.out_cap, W.cand, base);
+            if (A.run_cnt) nruns = emit_runs_pairs(w, cur.val, cur.n, cur.off, cur.P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
+        } else if (edited) {
+            const int lane = g.tid() & 63, sub = (g.tid() >> 6) - 1, nsub = (g.size() >> 6) - 1;
+            for (int j = sub; j < cur.n; j += nsub) {
+                const int a = cur.val[2 * j], o0 = cur.off[j], len = cur.off[j + 1] - o0;
+                for (int k = lane; k < len; k += 64) gpath2[o0 + k] = (rcell_t)(a + k);
+            }
+        }
+        nout = g.bcast_i32(nout, 0);
+        nruns = g.bcast_i32(nruns, 0);
+        AMBI_MARK(A, g, u, 20);
+    } else
+#endif
+    {
+        if (edited) expand_runs(g, cur.val, cur.n, cur.off, gpath2, base, n, (int32_t*)nullptr, (int32_t*)nullptr);
+        nout = synth_out_juncs_runs(g, cur.val, cur.n, cur.off, gout, U.out_cap, W.cand, base);
+        AMBI_MARK(A, g, u, 20);
+        if (A.run_cnt) nruns = emit_runs_pairs(g, cur.val, cur.n, cur.off, cur.P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
+    }
+    if (g.tid() == 0) {
+        out->path_len = P; out->path_indel_len = cur.P; out->indel_printed = printed; out->path_ind_stored = edited ? 1 : 0;
+        out->n_out_junc = nout >= 0 ? nout : 0;
+        if (nout < 0) out->status = nout;
+        runs_publish(A, u, nruns, cur.P);
+    }
+    g.sync();
+    AMBI_MARK(A, g, u, 21);
+}
+
+// ---------------------------------------------------------------------------------------------
 // stage_express: the whole reconstruction of a unit whose FIRST order is valid, in one workgroup -- for small batches,
 // where the latency of the kernel chain (prepare -> plan -> scan -> finish, each a single wavefront working through
 // order-dependent steps) is what a caller waits for.  allTopologicalOrders emits the orders in lexicographic order

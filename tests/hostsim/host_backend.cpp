@@ -265,6 +265,17 @@ class HostSimBackend : public Backend {
             // units with deletion / duplication candidates: the form with the path cells outside the work area (what the HIP
             // backend's direct full-stage launch runs), in buffers of exactly its sizes; AMBI_HOSTSIM_EXT_PATH=0: the ordinary form
             const char* ep = getenv("AMBI_HOSTSIM_EXT_PATH");
+            const char* ed = getenv("AMBI_HOSTSIM_EDIT");
+            if (U.direct_full && !(ed && atoi(ed) == 0)) {   // what the HIP backend's direct launch runs first: the edits on the runs of the path
+                std::vector<uint8_t> work((size_t)finish_edit_work_bytes(U.n_seg, U.n_junc, U.bkp_cap));
+                stage_finish_edit(g, A_, u, work.data());
+                const bool handed_on = unit_out(A_.results, u)->status == ST_REFINISH;
+                if (getenv("AMBI_HOSTSIM_DEBUG")) fprintf(stderr, "hostsim: unit %d through the edit stage: %s\n", u, handed_on ? "handed on" : "done");
+#if defined(AMBI_EDIT_TRACE_ON)
+                fprintf(stderr, "edit counts unit %d: table builds %ld sweeps %ld chain scans %ld (runs %d)\n", u, g_edit_count[0], g_edit_count[1], g_edit_count[2], 0); g_edit_count[0] = g_edit_count[1] = g_edit_count[2] = 0;
+#endif
+                if (!handed_on) continue;   // (handed on: the full stage below)
+            }
             if (U.direct_full && !(ep && atoi(ep) == 0)) {
                 std::vector<uint8_t> work((size_t)finish_work_bytes(U.n_seg, U.n_junc, U.bkp_cap, 0, U.out_cap));
                 std::vector<cell_t> cells((size_t)U.path_cap + 8 + 8);   // 2 * path_cap + 16 bytes, aligned to 16 below
