@@ -395,10 +395,40 @@ AMBI_HD int step_v(int32_t w) { return (int)((uint32_t)w & 0xFFFFu) - 32768; }
 // (u,v) words in cand[0,nc); cand must hold 3*nc ints.  A step joins the FIRST earlier step that is the same edge or
 // its complement edge (the reference bumps that entry's count); a record can never coexist with its complement, so
 // classes are disjoint.  Returns the number of output junctions or a negative Status.
+// htab / hsize: optional hash table (2 * hsize ints of group memory, hsize a power of two >= 2 * nc): the first step of every edge is
+// then found through it -- one insertion (compare-and-swap on the key, minimum on the index) and one look-up per step -- instead of a
+// scan of all earlier steps per step (nc^2 / 2 key reads: 15 k of the lean stage's 36 k cycles for the bench unit's ~100 steps).
+AMBI_HD int synth_hash_size(int nc, int ints_available) {   // 0: no room, the scan
+    int h = 64;
+    while (h < 2 * nc) h <<= 1;
+    return 2 * h <= ints_available ? h : 0;
+}
 template <class G>
-AMBI_HD int synth_classes(const G& g, int32_t* cand, int nc, OutJunc* out, int cap, int seg_base) {
+AMBI_HD int synth_classes(const G& g, int32_t* cand, int nc, OutJunc* out, int cap, int seg_base, int32_t* htab = nullptr, int hsize = 0) {
     int32_t* rep = cand + nc;      // [nc] representative (first occurrence) of every step
     int32_t* key = cand + 2 * nc;  // [nc] canonical edge key: the smaller of (u,v) and its complement (-v,-u), packed
+    if (htab != nullptr && hsize >= 2 * nc && (hsize & (hsize - 1)) == 0) {
+        int32_t* hk = htab;            // [hsize] key of the slot, 0 = empty (a packed step is never 0: ids are non-zero)
+        int32_t* hi = htab + hsize;    // [hsize] first step with that key
+        for (int i = g.tid(); i < hsize; i += g.size()) { hk[i] = 0; hi[i] = 0x7fffffff; }
+        g.sync();
+        for (int c = g.tid(); c < nc; c += g.size()) {
+            const int u = step_u(cand[c]), v = step_v(cand[c]);
+            const int32_t k1 = pack_step(u, v), k2 = pack_step(-v, -u);
+            const int32_t k = k1 < k2 ? k1 : k2;
+            uint32_t h = ((uint32_t)k * 0x9E3779B1u) >> 7 & (uint32_t)(hsize - 1);
+            while (true) {   // (the table is at most half full: an empty slot ends every probe sequence)
+                const int old = atomic_cas_i32(&hk[h], 0, k);
+                if (old == 0 || old == k) break;
+                h = (h + 1) & (uint32_t)(hsize - 1);
+            }
+            atomic_min_i32(&hi[h], c);
+            rep[c] = (int32_t)h;
+        }
+        g.sync();
+        for (int c = g.tid(); c < nc; c += g.size()) rep[c] = hi[rep[c]];
+        g.sync();
+    } else {
     for (int c = g.tid(); c < nc; c += g.size()) {
         const int u = step_u(cand[c]), v = step_v(cand[c]);
         const int32_t k1 = pack_step(u, v), k2 = pack_step(-v, -u);
@@ -417,6 +447,7 @@ AMBI_HD int synth_classes(const G& g, int32_t* cand, int nc, OutJunc* out, int c
         rep[c] = r;
     }
     g.sync();
+    }
     // class sizes in group memory (the key array is free now): every step bumps its representative's counter
     for (int c = g.tid(); c < nc; c += g.size()) key[c] = 0;
     g.sync();
@@ -580,7 +611,7 @@ AMBI_HD int indel_lookups_only(const G& g, int n, const JuncEnds* ends, int nsv,
 // output junctions from the runs; cand: 3 * (np + 1) ints
 template <class G>
 AMBI_HD int synth_out_juncs_runs(const G& g, const cell_t* bkp, int np, const int32_t* offs, OutJunc* out, int cap, int32_t* cand,
-                                 int seg_base) {
+                                 int seg_base, int32_t* htab = nullptr, int htab_ints = 0) {
     int nc = 0;
     for (int base = 0; base < np; base += g.size()) {
         const int j = base + g.tid();
@@ -601,7 +632,7 @@ AMBI_HD int synth_out_juncs_runs(const G& g, const cell_t* bkp, int np, const in
         nc += tot;
     }
     g.sync();
-    return synth_classes(g, cand, nc, out, cap, seg_base);
+    return synth_classes(g, cand, nc, out, cap, seg_base, htab, htab ? synth_hash_size(nc, htab_ints) : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -621,28 +652,37 @@ AMBI_HD void runs_fix_lengths(const G& g, int32_t* rl, int nr, int P) {
         g.sync();
     }
 }
-// from the breakpoint pairs (lean stage): pair j covers positions [offs[j], offs[j+1]) with the values bkp[2j] + k
+// from the breakpoint pairs (lean stage): pair j covers positions [offs[j], offs[j+1]) with the values bkp[2j] + k.  A pair starts a run
+// when it is not empty and does not continue the previous non-empty pair; the run's length follows from the next such pair, which the
+// starting thread looks for itself (a run rarely spans more than two or three pairs) -- nothing is read back from the slots, which lie
+// in device memory, and no pass over them follows.
 template <class G>
 AMBI_HD int emit_runs_pairs(const G& g, const cell_t* bkp, int np, const int32_t* offs, int P, int seg_base, int32_t* rs, int32_t* rl, int cap) {
+    auto starts = [&](int j) -> bool {   // pair j (not empty) opens a run
+        int pj = j - 1;
+        while (pj >= 0 && offs[pj + 1] == offs[pj]) pj--;      // previous non-empty pair
+        return pj < 0 || (int)bkp[2 * pj] + (offs[pj + 1] - offs[pj]) != (int)bkp[2 * j];
+    };
     int nr = 0;
     for (int base = 0; base < np; base += g.size()) {
         const int j = base + g.tid();
-        int start = 0, a = 0;
+        int start = 0, a = 0, len = 0;
         if (j < np && offs[j + 1] > offs[j]) {
             a = bkp[2 * j];
-            int pj = j - 1;
-            while (pj >= 0 && offs[pj + 1] == offs[pj]) pj--;      // previous non-empty pair
-            start = (pj < 0 || (int)bkp[2 * pj] + (offs[pj + 1] - offs[pj]) != a) ? 1 : 0;
+            start = starts(j) ? 1 : 0;
+            if (start) {
+                int k = j + 1;
+                while (k < np && (offs[k + 1] == offs[k] || !starts(k))) k++;
+                len = (k < np ? offs[k] : P) - offs[j];
+            }
         }
         int tot;
         const int ex = g.exscan_i32(start, &tot);
-        if (start && nr + ex < cap) { rs[nr + ex] = run_abs_cell(a, seg_base); rl[nr + ex] = offs[j]; }
+        if (start && nr + ex < cap) { rs[nr + ex] = run_abs_cell(a, seg_base); rl[nr + ex] = len; }
         nr += tot;
     }
     g.sync();
-    if (nr > cap) return -nr;
-    runs_fix_lengths(g, rl, nr, P);
-    return nr;
+    return nr > cap ? -nr : nr;
 }
 // from the cells (full stage; the cells in group or device memory): every thread takes a contiguous stretch
 template <class G>
@@ -734,10 +774,10 @@ AMBI_HD int runs_build(const G& g, const RunList& S, RunList& D, int cap, int32_
 constexpr int kTabV = 4;
 template <int NK, class G>
 AMBI_HD void tables_from_runs_pass(const G& g, int n, const RunList& R, int32_t* first, int32_t* last, int vb) {
-    const int nv = 2 * n + 1;
+    // vertex number j in [0, 2n) stands for the vertex j - n (j < n) or j - n + 1: there is no vertex 0
     int v[NK], rf[NK], rl[NK];
 #pragma unroll
-    for (int k = 0; k < NK; k++) { v[k] = vb + k * g.size() + g.tid() - n; rf[k] = 0x7fffffff; rl[k] = -1; }
+    for (int k = 0; k < NK; k++) { const int j = vb + k * g.size() + g.tid(); v[k] = j < n ? j - n : j - n + 1; rf[k] = 0x7fffffff; rl[k] = -1; }
     for (int r0 = 0; r0 < R.n; r0 += 8) {
         int o[9], a[8];
 #pragma unroll
@@ -758,15 +798,16 @@ AMBI_HD void tables_from_runs_pass(const G& g, int n, const RunList& R, int32_t*
     }
 #pragma unroll
     for (int k = 0; k < NK; k++) {
-        const int i = vb + k * g.size() + g.tid();
-        if (i >= nv) continue;
+        if (vb + k * g.size() + g.tid() >= 2 * n) continue;
+        const int i = v[k] + n;
         first[i] = rl[k] < 0 ? 0x7fffffff : R.off[rf[k]] + (v[k] - (int)R.val[2 * rf[k]]);
         last[i] = rl[k] < 0 ? -1 : R.off[rl[k]] + (v[k] - (int)R.val[2 * rl[k]]);
     }
 }
 template <class G>
 AMBI_HD void tables_from_runs(const G& g, int n, const RunList& R, int32_t* first, int32_t* last) {
-    const int nv = 2 * n + 1;
+    const int nv = 2 * n;
+    if (g.tid() == 0) { first[n] = 0x7fffffff; last[n] = -1; }
     for (int vb = 0; vb < nv; vb += kTabV * g.size()) {
         const int nk = (nv - vb + g.size() - 1) / g.size();
         if (nk >= 4) tables_from_runs_pass<4>(g, n, R, first, last, vb);
@@ -797,9 +838,14 @@ static long g_edit_count[4];
 #else
 #define EDIT_COUNT(x) ((void)0)
 #endif
+#if defined(AMBI_EDIT_MARKS)   // diagnostic build: shader-clock marks of the LAST pass of the loop in the slots of the prepare stage's marks
+#define EDIT_MARK(x) clk_mark(g, clk, x)
+#else
+#define EDIT_MARK(x) ((void)0)
+#endif
 template <class G>
 AMBI_HD int indel_bfb_runs(const G& g, int n, const JuncEnds* ends, int m, RunList& cur, RunList* buf, int cap, int pcap,
-                           const IndelScratch& S, int32_t* loc, bool* edited) {
+                           const IndelScratch& S, int32_t* loc, bool* edited, int64_t* clk = nullptr) {
     *edited = false;
     const int nsv = indel_collect(g, n, ends, m, S);
     if (nsv == 0) return 0;
@@ -818,8 +864,10 @@ AMBI_HD int indel_bfb_runs(const G& g, int n, const JuncEnds* ends, int m, RunLi
     bool tables_ok = false;
     int f = 0;
     while (f < nsv) {
+        EDIT_MARK(1);
         if (!tables_ok) { tables_from_runs(g, n, cur, S.first, S.last); tables_ok = true; EDIT_COUNT(0); }
         EDIT_COUNT(1);
+        EDIT_MARK(2);
         const RunPath RP{cur.val, cur.off, cur.n};
         const int P = cur.P;
         // parallel sweep: first SV at or after f that is not a no-op
@@ -831,6 +879,7 @@ AMBI_HD int indel_bfb_runs(const G& g, int n, const JuncEnds* ends, int m, RunLi
             if (eval_single(J.s, J.t, n, RP, P, S.first, S.last).kind != 0) { stop = i; break; }
         }
         stop = g.min_i32(stop);
+        EDIT_MARK(3);
         if (stop == 0x7fffffff) break;
         if (!S.has_ext[stop]) {
             const JuncEnds J = ends[S.sv[stop]];
@@ -879,6 +928,7 @@ AMBI_HD int indel_bfb_runs(const G& g, int n, const JuncEnds* ends, int m, RunLi
             cursor = cand + 1;
         }
         f = stop + 1;
+        EDIT_MARK(4);
         // -- apply the group (LGM.cpp:3779-3832), the std::finds answered from the occurrence tables as in indel_bfb
         auto t_find = [&](int val) -> int { int f0 = S.first[val + n]; return f0 == 0x7fffffff ? P : f0; };
         auto t_find_before = [&](int pos1, int val) -> int { int f0 = S.first[val + n]; return (f0 != 0x7fffffff && f0 < pos1) ? f0 : pos1; };
@@ -953,9 +1003,11 @@ AMBI_HD int indel_bfb_runs(const G& g, int n, const JuncEnds* ends, int m, RunLi
             const int cnt = pos2 - (pos1 + 1) > 0 ? pos2 - (pos1 + 1) : 0;
             const int ins = gs - 2;
             if (P - cnt + ins > pcap) return ST_ERR_PATH_CAPACITY;
+            EDIT_MARK(5);
             const int x[2] = {0, pos2}, y[2] = {pos1 + 1, P};
             if (!rebuild(2, x, y, 1, S.grp + head + 1, ins)) return kRunsNoRoom;
         }
+        EDIT_MARK(6);
         *edited = true;   // reached only when the group was applied (the no-op exits `continue` above)
     }
     return 1;

@@ -35,6 +35,15 @@ AMBI_HD uint32_t lane_get_u32(uint32_t v, int i) {
 #endif
 }
 
+// compare-and-swap on group memory, usable from both builds; returns the old value
+AMBI_HD int atomic_cas_i32(int* p, int expected, int desired) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicCAS(p, expected, desired);
+#else
+    int old = *p; if (old == expected) *p = desired; return old;
+#endif
+}
+
 struct HostGroup {
     static constexpr bool kIsBlock = false;
     static constexpr bool kLaneArrays = false;   // no cross-lane register arrays (ambi_sort.hpp: LaneWords)

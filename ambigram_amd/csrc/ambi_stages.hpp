@@ -1007,10 +1007,12 @@ struct FinishLeanWork {
     int32_t* last;      // [2n+1]
     uint8_t* taken;     // [m]
     uint8_t* has_ext;   // [m]
+    int32_t* htab;      // [lean_hash_ints(bkp_cap)]  hash table of the output-junction synthesis (synth_classes)
 };
+AMBI_HD int lean_hash_ints(int bkp_cap) { int h = 64; while (h < 2 * (bkp_cap / 2 + 1)) h <<= 1; return 2 * h; }
 AMBI_HD int64_t finish_lean_work_bytes(int n, int m, int bkp_cap) {
     return pad8(2ll * bkp_cap) + pad8(4ll * (bkp_cap / 2 + 2)) + pad8(int64_t(sizeof(JuncEnds)) * m) + pad8(4ll * m) +
-           pad8(12ll * (bkp_cap / 2 + 1)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m);
+           pad8(12ll * (bkp_cap / 2 + 1)) + 2 * pad8(4ll * (2 * n + 1)) + 2 * pad8(m) + pad8(4ll * lean_hash_ints(bkp_cap));
 }
 AMBI_HD FinishLeanWork carve_finish_lean(uint8_t* base, int n, int m, int bkp_cap) {
     FinishLeanWork W;
@@ -1023,13 +1025,19 @@ AMBI_HD FinishLeanWork carve_finish_lean(uint8_t* base, int n, int m, int bkp_ca
     W.first = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
     W.last = reinterpret_cast<int32_t*>(base + o); o += pad8(4ll * (2 * n + 1));
     W.taken = base + o; o += pad8(m);
-    W.has_ext = base + o;
+    W.has_ext = base + o; o += pad8(m);
+    W.htab = reinterpret_cast<int32_t*>(base + o);
     return W;
 }
 
 // mirror: a second place for the cells of the final path (the express stage's slot of the pinned result mailbox).
 // pre_nsv >= 0: the junction ends are in the work area and indel_collect has run on them already (the express stage does that
 // on its junction-side wavefront while the DAG side is still busy): its result.
+#if defined(AMBI_EDIT_MARKS)   // diagnostic build: marks inside the one-wavefront tail, in the slots of the prepare stage's marks
+#define LEAN_DIAG_MARK(w, x) AMBI_MARK(A, w, u, x)
+#else
+#define LEAN_DIAG_MARK(w, x) ((void)0)
+#endif
 template <class G>
 AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* work, rcell_t* mirror = nullptr, int pre_nsv = -1) {
     UnitOut* out = unit_out(A.results, u);
@@ -1094,15 +1102,28 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
 #else
         if (g.tid() < 64) {
             WaveGroup w;
-            v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
-            if (A.run_cnt) nruns = emit_runs_pairs(w, W.bkp, np, W.offs, P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
+            v = synth_out_juncs_runs(w, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base, W.htab, lean_hash_ints(U.bkp_cap));
+            LEAN_DIAG_MARK(w, 7);
         }
 #endif
 #if !defined(AMBI_LEAN_SKIP) || !(AMBI_LEAN_SKIP & 4)
-        else if (nsv > 0) stop = indel_lookups_thread(g.tid() - 64, g.size() - 64, n, W.ends, nsv, RP, P, S);
+        else {
+            // the second wavefront: the run-length form of the path first (reads the pairs only, as the synthesis does)
+            if (g.tid() < 128 && A.run_cnt) {
+                WaveGroup w;
+                nruns = emit_runs_pairs(w, W.bkp, np, W.offs, P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
+#if defined(AMBI_EDIT_MARKS)
+                if (g.tid() == 64 && A.stage_clk) A.stage_clk[(int64_t)u * kStageSlots + 8] = stage_clock();
+#endif
+            }
+            if (nsv > 0) stop = indel_lookups_thread(g.tid() - 64, g.size() - 64, n, W.ends, nsv, RP, P, S);
+#if defined(AMBI_EDIT_MARKS)
+            if (g.tid() == 64 && A.stage_clk) A.stage_clk[(int64_t)u * kStageSlots + 6] = stage_clock();
+#endif
+        }
 #endif
         nout = g.bcast_i32(v, 0);
-        nruns = g.bcast_i32(nruns, 0);
+        nruns = g.bcast_i32(nruns, 64);
         if (nsv > 0) { printed = g.any(stop != 0) ? 0 : 1; if (!printed) { refinish(); return; } }
         AMBI_MARK(A, g, u, 19);
     } else
@@ -1113,7 +1134,7 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
             if (!printed) { refinish(); return; }
         }
         AMBI_MARK(A, g, u, 19);
-        nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base);
+        nout = synth_out_juncs_runs(g, W.bkp, np, W.offs, gout, U.out_cap, W.cand, base, W.htab, lean_hash_ints(U.bkp_cap));
         if (A.run_cnt) nruns = emit_runs_pairs(g, W.bkp, np, W.offs, P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
     }
     AMBI_MARK(A, g, u, 20);
@@ -1142,6 +1163,7 @@ struct FinishEditWork {
     int32_t* off[2];        // [cap2 + 2]
     int32_t* cand;          // [3 * (cap2 + 1)]
     int32_t* misc;          // [16]  loc[8] of runs_build
+    int32_t* htab; int htab_ints;   // hash table of the output-junction synthesis: the occurrence tables, which indelBFB is done with by then (the run lists can be longer than the lean stage's own table allows for)
     int32_t* grp;           // [2m + 4]  the deque of chaining SVs (stage_finish keeps it in device memory: there it is touched rarely
                             //           compared with the cells; here every access would be the longest wait of its step)
 };
@@ -1160,6 +1182,7 @@ AMBI_HD FinishEditWork carve_finish_edit(uint8_t* base, int n, int m, int bkp_ca
     W.cand = reinterpret_cast<int32_t*>(base + o); o += pad8(12 * (c + 1));
     W.misc = reinterpret_cast<int32_t*>(base + o); o += 64;
     W.grp = reinterpret_cast<int32_t*>(base + o);
+    W.htab = W.L.first; W.htab_ints = (int)(2 * pad8(4ll * (2 * n + 1)) / 4);   // (first and last lie one behind the other, carve_finish_lean)
     return W;
 }
 
@@ -1219,7 +1242,7 @@ AMBI_HD void stage_finish_edit(const G& g, const BatchArgs& A, int u, uint8_t* w
     RunList cur{W.L.bkp, W.L.offs, np, P};
     RunList buf[2] = {{W.val[0], W.off[0], 0, 0}, {W.val[1], W.off[1], 0, 0}};
     bool edited = false;
-    const int printed = indel_bfb_runs(g, n, W.L.ends, m, cur, buf, cap2, U.path_cap, S, W.misc, &edited);
+    const int printed = indel_bfb_runs(g, n, W.L.ends, m, cur, buf, cap2, U.path_cap, S, W.misc, &edited, A.stage_clk ? A.stage_clk + (int64_t)u * kStageSlots : nullptr);
     if (printed < 0) { hand_on(); return; }           // no room for the runs, or an error the full stage reports
     AMBI_MARK(A, g, u, 19);
     int nout = 0, nruns = 0;
@@ -1229,23 +1252,28 @@ AMBI_HD void stage_finish_edit(const G& g, const BatchArgs& A, int u, uint8_t* w
         // emission without a workgroup barrier, the other wavefronts write the cells of the edited path meanwhile
         if (g.tid() < 64) {
             WaveGroup w;
-            nout = synth_out_juncs_runs(w, cur.val, cur.n, cur.off, gout, U.out_cap, W.cand, base);
-            if (A.run_cnt) nruns = emit_runs_pairs(w, cur.val, cur.n, cur.off, cur.P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
-        } else if (edited) {
-            const int lane = g.tid() & 63, sub = (g.tid() >> 6) - 1, nsub = (g.size() >> 6) - 1;
-            for (int j = sub; j < cur.n; j += nsub) {
-                const int a = cur.val[2 * j], o0 = cur.off[j], len = cur.off[j + 1] - o0;
-                for (int k = lane; k < len; k += 64) gpath2[o0 + k] = (rcell_t)(a + k);
+            nout = synth_out_juncs_runs(w, cur.val, cur.n, cur.off, gout, U.out_cap, W.cand, base, W.htab, W.htab_ints);
+        } else {
+            if (g.tid() < 128 && A.run_cnt) {
+                WaveGroup w;
+                nruns = emit_runs_pairs(w, cur.val, cur.n, cur.off, cur.P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
+            }
+            if (edited) {
+                const int lane = g.tid() & 63, sub = (g.tid() >> 6) - 1, nsub = (g.size() >> 6) - 1;
+                for (int j = sub; j < cur.n; j += nsub) {
+                    const int a = cur.val[2 * j], o0 = cur.off[j], len = cur.off[j + 1] - o0;
+                    for (int k = lane; k < len; k += 64) gpath2[o0 + k] = (rcell_t)(a + k);
+                }
             }
         }
         nout = g.bcast_i32(nout, 0);
-        nruns = g.bcast_i32(nruns, 0);
+        nruns = g.bcast_i32(nruns, 64);
         AMBI_MARK(A, g, u, 20);
     } else
 #endif
     {
         if (edited) expand_runs(g, cur.val, cur.n, cur.off, gpath2, base, n, (int32_t*)nullptr, (int32_t*)nullptr);
-        nout = synth_out_juncs_runs(g, cur.val, cur.n, cur.off, gout, U.out_cap, W.cand, base);
+        nout = synth_out_juncs_runs(g, cur.val, cur.n, cur.off, gout, U.out_cap, W.cand, base, W.htab, W.htab_ints);
         AMBI_MARK(A, g, u, 20);
         if (A.run_cnt) nruns = emit_runs_pairs(g, cur.val, cur.n, cur.off, cur.P, base, A.run_start + A.run_slot[u], A.run_len + A.run_slot[u], (int)(A.run_slot[u + 1] - A.run_slot[u]));
     }

@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from ambigram_amd import api, synth
-lib = api.load(); lib.ambi_set_device(0); torch.cuda.set_device(0)
+libp = os.environ.get("AMBI_PROFILE_LIB")
+if libp: api._preload_hip_runtime()
+lib = api.load(libp); lib.ambi_set_device(0); torch.cuda.set_device(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 lean = len(sys.argv) > 2 and sys.argv[2] == "lean"     # units without SVs: the lean finish stage
 tmp = tempfile.mkdtemp(); b = api.Batch(lib); keep = []
