@@ -244,47 +244,81 @@ __global__ __launch_bounds__(1024) void ambi_plan_kernel(BatchArgs A) {
         __threadfence();
         __syncthreads();
     }
+    // Every thread takes kPlanPer CONSECUTIVE units of a chunk of kPlanPer * blockDim.x: their headers are read together (one round
+    // trip to memory per chunk and pass instead of one per unit), the prefix sums inside a thread are serial, and a chunk costs two
+    // block scans (offsets; work blocks, which depend on what fits) -- round 3's form read and scanned blockDim.x units at a time: nine
+    // scans and five dependent round trips for the bench batch's 4096 units, 27 us with the chip otherwise idle.
+    constexpr int kPlanPer = 4;
+    const int chunk = kPlanPer * (int)blockDim.x;
+    const bool one_chunk = A.n_units <= chunk;
+    int64_t R_[kPlanPer]; int K_[kPlanPer]; bool wanted_[kPlanPer];
+    auto load_chunk = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < kPlanPer; k++) {
+            const int i = base + (int)threadIdx.x * kPlanPer + k;
+            R_[k] = 0; K_[k] = 0; wanted_[k] = false;
+            if (i < A.n_units) {
+                const UnitOut* o = unit_out(A.results, A.unit_base + i);
+                wanted_[k] = o->order_off == kOrderOffWanted;   // (not the status: the scan for the first valid order may be rewriting it)
+                R_[k] = o->num_orders; K_[k] = o->K;
+            }
+        }
+    };
     // pass 1: rows of the whole batch -> rows per lane of the enumerate kernel
     int64_t my_rows = 0;
-    for (int i = threadIdx.x; i < A.n_units; i += blockDim.x) {
-        const UnitOut* o = unit_out(A.results, A.unit_base + i);
-        if (o->order_off == kOrderOffWanted && o->num_orders < (int64_t)kCountSat) my_rows += o->num_orders;
+    for (int base = 0; base < A.n_units; base += chunk) {
+        load_chunk(base);
+#pragma unroll
+        for (int k = 0; k < kPlanPer; k++) if (wanted_[k] && R_[k] < (int64_t)kCountSat) my_rows += R_[k];
     }
     int64_t total_rows;
     (void)block_exscan_i64(my_rows, &total_rows, sh);
     const int TL = rows_per_lane_for(total_rows, A.target_lanes);
     int64_t off_carry = 0, blk_carry = 0;
-    for (int base = 0; base < A.n_units; base += blockDim.x) {
-        const int i = base + (int)threadIdx.x;     // local index inside the slice
-        const int u = A.unit_base + i;              // global unit
-        int64_t bytes = 0, blocks = 0;
+    for (int base = 0; base < A.n_units; base += chunk) {
+        if (!one_chunk) load_chunk(base);
         const int T = TL;
-        bool live = false, toobig = false;
-        UnitOut* out = nullptr;
-        if (i < A.n_units) {
-            out = unit_out(A.results, u);
-            if (out->order_off == kOrderOffWanted) {   // (not the status: the scan for the first valid order may be rewriting it)
-                const int K = out->K;
-                const int64_t R = out->num_orders;
-                if (R >= (int64_t)kCountSat) toobig = true;
+        int64_t bytes[kPlanPer], blocks[kPlanPer], sum_b = 0;
+        bool live[kPlanPer], toobig[kPlanPer];
+#pragma unroll
+        for (int k = 0; k < kPlanPer; k++) {
+            bytes[k] = 0; blocks[k] = 0; live[k] = false; toobig[k] = false;
+            if (wanted_[k]) {
+                if (R_[k] >= (int64_t)kCountSat) toobig[k] = true;
                 else {
-                    live = true;
-                    bytes = order_bytes(R, K, A.order_align);
-                    blocks = (R + 256ll * T - 1) / (256ll * T);   // one work block = one workgroup = 4 waves x 64*T rows
+                    live[k] = true;
+                    bytes[k] = order_bytes(R_[k], K_[k], A.order_align);
+                    blocks[k] = (R_[k] + 256ll * T - 1) / (256ll * T);   // one work block = one workgroup = 4 waves x 64*T rows
                 }
             }
+            sum_b += bytes[k];
         }
         int64_t tot_b, tot_k;
-        int64_t off = off_carry + block_exscan_i64(bytes, &tot_b, sh);
-        // a unit that does not fit contributes no work blocks
-        bool fits = live && (off + bytes <= A.order_arena_bytes);
-        int64_t blk = blk_carry + block_exscan_i64(fits ? blocks : 0, &tot_k, sh);
-        if (i < A.n_units) {
-            A.blk_off[i] = blk;
-            A.rows_per_lane[u] = T;
-            if (toobig) out->order_off = kOrderOffNoRoom;
-            else if (live) out->order_off = fits ? A.arena_base + off : kOrderOffNoRoom;   // (no room: the finish stage turns the status into ORDERS_CAPACITY)
-            if ((toobig || (live && !fits)) && A.late_flag) { *A.late_flag = 1; __threadfence_system(); }   // a result the express stage published is void
+        int64_t off = off_carry + block_exscan_i64(sum_b, &tot_b, sh);
+        // a unit that does not fit contributes no work blocks (and still advances the offset: orders_needed is the true total)
+        bool fits[kPlanPer];
+        int64_t offs_[kPlanPer], sum_k = 0;
+#pragma unroll
+        for (int k = 0; k < kPlanPer; k++) {
+            offs_[k] = off;
+            fits[k] = live[k] && (off + bytes[k] <= A.order_arena_bytes);
+            off += bytes[k];
+            sum_k += fits[k] ? blocks[k] : 0;
+        }
+        int64_t blk = blk_carry + block_exscan_i64(sum_k, &tot_k, sh);
+#pragma unroll
+        for (int k = 0; k < kPlanPer; k++) {
+            const int i = base + (int)threadIdx.x * kPlanPer + k;
+            if (i < A.n_units) {
+                const int u = A.unit_base + i;
+                UnitOut* out = unit_out(A.results, u);
+                A.blk_off[i] = blk;
+                A.rows_per_lane[u] = T;
+                if (toobig[k]) out->order_off = kOrderOffNoRoom;
+                else if (live[k]) out->order_off = fits[k] ? A.arena_base + offs_[k] : kOrderOffNoRoom;   // (no room: the finish stage turns the status into ORDERS_CAPACITY)
+                if ((toobig[k] || (live[k] && !fits[k])) && A.late_flag) { *A.late_flag = 1; __threadfence_system(); }   // a result the express stage published is void
+            }
+            blk += fits[k] ? blocks[k] : 0;
         }
         off_carry += tot_b;
         blk_carry += tot_k;
@@ -1720,7 +1754,8 @@ class HipBackend : public Backend {
             // beside the plan kernel (one workgroup, 25 us during which the chip is otherwise idle) and the ramp of the
             // enumerate kernel, instead of queueing behind 4096 enumerate workgroups for group memory.
             first_launched_ = false;
-            if (overlap_back_ && first_ahead_ == 3) {
+            static const bool one_event = [] { const char* e = getenv("AMBI_ONE_FRONT_EVENT"); return e && atoi(e) != 0; }();   // experiment: see below
+            if (overlap_back_ && first_ahead_ == 3 && !(one_event && !lazy_)) {
                 (void)hipEventRecord(ev_prep_, st);
                 hipStream_t sf = first_stream_ ? first_stream_ : back_stream_;
                 (void)hipStreamWaitEvent(sf, ev_prep_, 0);
@@ -1738,6 +1773,22 @@ class HipBackend : public Backend {
         tick("ambi_plan_kernel", s, 1, false);
         // (express chain: the lattice kernel reads the status, so the scan of the units the express kernel left stays behind
         // the plan kernel there)
+        {
+            static const bool one_event = [] { const char* e = getenv("AMBI_ONE_FRONT_EVENT"); return e && atoi(e) != 0; }();
+            if (one_event && !express_ && !lazy_ && overlap_back_ && first_ahead_ == 3) {
+                // experiment: ONE event on the caller's stream between prepare and the order-table kernel (behind the plan kernel) instead
+                // of one on either side of the plan kernel; the scan then starts behind the plan kernel
+                (void)hipEventRecord(ev_plan_, st);
+                hipStream_t sf = first_stream_ ? first_stream_ : back_stream_;
+                (void)hipStreamWaitEvent(sf, ev_plan_, 0);
+                tick("ambi_first_kernel", s, 4, true, sf);
+                hipLaunchKernelGGL(ambi_first_kernel, dim3(A.n_units), dim3(64), lds_first_, sf, A);
+                tick("ambi_first_kernel", s, 4, false, sf);
+                (void)hipEventRecord(ev_first_, sf);
+                first_launched_ = true;
+                return;
+            }
+        }
         if (overlap_back_) (void)hipEventRecord(first_launched_ ? ev_plan_ : ev_prep_, st);
     }
     void launch_build(int s, const BatchArgs& A) {   // block-emission images
