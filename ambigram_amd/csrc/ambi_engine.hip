@@ -1821,10 +1821,12 @@ class HipBackend : public Backend {
         // 1.16 / 1.14 / 1.09-1.11 / 1.087-1.091 / 1.10-1.13 / 1.10-1.14 / 1.13-1.15, profiles/r03_notes.md: the rule gives 164 there,
         // rounded up to a multiple of 16 = 176; round 2 rounded to 32 = 192)
         // (with the direct launch's units edited on their runs -- ambi_finish_edit_kernel, done well before the table -- the lean kernel
-        // gets the room the full-stage workgroups used to take: 224 (this rule) / 256 / 288 / 320 / 352 / 384 workgroups = 0.877 / 0.836 /
-        // 0.802 / 0.792 / -- / 0.813 ms per step on one box, 288 / 304 / 320 / 336 / 352 = 0.866 / 0.853 / 0.842 / 0.848 / 0.843 on another,
-        // against 0.844-0.855 and 0.880-0.886 with the full-stage launch: half as many again)
-        const double room = (direct_edit_ && direct_n_ > 0 && direct_ext_ && d_direct_cells_) ? 1.5 : 1.0;
+        // gets some of the room the full-stage workgroups used to take.  First build of that stage: 224 (this rule) / 256 / 288 / 320 / 384
+        // workgroups = 0.877 / 0.836 / 0.802 / 0.792 / 0.813 ms per step on one box, against 0.844-0.855 with the full-stage launch; with the
+        // shorter lean stage of the final code (hashed synthesis, run emission beside it): 192 / 208 / 224 / 240 / 256 / 272 / 288 / 304 / 320 /
+        // 336 = 0.82-0.86 / 0.78-0.83 / 0.82 / 0.78-0.81 / 0.77-0.81 / 0.826 / 0.830 / 0.847 / 0.847 / 0.848 on two boxes, three runs each
+        // (profiles/r04_notes.md): one lean workgroup per CU; a fifth more than the rule's own figure)
+        const double room = (direct_edit_ && direct_n_ > 0 && direct_ext_ && d_direct_cells_) ? 1.2 : 1.0;
         int64_t grid = (int64_t)((double)U * unit_us * room / enum_us) + 1;
         grid = (grid + 15) & ~int64_t(15);
         if (grid < 32) grid = 32;
