@@ -85,7 +85,7 @@ def main():
         wr_all, wr_k = total(a.paths[0], "WRITE_SIZE")
         rd_all, rd_k = total(a.paths[1], "FETCH_SIZE")
         step_kernels = ("ambi_prepare_kernel", "ambi_plan_kernel", "ambi_blocks_build_kernel", "ambi_enumerate_blocks_kernel", "ambi_enumerate_kernel",
-                        "ambi_first_kernel", "ambi_finish_lean_kernel", "ambi_finish_kernel", "ambi_finish_ext_kernel", "ambi_express_kernel", "ambi_lattice_kernel")
+                        "ambi_first_kernel", "ambi_finish_lean_kernel", "ambi_finish_kernel", "ambi_finish_ext_kernel", "ambi_finish_edit_kernel", "ambi_express_kernel", "ambi_lattice_kernel")
         per_kernel = {k: {"write": wr_k.get(k, 0.0), "fetch_corrected": 2.0 * rd_k.get(k, 0.0)} for k in sorted(set(wr_k) | set(rd_k))
                       if k.split("<")[0] in step_kernels}
         step_bytes = sum(v["write"] + v["fetch_corrected"] for v in per_kernel.values())
