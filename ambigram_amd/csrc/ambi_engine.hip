@@ -1078,7 +1078,7 @@ static int lease_stream(Lease* L, int kind, int prio, hipStream_t* out) {
 struct StreamClasses {
     std::vector<hipStream_t> cand; std::vector<int> cls;    // candidates and their classes
     std::vector<hipStream_t> rep;                            // one stream per class (class index = position)
-    std::vector<std::pair<hipStream_t, int>> callers;        // callers' streams seen so far
+    std::vector<std::pair<hipStream_t, uint32_t>> callers;   // callers' streams seen so far, with the SET of classes each collides with
     bool built = false;
 };
 constexpr float kProbeSharedUs = 55.f;   // measured: 10-17 us side by side, 105-125 us behind the backlog
@@ -1120,19 +1120,31 @@ static int classified_side_streams(int device, hipStream_t caller, int set, hipS
     std::lock_guard<std::mutex> lk(g_classes_mu);
     StreamClasses& C = g_classes[device];
     if (int rc = build_stream_classes(C)) return rc;
-    int cc = -2;
-    for (auto& pr : C.callers) if (pr.first == caller) cc = pr.second;
-    if (cc == -2) {
-        for (size_t i = 0; i < C.cand.size(); i++) if (C.cand[i] == caller) cc = C.cls[i];
-        if (cc == -2) { if (int rc = stream_class_of(C, caller, &cc)) return rc; }
-        C.callers.push_back({caller, cc});
-        if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: caller's stream %p is in dispatch class %d\n", (void*)caller, cc);
-    }
+    // Every class the caller's stream collides with, in either direction: a stream can sit on the dispatch pipe of one class AND share a
+    // hardware queue with a candidate of another (the legacy default stream of a process that creates it after the candidates: the lattice
+    // kernel of a single sample then ran BEHIND the express kernel on one queue, 142 instead of 89 us end to end from a C caller).
     const int nc = (int)C.rep.size();
+    uint32_t mask = 0; bool known = false;
+    for (auto& pr : C.callers) if (pr.first == caller) { mask = pr.second; known = true; }
+    if (!known) {
+        for (size_t i = 0; i < C.cand.size(); i++) if (C.cand[i] == caller) { mask = 1u << C.cls[i]; known = true; }
+        if (!known) {
+            for (int c = 0; c < nc; c++) {
+                float ab = 0, ba = 0;
+                if (int rc = stream_probe_us(C.rep[c], caller, &ab)) return rc;
+                if (ab <= kProbeSharedUs) { if (int rc = stream_probe_us(caller, C.rep[c], &ba)) return rc; }
+                if (ab > kProbeSharedUs || ba > kProbeSharedUs) mask |= 1u << c;
+            }
+        }
+        C.callers.push_back({caller, mask});
+        if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: caller's stream %p collides with the dispatch classes 0x%x (of %d)\n", (void*)caller, mask, nc);
+    }
+    int cc = -1;
+    for (int c = 0; c < nc; c++) if ((mask >> c) & 1u) { cc = c; break; }
     int k = 0;
     for (int step = 1; step <= nc && k < 3; step++) {
         const int c = ((cc < 0 ? 0 : cc) + step) % nc;
-        if (c == cc) continue;
+        if ((mask >> c) & 1u) continue;
         // the set-th candidate of class c (wrapping)
         std::vector<hipStream_t> of;
         for (size_t i = 0; i < C.cand.size(); i++) if (C.cls[i] == c) of.push_back(C.cand[i]);
