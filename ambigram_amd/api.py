@@ -101,6 +101,7 @@ def _declare(L):
         "ambi_batch_unit_prepare": (C.c_int, [vp, i32, pd, pd, pi32, pi32]),
         "ambi_batch_unit_dag": (C.c_int, [vp, i32, pi32, pi32, _P(C.c_uint64)]),
         "ambi_batch_unit_dag_words": (C.c_int, [vp, i32, _P(C.c_uint64)]),
+        "ambi_batch_unit_dag_nwords": (C.c_int, [vp, i32, i32, _P(C.c_uint64)]),
         "ambi_batch_unit_out_juncs": (C.c_int, [vp, i32, pi32, pi32, pi32, i32]),
         "ambi_batch_unit_orders": (C.c_int, [vp, i32, i64, i64, pu8]),
         "ambi_batch_set_timing": (C.c_int, [vp, i32]),
@@ -502,10 +503,10 @@ class Batch:
         pat = np.zeros((max(K, 1), 3), np.int32); loop = np.zeros((max(K, 1), 3), np.int32); succ = np.zeros(max(K, 1), np.uint64)
         self._ck(self.lib.ambi_batch_unit_dag(self.h, u, pat.ctypes.data_as(_P(C.c_int32)), loop.ctypes.data_as(_P(C.c_int32)),
                                                succ.ctypes.data_as(_P(C.c_uint64))), "unit_dag")
-        if K > 63:      # a wide unit: successor sets as Python integers over both words
-            w = np.zeros(2 * K, np.uint64)
-            self._ck(self.lib.ambi_batch_unit_dag_words(self.h, u, w.ctypes.data_as(_P(C.c_uint64))), "unit_dag_words")
-            return pat[:K], loop[:K], [int(w[2 * i]) | (int(w[2 * i + 1]) << 64) for i in range(K)]
+        if K > 63:      # a wide unit: successor sets as Python integers over all four words
+            w = np.zeros(4 * K, np.uint64)
+            self._ck(self.lib.ambi_batch_unit_dag_nwords(self.h, u, 4, w.ctypes.data_as(_P(C.c_uint64))), "unit_dag_nwords")
+            return pat[:K], loop[:K], [sum(int(w[4 * i + k]) << (64 * k) for k in range(4)) for i in range(K)]
         return pat[:K], loop[:K], succ[:K]
 
     def unit_out_juncs(self, u):

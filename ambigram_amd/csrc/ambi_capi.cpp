@@ -640,9 +640,9 @@ int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, 
     int local = unit;
     Backend* be = b->owner(unit, &local);
     const int base = b->hb.units[unit].seg_base;
-    if (h->K > kMaxNodes) {   // a wide unit (64..127 nodes): succ[] gets the LOW word of every successor set (ambi_batch_unit_dag_words has both)
-        std::vector<int32_t> p(128 * 3), l(128 * 3);
-        std::vector<uint64_t> s2(256);
+    if (h->K > kMaxNodes) {   // a wide unit (64..255 nodes): succ[] gets the LOW word of every successor set (ambi_batch_unit_dag_nwords has all)
+        std::vector<int32_t> p(kWideNodeCap * 3), l(kWideNodeCap * 3);
+        std::vector<uint64_t> s2((size_t)kWideNodeCap * kWideWords);
         int rc = be->copy_dag_wide(local, p.data(), l.data(), s2.data());
         if (rc) return rc;
         for (int i = 0; i < h->K; i++) {
@@ -650,7 +650,7 @@ int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, 
                 if (node2pat) node2pat[3 * i + c] = p[3 * i + c] + ((c < 2 && p[3 * i] != 0) ? base : 0);
                 if (node2loop) node2loop[3 * i + c] = l[3 * i + c] + ((c < 2 && l[3 * i] != 0) ? base : 0);
             }
-            if (succ) succ[i] = s2[2 * i];
+            if (succ) succ[i] = s2[(size_t)kWideWords * i];
         }
         return h->K;
     }
@@ -666,25 +666,27 @@ int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, 
     }
     return h->K;
 }
-int ambi_batch_unit_dag_words(const ambi_batch_t* b, int32_t unit, uint64_t* succ2) {
+int ambi_batch_unit_dag_nwords(const ambi_batch_t* b, int32_t unit, int32_t nwords, uint64_t* succ) {
     const UnitOut* h = header(b, unit);
-    if (!h || !succ2) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
+    if (!h || !succ || nwords < 1) return b && !b->downloaded ? AMBI_ERR_STATE : AMBI_ERR_ARG;
     int local = unit;
     Backend* be = b->owner(unit, &local);
     if (h->K > kMaxNodes) {
-        std::vector<int32_t> p(128 * 3), l(128 * 3);
-        std::vector<uint64_t> s2(256);
+        std::vector<int32_t> p(kWideNodeCap * 3), l(kWideNodeCap * 3);
+        std::vector<uint64_t> s2((size_t)kWideNodeCap * kWideWords);
         int rc = be->copy_dag_wide(local, p.data(), l.data(), s2.data());
         if (rc) return rc;
-        for (int i = 0; i < 2 * h->K; i++) succ2[i] = s2[i];
+        for (int i = 0; i < h->K; i++)
+            for (int w = 0; w < nwords; w++) succ[(size_t)nwords * i + w] = w < kWideWords ? s2[(size_t)kWideWords * i + w] : 0;
         return h->K;
     }
     Dag D;
     int rc = be->copy_dag(local, &D);
     if (rc) return rc;
-    for (int i = 0; i < h->K; i++) { succ2[2 * i] = D.succ[i]; succ2[2 * i + 1] = 0; }
+    for (int i = 0; i < h->K; i++) for (int w = 0; w < nwords; w++) succ[(size_t)nwords * i + w] = w == 0 ? D.succ[i] : 0;
     return h->K;
 }
+int ambi_batch_unit_dag_words(const ambi_batch_t* b, int32_t unit, uint64_t* succ2) { return ambi_batch_unit_dag_nwords(b, unit, 2, succ2); }
 int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap) {
     PathView pv;
     if (!path_view(b, unit, pv)) return b && !b->downloaded && !b->mail_view ? AMBI_ERR_STATE : AMBI_ERR_ARG;

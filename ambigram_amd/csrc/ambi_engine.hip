@@ -560,7 +560,7 @@ __global__ __launch_bounds__(1024) AMBI_ENUM_ATTR void ambi_enumerate_blocks_ker
 }
 
 // Order tables of the wide units (64..127 nodes, row class 3): 64 workgroups per wide unit, one thread per row -- the row is
-// unranked from the unit's completion counts (unrank_wide) and written as 128 bytes (nodes, then 0xFF).  Rare units, at most
+// unranked from the unit's completion counts (unrank_wide) and written as 128 or 256 bytes (nodes, then 0xFF).  Rare units, at most
 // kWideMaxOrders rows each: written for correctness, not for the roofline.
 __global__ __launch_bounds__(256) void ambi_enumerate_wide_kernel(BatchArgs A, const int32_t* wide_units, int n_wide) {
     const int w = blockIdx.y;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void ambi_enumerate_wide_kernel(BatchArgs A, c
     const int K = out->K, stride = row_stride(K);
     uint8_t* rows = A.order_arena + out->order_off;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < out->num_orders; r += (int64_t)gridDim.x * blockDim.x) {
-        alignas(16) uint8_t row[128];
+        alignas(16) uint8_t row[kWideNodeCap];
         unrank_wide(X, (uint64_t)r, row);
         for (int d = K; d < stride; d++) row[d] = 0xFF;
         uint4* dst = reinterpret_cast<uint4*>(rows + r * stride);
@@ -1463,7 +1463,12 @@ class HipBackend : public Backend {
         // (measured, lean grid re-tuned for each: 128 threads 0.94-1.00, 256 threads 0.90 ms per step on one box)
         { const char* e = getenv("AMBI_LEAN_THREADS"); lean_threads_ = e ? atoi(e) : 256; if (lean_threads_ != 128) lean_threads_ = 256; }
         { const char* e = getenv("AMBI_LEAN_WAVE_GRID"); lean_wave_grid_ = e ? atoi(e) : 0; if (lean_wave_grid_ < 0) lean_wave_grid_ = 0; }
-        enum_stack_lds_ = (int)enum_stack_bytes(H.max_k > 0 ? H.max_k : 1);
+        {   // the general enumerate kernel serves ordinary units only (wide ones have their own table kernel): its per-lane stacks are
+            // sized by the largest ORDINARY unit -- with the wide units' node count they outgrew a CU's group memory at 255 nodes
+            int mk = 1;
+            for (const UnitIn& un : H.units) if (un.n_elem <= kMaxNodes && un.n_elem > mk) mk = un.n_elem;
+            enum_stack_lds_ = (int)enum_stack_bytes(mk);
+        }
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
         { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
         { const char* env = getenv("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
@@ -1475,8 +1480,8 @@ class HipBackend : public Backend {
         if (block_scratch_lds_ > kLdsLimit) block_scratch_lds_ = kLdsLimit & ~15;
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
-            fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d bytes)\n",
-                    lds_prepare_, lds_first_, lds_finish_);
+            fprintf(stderr, "ambigram_hip: a unit needs more LDS than one CU has (prepare %d, first %d, finish %d, general enumerate %d, block emission %d bytes)\n",
+                    lds_prepare_, lds_first_, lds_finish_, lds_enum_, lds_blocks_);
             return ST_ERR_BAD_INPUT;
         }
         {   // the dynamic-LDS ceiling of every kernel: a per-function, process-wide attribute, set once
@@ -2547,9 +2552,9 @@ class HipBackend : public Backend {
         if (unit < 0 || unit >= (int)hb().units.size() || hb().wide_index[unit] < 0) return ST_ERR_BAD_INPUT;
         const WideUnit* X = d_wide_ + hb().wide_index[unit];
         const uint8_t* base = reinterpret_cast<const uint8_t*>(X);
-        HIP_CK(hipMemcpy(pat, base + offsetof(WideUnit, dag) + offsetof(WideDag, pat), sizeof(int32_t) * 128 * 3, hipMemcpyDeviceToHost));
-        HIP_CK(hipMemcpy(loop, base + offsetof(WideUnit, dag) + offsetof(WideDag, loop), sizeof(int32_t) * 128 * 3, hipMemcpyDeviceToHost));
-        HIP_CK(hipMemcpy(succ2, base + offsetof(WideUnit, succ), sizeof(U128) * 128, hipMemcpyDeviceToHost));
+        HIP_CK(hipMemcpy(pat, base + offsetof(WideUnit, dag) + offsetof(WideDag, pat), sizeof(int32_t) * kWideNodeCap * 3, hipMemcpyDeviceToHost));
+        HIP_CK(hipMemcpy(loop, base + offsetof(WideUnit, dag) + offsetof(WideDag, loop), sizeof(int32_t) * kWideNodeCap * 3, hipMemcpyDeviceToHost));
+        HIP_CK(hipMemcpy(succ2, base + offsetof(WideUnit, succ), sizeof(WideSet) * kWideNodeCap, hipMemcpyDeviceToHost));
         return 0;
     }
     void set_timing(bool on) override { timing_ = on; timing_mask_ = ~0u; timed_runs_ = 0; }
@@ -2615,7 +2620,9 @@ class HipBackend : public Backend {
             // of resident wavefronts (group-memory latency), and every KB of group memory costs some.
             int auto_bytes = 0;
             { const char* e = getenv("AMBI_ALL_AUTO_LDS"); if (e) auto_bytes = atoi(e) & ~15; if (auto_bytes < 0) auto_bytes = 0; }
-            const int rows_bytes = 64 * ((hb().max_k + 3) & ~3);   // transposed orders: one 64-lane row per position
+            int max_k_lane = 1;
+            for (const UnitIn& un : hb().units) if (un.n_elem <= kMaxNodes && un.n_elem > max_k_lane) max_k_lane = un.n_elem;   // (wide units: ambi_all_kernel)
+            const int rows_bytes = 64 * ((max_k_lane + 3) & ~3);   // transposed orders: one 64-lane row per position
             const int lane_wave_lds = (head_bytes + rows_bytes + max_lane_cells * 64 * (int)sizeof(cell_t) + auto_bytes + 15) & ~15;
             int lane_waves = 1;   // wavefronts per workgroup (measured 1 / 2 / 4 = 563 / 553 / 379 M orders/s: group-memory allocation granularity)
             { const char* e = getenv("AMBI_ALL_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 4) lane_waves = atoi(e); }

@@ -30,10 +30,10 @@ constexpr int kFirstRowStride = 64;       // bytes between the pre-unranked firs
 // number of dwords: 12 bytes for K = 19 where rounds 1-3 wrote 20, 32 for K = 41 instead of 48.  The table is the reference's
 // `orders` (LGM.cpp:3380-3409) in the engine's own layout: nothing but the engine's kernels and ambi_batch_unit_orders (which
 // unpacks) ever reads it, and the block emission (ambi_enum_blocks.hpp) ORs prefix and suffix DWORDS, whatever the fields inside
-// them are.  64..127 nodes (wide units, ambi_wide.hpp): one byte per node, 128 bytes.
+// them are.  64..255 nodes (wide units, ambi_wide.hpp): one byte per node, 128 bytes up to 127 nodes, 256 above.
 AMBI_HD int row_bits(int K) { return K <= 32 ? 5 : (K <= 63 ? 6 : 8); }
 AMBI_HD bool row_packed(int K) { return K <= 63; }
-AMBI_HD int row_stride(int K) { return K <= 63 ? 4 * ((K * row_bits(K) + 31) >> 5) : 128; }
+AMBI_HD int row_stride(int K) { return K <= 63 ? 4 * ((K * row_bits(K) + 31) >> 5) : (K <= 127 ? 128 : 256); }
 // dwords of the register form of a row in the general enumerate path (one byte per node there; packed when it is stored)
 AMBI_HD int row_byte_words(int K) { return K <= 32 ? ((K + 3) >> 2) : (K <= 48 ? 12 : (K <= 63 ? 16 : 32)); }
 // node d of a row (`row` = its first dword)

@@ -13,7 +13,7 @@ int HostBatch::add_unit(int n_seg, int seg_base, const double* cn_local, int n_j
                         const int32_t* e_is_loop, const int32_t* e_a, const int32_t* e_b, const int32_t* e_cn,
                         int infeasible, int has_components) {
     if (n_seg < 1 || n_seg > kMaxSegLocal || n_junc < 0 || n_junc > 65535 || n_elem < 0) return ST_ERR_BAD_INPUT;   // 16-bit junction indices in LDS
-    if (n_elem > kMaxNodesWide) return ST_ERR_TOO_MANY_NODES;   // (64..127: a wide unit, ambi_wide.hpp)
+    if (n_elem > kMaxNodesWide) return ST_ERR_TOO_MANY_NODES;   // (64..255: a wide unit, ambi_wide.hpp)
     UnitIn U{};
     U.n_seg = n_seg; U.seg_base = seg_base; U.n_junc = n_junc; U.n_elem = n_elem;
     U.infeasible = infeasible; U.has_components = has_components;

@@ -41,7 +41,7 @@ AMBI_HD bool compare_keys(uint32_t x, uint32_t y) { return (y >> 8) != 0u && (x 
 //   last_not_after(from, x)        largest  i in [0, from] with !comp(x, a[i]), else -1   (right scan; __unguarded_linear_insert)
 //   shift_up(lo, hi)               a[k + 1] = a[k] for k = hi-1 .. lo                     (move_backward / the insert's moves)
 struct MemWords {
-    static constexpr int kCap = 128;   // elements the replay may be asked for (the record's position rides in the key's low byte)
+    static constexpr int kCap = 255;   // elements the replay may be asked for (the record's position rides in the key's low byte)
     uint32_t* a;
     AMBI_HD uint32_t get(int i) const { return a[i]; }
     AMBI_HD void set(int i, uint32_t x) { a[i] = x; }
@@ -188,7 +188,7 @@ AMBI_HD int floor_lg(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return 
 
 }  // namespace sortdetail
 
-// std::sort(a, a+n, compareLoops) on the keys, n <= ARR::kCap (64 in lane registers, 128 in memory).  `stack`: kSortStack words for the parked left parts, one
+// std::sort(a, a+n, compareLoops) on the keys, n <= ARR::kCap (64 in lane registers, 255 in memory).  `stack`: kSortStack words for the parked left parts, one
 // packed word { first : 10, last : 10, depth : 12 } each.  The parked parts have strictly increasing depth budgets from
 // the top of the stack down, so 2*floor(log2 n) + 1 <= 15 words suffice.
 constexpr int kSortStack = 24;
@@ -231,16 +231,16 @@ AMBI_HD void libstdcxx_sort_keys(ARR& a, int n, bool* ub, STK& stack) {
 }
 
 // Record form (tests/hostsim/sort_probe.cpp checks it against the real std::sort with compareLoops): keys from the
-// records, replay, records permuted by the position bytes.  n <= 128; `stack`: kSortStack + 128 words.
+// records, replay, records permuted by the position bytes.  n <= 255; `stack`: kSortStack + 256 words.
 AMBI_HD void libstdcxx_sort_loops(Rec3* a, int n, bool* ub, uint32_t* stack) {
-    if (n > 128) { if (ub) *ub = true; return; }
+    if (n > 255) { if (ub) *ub = true; return; }
     MemWords keys{stack + kSortStack}, stk{stack};
     for (int i = 0; i < n; i++) keys.a[i] = loop_sort_key(a[i].v[0], a[i].v[1], i);
     bool u = false;
     libstdcxx_sort_keys(keys, n, &u, stk);
     if (ub) *ub = u;
     if (u) return;
-    Rec3 tmp[128];
+    Rec3 tmp[256];
     for (int i = 0; i < n; i++) tmp[i] = a[i];
     for (int i = 0; i < n; i++) a[i] = tmp[keys.a[i] & 255u];
 }

@@ -540,11 +540,11 @@ struct FirstWork {
     int16_t* inv_tgt;   // [n+1]
     Dag* dag;           // node records of an ordinary unit ...
     WideDag* wdag;      // ... or of a wide one (the same bytes; nullptr for ordinary units)
-    uint8_t* ord;       // [64], [128] for a wide unit
+    uint8_t* ord;       // [64], [256] for a wide unit
 };
-// wide: the area is laid out for a unit with 64..127 nodes (larger node records, 128-byte order row)
+// wide: the area is laid out for a unit with 64..255 nodes (larger node records, an order row of up to 256 bytes)
 AMBI_HD int64_t first_work_bytes(int n, int bkp_cap, bool wide = false) {
-    return pad8(2ll * bkp_cap) + 2 * pad8(2ll * (n + 1)) + pad8(wide ? sizeof(WideDag) : sizeof(Dag)) + (wide ? 128 : 64);
+    return pad8(2ll * bkp_cap) + 2 * pad8(2ll * (n + 1)) + pad8(wide ? sizeof(WideDag) : sizeof(Dag)) + (wide ? 256 : 64);
 }
 AMBI_HD FirstWork carve_first(uint8_t* base, int n, int bkp_cap, bool wide = false) {
     FirstWork W;

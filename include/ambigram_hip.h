@@ -35,7 +35,7 @@ extern "C" {
 #define AMBI_ST_SHORTCUT 1        /* no fold-back inversion: path 1+..n+ (localhap.cpp:164-170) */
 #define AMBI_ST_INFEASIBLE 2      /* .sol Infeasible: path 1+..n+ + "ILP is unsolvable." (localhap.cpp:213-220) */
 #define AMBI_ST_NO_VALID_ORDER 3  /* no order assembles in either orientation (reference leaves the path empty) */
-#define AMBI_ERR_TOO_MANY_NODES (-10)  /* more than 127 selected patterns + loops in one chromosome */
+#define AMBI_ERR_TOO_MANY_NODES (-10)  /* more than 255 selected patterns + loops in one chromosome */
 #define AMBI_ERR_NO_ELEMENTS (-11)
 #define AMBI_ERR_REF_UB (-12)     /* the reference reads out of bounds on this input; refused instead of guessed */
 #define AMBI_ERR_BKP_CAPACITY (-13)
@@ -278,8 +278,10 @@ int ambi_batch_unit_prepare(const ambi_batch_t* b, int32_t unit, double* junc_cn
                             int32_t* inv_junc_global);
 /* DAG of the unit: node2pat / node2loop as [K][3] (absolute ids; a==0 empty), successor bit masks [K] */
 int ambi_batch_unit_dag(const ambi_batch_t* b, int32_t unit, int32_t* node2pat, int32_t* node2loop, uint64_t* succ);
-/* successor sets of the unit's K nodes as [K][2] 64-bit words (bit j of word j/64): a unit may have up to 127 nodes (64..127: a
- * "wide" unit, served by the plain two-word form of the DAG / lattice stages; ambi_batch_unit_dag's succ[] carries the low word) */
+/* successor sets of the unit's K nodes as [K][nwords] 64-bit words (bit j of word j/64): a unit may have up to 255 nodes (64..255: a
+ * "wide" unit, served by the plain four-word form of the DAG / lattice stages of LocalGenomicMap.cpp:3276-3409; ambi_batch_unit_dag's
+ * succ[] carries the low word).  ambi_batch_unit_dag_words = the same with nwords = 2 (enough up to 127 nodes; kept from round 3). */
+int ambi_batch_unit_dag_nwords(const ambi_batch_t* b, int32_t unit, int32_t nwords, uint64_t* succ);
 int ambi_batch_unit_dag_words(const ambi_batch_t* b, int32_t unit, uint64_t* succ2);
 int ambi_batch_unit_out_juncs(const ambi_batch_t* b, int32_t unit, int32_t* u, int32_t* v, int32_t* count, int32_t cap);
 /* --all (localhap.cpp:38, LocalGenomicMap.cpp:3672-3695): after ambi_batch_run(b, AMBI_FLAG_ALL, ...) + wait, every

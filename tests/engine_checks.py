@@ -346,8 +346,8 @@ def check_mixed_batch(lib, oracle, workdir, big=False):
 
 
 def check_max_sizes(lib, oracle, workdir):
-    """The engine's documented limits: 63 DAG nodes per unit on the fast path, 64..127 on the wide path
-    (tests/test_wide_units.py), 128 are refused when the unit is added;
+    """The engine's documented limits: 63 DAG nodes per unit on the fast path, 64..255 on the wide path
+    (tests/test_wide_units.py), 256 are refused when the unit is added;
     a path longer than the 65 536 cells the full finish stage can hold in group memory is served by the lean stage (runs
     only); if its SVs edit the path, by the direct full-stage launch with the cells in device memory -- ST_ERR_PATH_CAPACITY
     only where the group-memory form runs."""
@@ -366,8 +366,8 @@ def check_max_sizes(lib, oracle, workdir):
         assert r["status"] == 0 and r["n_nodes"] == K and r["num_orders"] == o["num_orders"], r
         assert b.unit_path(0, 0).tolist() == o["path"] and b.unit_path(0, 1).tolist() == o["path_indel"]
         b.close(); g.close()
-    s = synth.make_sample(512, 1024, "chain", 128, seed=4242)
-    lh, sols = s.write(workdir, "max_chain128")
+    s = synth.make_sample(620, 1300, "chain", 256, seed=4242)
+    lh, sols = s.write(workdir, "max_chain256")
     g = api.Graph(lib, lh)
     with pytest.raises(api.AmbiError) as e:
         api.Batch(lib).add_chromosome_sol(g, 0, sols[0])

@@ -122,7 +122,7 @@ class HostSimBackend : public Backend {
                     const WideUnit& X = A_.wide[A_.wide_index[u]];
                     const int stride = row_stride(K);
                     for (int64_t r = 0; r < R; r++) {
-                        uint8_t row[128];
+                        uint8_t row[kWideNodeCap];
                         unrank_wide(X, (uint64_t)r, row);
                         for (int d = K; d < stride; d++) row[d] = 0xFF;
                         memcpy(rows + r * stride, row, (size_t)stride);

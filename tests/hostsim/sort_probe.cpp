@@ -23,7 +23,7 @@ int hostsim_sort_both(const int* recs, int n, int* out_engine, int* out_std) {
         if (recs[3 * i] != 0) v[i] = {recs[3 * i], recs[3 * i + 1], recs[3 * i + 2]};
     }
     bool ub = false;
-    uint32_t stack[ambi::kSortStack + 128];
+    uint32_t stack[ambi::kSortStack + 256];
     ambi::libstdcxx_sort_loops(a.data(), n, &ub, stack);
     std::sort(v.begin(), v.end(), compareLoopsRef);
     for (int i = 0; i < n; i++) {

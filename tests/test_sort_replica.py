@@ -20,14 +20,14 @@ def _both(lib, recs):
 def test_sort_matches_libstdcxx(hostsim_lib):
     rng = random.Random(1234)
     for trial in range(3000):
-        n = rng.choice([0, 1, 2, 5, 9, 15, 16, 17, 18, 24, 31, 32, 33, 40, 48, 63, 64, 65, 80, 100, 127])   # (above 63: the memory form, units with 64..127 nodes)
+        n = rng.choice([0, 1, 2, 5, 9, 15, 16, 17, 18, 24, 31, 32, 33, 40, 48, 63, 64, 65, 80, 100, 127, 128, 129, 160, 200, 254, 255])   # (above 63: the memory form, units with 64..255 nodes)
         recs = []
         for _ in range(n):
             if rng.random() < 0.35:
                 recs.append([0, 0, 0])                       # empty slot (pattern position)
             else:
                 a = rng.randint(1, 40 if n < 64 else 200)
-                b = rng.randint(a, min(60 if n < 64 else 255, a + rng.choice([0, 1, 2, 3, 5, 8, 20])))
+                b = rng.randint(a, min(60 if n < 64 else 600, a + rng.choice([0, 1, 2, 3, 5, 8, 20, 150])))
                 recs.append([a, b, rng.randint(1, 3)])
         ub, eng, std = _both(hostsim_lib, recs)
         assert ub == 0
@@ -37,7 +37,7 @@ def test_sort_matches_libstdcxx(hostsim_lib):
 def test_sort_reference_layout_loops_then_patterns(hostsim_lib):
     # std::map order puts every "l:" key before every "p:" key, i.e. loops first, empties last
     rng = random.Random(7)
-    for n in range(1, 128):
+    for n in range(1, 256):
         k = rng.randint(0, n)
         recs = [[rng.randint(1, 30), 0, 1] for _ in range(k)] + [[0, 0, 0]] * (n - k)
         for r in recs:

@@ -1,6 +1,6 @@
-"""Units with 64..127 DAG nodes ("wide units", csrc/ambi_wide.hpp).  The reference has no bound on the number of selected
+"""Units with 64..255 DAG nodes ("wide units", csrc/ambi_wide.hpp; up to 127 in round 3).  The reference has no bound on the number of selected
 patterns / loops of a chromosome (constructDAG, LocalGenomicMap.cpp:3276-3301); rounds 1-2 refused more than 63.  Wide units
-take the plain two-word form of the DAG / lattice stages and then the ordinary machinery (order table, parallel search for
+take the plain four-word form of the DAG / lattice stages and then the ordinary machinery (order table, parallel search for
 the first valid order, finish stages, --all).  Everything against the oracle, on the host simulation and on the GPU."""
 import numpy as np
 import pytest
@@ -42,7 +42,8 @@ def _check_unit(lib, oracle, lh, sols, rev=False, orders=True):
 def _cases(workdir, tag):
     out = []
     for (n, m, tier, K, seed) in [(256, 512, "chain", 64, 2), (256, 512, "chain", 80, 1), (256, 512, "chain", 127, 3), (140, 300, "mixed", 65, 1),
-                                  (200, 420, "chain", 100, 4)]:
+                                  (200, 420, "chain", 100, 4), (330, 700, "chain", 128, 5), (400, 840, "chain", 160, 6), (600, 1260, "chain", 255, 7),
+                                  (330, 700, "mixed", 129, 2)]:
         s = synth.make_sample(n, m, tier, K, seed=seed, imperfect=seed % 2, n_del=seed % 3, n_dup=seed % 2, name="%s_%s%d" % (tag, tier, K))
         out.append((tier, K) + tuple(s.write(workdir)))
     return out
@@ -62,8 +63,8 @@ def test_wide_units_on_the_host_simulation(hostsim_lib, oracle, workdir):
     check_wide(hostsim_lib, oracle, workdir, "wh")
 
 
-def test_more_than_127_nodes_is_refused(hostsim_lib, workdir):
-    s = synth.make_sample(300, 640, "chain", 128, seed=9, name="w128")
+def test_more_than_255_nodes_is_refused(hostsim_lib, workdir):
+    s = synth.make_sample(620, 1300, "chain", 256, seed=9, name="w256")
     lh, sols = s.write(workdir)
     g = api.Graph(hostsim_lib, lh)
     b = api.Batch(hostsim_lib)
