@@ -160,6 +160,7 @@ struct BatchArgs {
     int32_t finish_retry;        // 1 (a full-stage launch whose path area, finish_path_cells, is smaller than the units' capacities): a path that
                                  // does not fit the area is handed to the list kernel behind (refin_list), which has the full area
     int32_t direct_full_on;      // 1: units with UnitIn::direct_full are served by a full-stage launch of their own (the lean stage skips them)
+    int32_t edit_cap_limit;      // tests (env AMBI_EDIT_RUN_CAP): upper limit of the edit stage's run lists, so that its hand-over to the full stage can be reached; 0: none
     int32_t* refin_count;        // [1] entries of refin_list; zeroed before the lean kernel, read by the full-stage kernel behind it
     int64_t* host_needed;        // device address of a pinned host int64 (nullptr: the host copies orders_needed itself)
     int64_t* stage_clk;          // [U][kStageSlots] shader-clock marks inside the per-unit stages (nullptr: off; env AMBI_STAGE_PROFILE)

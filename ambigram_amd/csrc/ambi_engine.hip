@@ -1680,6 +1680,7 @@ class HipBackend : public Backend {
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
+        { const char* ec = getenv("AMBI_EDIT_RUN_CAP"); A_.edit_cap_limit = ec ? atoi(ec) : 0; }
         A_.wide = n_wide_ > 0 ? d_wide_ : nullptr; A_.wide_index = n_wide_ > 0 ? d_wide_index_ : nullptr;
         A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
         {   // the finish stages leave the final paths in run-length form in the block of this run's parity (the other one may still be on its way to the host)

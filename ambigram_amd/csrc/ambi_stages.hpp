@@ -1224,7 +1224,7 @@ AMBI_HD void stage_finish_edit(const G& g, const BatchArgs& A, int u, uint8_t* w
         return;
     }
     FinishEditWork W = carve_finish_edit(work, n, m, U.bkp_cap);
-    const int cap2 = edit_run_cap(U.bkp_cap);
+    const int cap2 = (A.edit_cap_limit > 0 && A.edit_cap_limit < edit_run_cap(U.bkp_cap)) ? A.edit_cap_limit : edit_run_cap(U.bkp_cap);
     const int L = out->bkp_len, np = L / 2;
     AMBI_MARK(A, g, u, 16);
     copy_words(g, W.L.bkp, reinterpret_cast<const cell_t*>(res + Lay.bkp), int64_t(L));

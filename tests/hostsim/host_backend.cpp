@@ -82,6 +82,7 @@ class HostSimBackend : public Backend {
         A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
         refin_list_.assign(units_.size() + 1, 0); refin_count_ = 0;
         A_.refin_list = refin_list_.data(); A_.refin_count = &refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
+        { const char* ec = getenv("AMBI_EDIT_RUN_CAP"); A_.edit_cap_limit = ec ? atoi(ec) : 0; }
         A_.wide = wide_.empty() ? nullptr : wide_.data(); A_.wide_index = wide_.empty() ? nullptr : hb_.wide_index.data();
         A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
         A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
