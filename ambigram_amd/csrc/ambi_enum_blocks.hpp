@@ -220,6 +220,29 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
     }
     if (with_directory && g.tid() == 0) img[nB * S] = (uint32_t)R;
     clk_mark(g, clk, 29);
+    // Node records for the walks below (round 4): { available nodes, first link, second link, index of the first link } of every ideal in ONE
+    // 16-byte word, so that a level of a walk is one round trip to group memory where it was two or three (mask and link base, then the
+    // links one after the other; the wide tier's ideals have at most two children).  The records overlay the 64-bit masks and counts at the
+    // front of the tables, which nothing reads any more once the directory is written -- hence only with a directory (the directory-free
+    // emission walks the tables itself) and up to 32 nodes.
+    // (they are put together in the suffix-row area of the image, which is written only afterwards, and copied over the tables behind a barrier)
+    const bool fast_rows = with_directory && K <= 32 && 4ll * nI <= suf_words;
+    if (fast_rows) {
+        g.sync();                                               // (the directory loop above reads avail / cnt64)
+        for (int i = g.tid(); i < nI; i += g.size()) {
+            const uint32_t av = (uint32_t)B.avail[i];
+            const int k0 = B.cbase[i], nch = __builtin_popcount(av);
+            store4(suf + 4 * i, av, nch >= 1 ? B.link[k0] : 0u, nch >= 2 ? B.link[k0 + 1] : 0u, (uint32_t)k0);
+        }
+        g.sync();
+        uint32_t* rec = reinterpret_cast<uint32_t*>(B.avail);   // 16 bytes per ideal over avail[] and cnt64[] (8 + 8 bytes per ideal, one behind the other)
+        for (int i = g.tid(); i < nI; i += g.size()) {
+            uint32_t a, b, c, d;
+            load4(suf + 4 * i, a, b, c, d);
+            store4(rec + 4 * i, a, b, c, d);
+        }
+        g.sync();
+    }
     // ---- suffix rows: row r of root p = r-th completion of p in lexicographic order, bytes in their final positions ----
     const int total_rows = (int)B.root_row[nRoots];
     for (int f = g.tid(); f < total_rows; f += g.size()) {
@@ -234,6 +257,34 @@ AMBI_HD bool build_block_image(const G& g, const IdealTable& T, int K, int NW, i
         for (int x = 0; x < rb.wi; x++) dst[x] = 0;
         auto flush = [&](int wi, uint32_t w) { dst[wi] = w; };
         int j = p, d = D;
+        if (fast_rows) {
+            const uint32_t* rec = reinterpret_cast<const uint32_t*>(B.avail);
+            for (; d < K; d++) {
+                uint32_t av, l0, l1, k0;
+                load4(rec + 4 * j, av, l0, l1, k0);
+                int chosen = __builtin_ctz(av), nxt = (int)(l0 & 0xFFFFu), cc = (int)(l0 >> 16);
+                if (rr >= cc) {
+                    rr -= cc; av &= av - 1;
+                    chosen = __builtin_ctz(av); nxt = (int)(l1 & 0xFFFFu); cc = (int)(l1 >> 16);
+                    if (rr >= cc) {   // a third or later child: the links one by one, as below
+                        rr -= cc; av &= av - 1;
+                        int k = (int)k0 + 2;
+                        chosen = 0;
+                        while (av) {
+                            const int v = __builtin_ctz(av);
+                            av &= av - 1;
+                            const uint32_t lk = B.link[k++];
+                            const int c3 = (int)(lk >> 16);
+                            nxt = (int)(lk & 0xFFFFu);
+                            if (rr < c3) { chosen = v; break; }
+                            rr -= c3;
+                        }
+                    }
+                }
+                rb.put((uint32_t)chosen, fb, flush);
+                j = nxt;
+            }
+        } else
         if (K <= 32) {   // 32-bit masks (low halves of the 64-bit ones), one packed read per sibling
             const uint32_t* av32 = reinterpret_cast<const uint32_t*>(B.avail);
             for (; d < K; d++) {

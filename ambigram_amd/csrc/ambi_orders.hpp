@@ -443,6 +443,16 @@ AMBI_HD void store4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t 
 #endif
 }
 
+// ... and a 16-byte read (group memory: one ds_read_b128)
+AMBI_HD void load4(const uint32_t* src, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *reinterpret_cast<const uint4*>(src);
+    a = v.x; b = v.y; c = v.z; d = v.w;
+#else
+    a = src[0]; b = src[1]; c = src[2]; d = src[3];
+#endif
+}
+
 // Writes rows [first, first+nrows) of the order table.  `out` points at row `first` (16-byte aligned; rows are NW
 // dwords).  Requires first + nrows <= R.  One thread; all lanes of a wave run it in lockstep on their own ranges.
 //
