@@ -29,7 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The engine runs its kernels on four HIP streams (caller's, scan, lean finish, direct full finish).  The HIP runtime puts the
+# The engine runs its kernels on four HIP streams (caller's, scan, lean finish, direct launch for the units whose SVs may edit the path).  The HIP runtime puts the
 # streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; once RCCL has created its own
 # streams (init_process_group), two of the engine's land on ONE queue and the finish kernels run BEHIND the enumerate
 # kernel instead of beside it: 1.55 instead of 1.10 ms per step, measured.  Eight queues keep them apart (and are no worse
@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--tier", default="wide", choices=["chain", "wide", "mixed"])
     ap.add_argument("--K", type=int, default=19)
     ap.add_argument("--sv-every", type=int, default=8, help="every N-th sample carries deletions / duplications that make indelBFB EDIT the path "
-                    "(SURVEY.md 8d padding; those units go through the full finish stage inside the timed region); 0: none")
+                    "(SURVEY.md 8d padding; those units go through indelBFB with edits -- the edit stage on the runs of the path, the full stage for what it hands on -- inside the timed region); 0: none")
     ap.add_argument("--mode", default="default", choices=["default", "all"], help="all: the timed step runs --all (every order of every sample "
                     "evaluated by the fused unrank + evaluate kernel); the headline value stays reconstructions/s")
     ap.add_argument("--all-steps", type=int, default=2, help="steps of the --all leg reported beside the headline (0 disables it)")
@@ -201,7 +201,7 @@ def main():
                     "end_of_last_kernel_ms": warm_spans[last][1],
                     "spans_ms": {k: [round(v[0], 4), round(v[1], 4)] for k, v in sorted(warm_spans.items(), key=lambda kv: kv[1][0])},
                     "note": "HIP events on the streams the kernels run on, warm-up steps (every kernel carries events there: ~4 % slower than the timed steps); "
-                            "ambi_finish_kernel = lean finish + list kernel on their stream, ambi_finish_ext_kernel = direct full finish on its own"}
+                            "ambi_finish_kernel = lean finish + list kernel on their stream, ambi_finish_ext_kernel = the direct launch on its own stream: ambi_finish_edit_kernel (indelBFB on the runs of the path) + the full-stage launch for what it hands on"}
 
     # sanity (outside the timed region): the exchanged payload, expanded again, equals the downloaded paths
     gather()
@@ -633,7 +633,7 @@ def main():
         "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/int16 (node ids, stored as 5-bit fields of the order table / breakpoint cells; f64 copy numbers)", "data": "synthetic",
-        "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, %s; every %s sample carries 2 deletions + 1 duplication that edit the path (full finish stage); %d samples per GPU resident in HBM"
+        "config": {"workload": "synthetic %d-seg/%d-junc .lh, %s DAG tier K=%d, planted .sol, %s; every %s sample carries 2 deletions + 1 duplication that edit the path (indelBFB with edits inside the timed region); %d samples per GPU resident in HBM"
                                % (args.segs, args.juncs, args.tier, args.K, "--all mode" if args.mode == "all" else "default CLI mode",
                                   ("%d-th" % args.sv_every) if args.sv_every > 0 else "no", B),
                    "samples_per_gpu": B, "orders_per_sample": res[0]["num_orders"], "parallelism": "samples sharded over %d GPU(s), results stay in each GPU's HBM%s" % (world, {0: " (no data-path collective)", 1: "; ONE RCCL gather of the last batch's paths (run-length form, expanded on rank 0) at the end of the timed steps", 2: "; one RCCL gather of the paths (run-length form) to rank 0 at the end of every step"}[gather_mode])},
