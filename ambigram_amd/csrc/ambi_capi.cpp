@@ -293,7 +293,7 @@ int ambi_batch_create(ambi_batch_t** out) {
     ambi_batch* b = new ambi_batch();
     b->be.reset(make_backend());
     *out = b;
-    if (getenv("AMBI_DEBUG_SIZES")) {   // diagnostics: heap objects the engine creates and frees per batch
+    if (ambi_env("AMBI_DEBUG_SIZES")) {   // diagnostics: heap objects the engine creates and frees per batch
         static bool once = false;
         if (!once) fprintf(stderr, "ambigram sizes: ambi_batch %zu, HostBatch %zu, backend %zu, BatchArgs (kernel argument block) %zu, UnitIn %zu, UnitOut %zu, Dag %zu\n",
                            sizeof(ambi_batch), sizeof(HostBatch), b->be->object_bytes(), sizeof(BatchArgs), sizeof(UnitIn), sizeof(UnitOut), sizeof(Dag));
@@ -315,7 +315,7 @@ void check_quarantine() {
 }  // namespace
 }  // extern "C++"
 void ambi_batch_destroy(ambi_batch_t* b) {
-    static const bool quarantine_on = getenv("AMBI_DEBUG_QUARANTINE") != nullptr;
+    static const bool quarantine_on = ambi_env("AMBI_DEBUG_QUARANTINE") != nullptr;
     if (!quarantine_on || !b) { delete b; return; }
     check_quarantine();
     Backend* raw = b->be.release();

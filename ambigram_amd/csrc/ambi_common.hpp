@@ -14,6 +14,8 @@
 // `pytest -m "not gpu"` instantiates the very same source with a 1-thread group.
 #pragma once
 #include <stdint.h>
+#include <cstdlib>
+#include <cstring>
 
 #if defined(__HIPCC__)
 #define AMBI_HD __host__ __device__ inline
@@ -109,5 +111,18 @@ AMBI_HD int64_t stage_clock() {
 }
 template <class G>
 AMBI_HD void clk_mark(const G& g, int64_t* clk, int slot) { if (clk && g.tid() == 0) clk[slot] = stage_clock(); }
+
+
+// Environment switches of the engine (host code).  They are experiments and diagnostics, not a user interface: a switch that changes
+// WHICH kernels run or how they are launched is honoured only when AMBI_EXPERIMENTS=1 is set as well (the tests, profiles/tools and the A/B
+// scripts set it); without it the engine runs its measured defaults whatever else is in the environment.  Always honoured: the switches that
+// only print or record (AMBI_DEBUG*, AMBI_STAGE_PROFILE) and the memory budget of the order-table arena.
+inline const char* ambi_env(const char* name) {
+    static const bool experiments = [] { const char* e = std::getenv("AMBI_EXPERIMENTS"); return e && std::atoi(e) != 0; }();
+    if (experiments) return std::getenv(name);
+    static const char* const always[] = {"AMBI_DEBUG", "AMBI_DEBUG_SIZES", "AMBI_DEBUG_LATENCY", "AMBI_DEBUG_QUARANTINE", "AMBI_STAGE_PROFILE", "AMBI_ARENA_MAX_BYTES"};
+    for (const char* a : always) if (std::strcmp(a, name) == 0) return std::getenv(name);
+    return nullptr;
+}
 
 }  // namespace ambi

@@ -1048,7 +1048,7 @@ class DevicePool {
 };
 // a side stream of the lease: kind 0 lean finish / scan, 1 direct full finish, 2 scan ahead; prio 0 default, 1 lowest, 2 highest
 static int lease_stream(Lease* L, int kind, int prio, hipStream_t* out) {
-    static const bool shared = [] { const char* e = getenv("AMBI_SHARE_STREAMS"); return e && atoi(e) != 0; }();
+    static const bool shared = [] { const char* e = ambi_env("AMBI_SHARE_STREAMS"); return e && atoi(e) != 0; }();
     if (shared && L->device >= 0 && L->device < 16) {
         // experiment: one set of side streams per DEVICE, used by every lease (several resident batches then need no more hardware queues than one)
         static std::recursive_mutex mu; static Lease* holder[16] = {};
@@ -1110,7 +1110,7 @@ static int build_stream_classes(StreamClasses& C) {
         C.cls.push_back(c);
     }
     C.built = true;
-    if (getenv("AMBI_DEBUG")) { fprintf(stderr, "ambigram_hip: %zu dispatch classes among %zu candidate streams:", C.rep.size(), C.cand.size()); for (int c : C.cls) fprintf(stderr, " %d", c); fprintf(stderr, "\n"); }
+    if (ambi_env("AMBI_DEBUG")) { fprintf(stderr, "ambigram_hip: %zu dispatch classes among %zu candidate streams:", C.rep.size(), C.cand.size()); for (int c : C.cls) fprintf(stderr, " %d", c); fprintf(stderr, "\n"); }
     return 0;
 }
 // side streams for a batch whose kernels start on `caller`: out[k], k = 0 lean finish, 1 direct full finish, 2 scan / lattice -- from
@@ -1137,7 +1137,7 @@ static int classified_side_streams(int device, hipStream_t caller, int set, hipS
             }
         }
         C.callers.push_back({caller, mask});
-        if (getenv("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: caller's stream %p collides with the dispatch classes 0x%x (of %d)\n", (void*)caller, mask, nc);
+        if (ambi_env("AMBI_DEBUG")) fprintf(stderr, "ambigram_hip: caller's stream %p collides with the dispatch classes 0x%x (of %d)\n", (void*)caller, mask, nc);
     }
     int cc = -1;
     for (int c = 0; c < nc; c++) if ((mask >> c) & 1u) { cc = c; break; }
@@ -1434,7 +1434,7 @@ class HipBackend : public Backend {
         const HostBatch& H = hb();
         const size_t U = H.units.size();
         int rc;
-        debug_ = getenv("AMBI_DEBUG") != nullptr;
+        debug_ = ambi_env("AMBI_DEBUG") != nullptr;
         if ((rc = DevicePool::get().acquire(&lease_))) return rc;
         Lease* L = lease_;
         if (device_ != L->device) classed_for_ = (hipStream_t)-1;   // (another device: its own stream classes)
@@ -1444,8 +1444,8 @@ class HipBackend : public Backend {
         h_express_left_ = &L->h_words->express_left; dh_express_left_ = &L->dh_words->express_left;
         L->h_words->npending = 0; L->h_words->express_left = 1; L->h_words->late_flag = 0;
         ev_fork_ = L->ev_fork; ev_prep_ = L->ev_prep; ev_back_ = L->ev_back; ev_first_ = L->ev_first; ev_full_ = L->ev_full; ev_plan_ = L->ev_plan; ev_express_ = L->ev_express;
-        if (getenv("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
-        { const char* e9 = getenv("AMBI_ORDER_ALIGN"); order_align_ = e9 ? atoi(e9) : 4096; if (order_align_ < 16 || (order_align_ & (order_align_ - 1))) order_align_ = 4096; }
+        if (ambi_env("AMBI_STAGE_PROFILE")) { if ((rc = dalloc(&d_stage_clk_, U * kStageSlots))) return rc; HIP_CK(hipMemset(d_stage_clk_, 0, U * kStageSlots * sizeof(int64_t))); }
+        { const char* e9 = ambi_env("AMBI_ORDER_ALIGN"); order_align_ = e9 ? atoi(e9) : 4096; if (order_align_ < 16 || (order_align_ & (order_align_ - 1))) order_align_ = 4096; }
         // LDS budgets (dynamic shared memory), sized for the largest unit of the batch
         lds_prepare_ = (int)prepare_work_bytes(H.max_n, H.max_m, H.max_k);
         n_wide_ = H.n_wide;
@@ -1457,12 +1457,12 @@ class HipBackend : public Backend {
             finish_path_cells_ -= 2048;
         lds_finish_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, finish_path_cells_, H.max_out);
         lds_finish_lean_ = (int)finish_lean_work_bytes(H.max_n, H.max_m, H.max_bkp);
-        { const char* e = getenv("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
-        { const char* e = getenv("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
-        { const char* e = getenv("AMBI_LEAN_WAVE"); lean_wave_ = e ? atoi(e) : 0; }
+        { const char* e = ambi_env("AMBI_LEAN_FINISH"); lean_finish_ = e ? atoi(e) != 0 : true; }
+        { const char* e = ambi_env("AMBI_FINISH_GRID"); finish_grid_ = e ? atoi(e) : 0; if (finish_grid_ < 0) finish_grid_ = 0; }
+        { const char* e = ambi_env("AMBI_LEAN_WAVE"); lean_wave_ = e ? atoi(e) : 0; }
         // (measured, lean grid re-tuned for each: 128 threads 0.94-1.00, 256 threads 0.90 ms per step on one box)
-        { const char* e = getenv("AMBI_LEAN_THREADS"); lean_threads_ = e ? atoi(e) : 256; if (lean_threads_ != 128) lean_threads_ = 256; }
-        { const char* e = getenv("AMBI_LEAN_WAVE_GRID"); lean_wave_grid_ = e ? atoi(e) : 0; if (lean_wave_grid_ < 0) lean_wave_grid_ = 0; }
+        { const char* e = ambi_env("AMBI_LEAN_THREADS"); lean_threads_ = e ? atoi(e) : 256; if (lean_threads_ != 128) lean_threads_ = 256; }
+        { const char* e = ambi_env("AMBI_LEAN_WAVE_GRID"); lean_wave_grid_ = e ? atoi(e) : 0; if (lean_wave_grid_ < 0) lean_wave_grid_ = 0; }
         {   // the general enumerate kernel serves ordinary units only (wide ones have their own table kernel): its per-lane stacks are
             // sized by the largest ORDINARY unit -- with the wide units' node count they outgrew a CU's group memory at 255 nodes
             int mk = 1;
@@ -1470,13 +1470,13 @@ class HipBackend : public Backend {
             enum_stack_lds_ = (int)enum_stack_bytes(mk);
         }
         lds_enum_ = 4 * (enum_stack_lds_ + enum_auto_lds_);
-        { const char* env = getenv("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
-        { const char* env = getenv("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
+        { const char* env = ambi_env("AMBI_BLOCK_LDS"); block_lds_ = env ? atoi(env) : cfg.block_lds; if (block_lds_ < 64) block_lds_ = 64; block_lds_ = (block_lds_ + 15) & ~15; }
+        { const char* env = ambi_env("AMBI_BLOCK_MAX"); block_max_ = env ? atoi(env) : cfg.block_max; if (block_max_ < 1) block_max_ = 1; if (block_max_ > kBlockMaxLimit) block_max_ = kBlockMaxLimit; }
         lds_blocks_ = block_lds_;
         const int kLdsLimit = 160 * 1024 - 1024;
-        emit_lds_auto_ = !getenv("AMBI_BLOCK_LDS");
-        { const char* e = getenv("AMBI_EMIT_LDS_TIGHT"); emit_lds_tight_ = e ? atoi(e) != 0 : true; }
-        { const char* env = getenv("AMBI_BLOCK_SCRATCH_LDS"); block_scratch_lds_ = ((env ? atoi(env) : cfg.block_scratch_lds) + 15) & ~15; }
+        emit_lds_auto_ = !ambi_env("AMBI_BLOCK_LDS");
+        { const char* e = ambi_env("AMBI_EMIT_LDS_TIGHT"); emit_lds_tight_ = e ? atoi(e) != 0 : true; }
+        { const char* env = ambi_env("AMBI_BLOCK_SCRATCH_LDS"); block_scratch_lds_ = ((env ? atoi(env) : cfg.block_scratch_lds) + 15) & ~15; }
         if (block_scratch_lds_ > kLdsLimit) block_scratch_lds_ = kLdsLimit & ~15;
         lds_build_ = block_scratch_lds_;   // the image itself is assembled in HBM
         if (lds_prepare_ > kLdsLimit || lds_first_ > kLdsLimit || lds_finish_ > kLdsLimit || lds_enum_ > kLdsLimit || lds_blocks_ > kLdsLimit) {
@@ -1507,7 +1507,7 @@ class HipBackend : public Backend {
         // slices: env AMBI_SLICES or the configuration; 0 = automatic (4 when the batch is large enough to fill the
         // chip four times over, else 1)
         {
-            const char* env = getenv("AMBI_SLICES");
+            const char* env = ambi_env("AMBI_SLICES");
             int want = env ? atoi(env) : cfg.slices;
             // Measured on MI355X (profiles/r01_slices.md): the per-unit kernels already fill the issue slots of the chip,
             // so slicing brings nothing on this workload (2 slices: +3 %, 4 staggered slices: -17 %); default 1.
@@ -1524,46 +1524,46 @@ class HipBackend : public Backend {
             side_.assign(L->slice_streams.begin(), L->slice_streams.begin() + (n_slices_ - 1));
             ev_join_.assign(L->slice_events.begin(), L->slice_events.begin() + (n_slices_ - 1));
             ev_stage_.assign(L->slice_events.begin() + (n_slices_ - 1), L->slice_events.begin() + 2 * (n_slices_ - 1));
-            { const char* e2 = getenv("AMBI_STAGGER"); stagger_ = e2 ? atoi(e2) != 0 : true; }
-            { const char* e4 = getenv("AMBI_ENUM_THREADS"); enum_threads_ = e4 ? atoi(e4) : 256; if (enum_threads_ != 512 && enum_threads_ != 1024) enum_threads_ = 256; }
-            { const char* e3 = getenv("AMBI_ENUM_GRID"); enum_grid_ = e3 ? atoi(e3) : 16384; if (enum_grid_ < 1) enum_grid_ = 1; }   // >= work blocks: one block per workgroup, the rest exit (measured: 2048 -> 16384 workgroups = -8 % kernel time)
+            { const char* e2 = ambi_env("AMBI_STAGGER"); stagger_ = e2 ? atoi(e2) != 0 : true; }
+            { const char* e4 = ambi_env("AMBI_ENUM_THREADS"); enum_threads_ = e4 ? atoi(e4) : 256; if (enum_threads_ != 512 && enum_threads_ != 1024) enum_threads_ = 256; }
+            { const char* e3 = ambi_env("AMBI_ENUM_GRID"); enum_grid_ = e3 ? atoi(e3) : 16384; if (enum_grid_ < 1) enum_grid_ = 1; }   // >= work blocks: one block per workgroup, the rest exit (measured: 2048 -> 16384 workgroups = -8 % kernel time)
         }
-        { const char* e9 = getenv("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
-        { const char* e9 = getenv("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
-        { const char* e9 = getenv("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
-        { const char* e5 = getenv("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
+        { const char* e9 = ambi_env("AMBI_BUILD_IN_EMIT"); build_in_emit_ = e9 ? (atoi(e9) != 0) : 1; }
+        { const char* e9 = ambi_env("AMBI_BLOCK_DFS"); block_dfs_ = e9 ? (atoi(e9) != 0) : 1; }
+        { const char* e9 = ambi_env("AMBI_EMIT_INTERLEAVE"); emit_interleave_ = e9 ? (atoi(e9) != 0) : 1; }
+        { const char* e5 = ambi_env("AMBI_OVERLAP_BACK"); want_overlap_ = e5 ? atoi(e5) != 0 : true; }
         back_stream_ = nullptr; full_stream_ = nullptr; first_stream_ = nullptr; direct_n_ = 0; d_direct_cells_ = nullptr; direct_slots_ = 0;
         want_back_ = want_full_ = want_first_ = want_lattice_ = false;
-        { const char* e = getenv("AMBI_STREAM_CLASSES"); classed_ = e ? atoi(e) != 0 : true; }
+        { const char* e = ambi_env("AMBI_STREAM_CLASSES"); classed_ = e ? atoi(e) != 0 : true; }
         std::vector<int32_t> dl;
         if (want_overlap_ && n_slices_ == 1) {
             // the stream of the lean finish kernel: default dispatch priority (AMBI_BACK_PRIORITY=1: lowest, round 1's setting
             // -- with the scan out of the way early the finish kernels have the whole enumerate kernel to hide behind, and
             // holding them back only lengthens the tail after it: 1.185 -> 1.168 ms per step, four interleaved runs)
-            { const char* e8 = getenv("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : false;
+            { const char* e8 = ambi_env("AMBI_BACK_PRIORITY"); const bool low = e8 ? atoi(e8) != 0 : false;
               if ((rc = lease_stream(L, 0, low ? 1 : 0, &back_stream_))) return rc; want_back_ = !low; }
-            { const char* e = getenv("AMBI_FIRST_AHEAD"); first_ahead_ = e ? atoi(e) : 3; }
+            { const char* e = ambi_env("AMBI_FIRST_AHEAD"); first_ahead_ = e ? atoi(e) : 3; }
             // (direct full-stage launch: 512 threads with the path cells in device memory, 1024 with the cells in group memory --
             // measured, four interleaved runs: cells in group memory 1.151 ms per step; in device memory 256 / 512 / 1024
             // threads = 1.133 / 1.110 / 1.200)
-            { const char* ee = getenv("AMBI_DIRECT_EXT"); direct_ext_ = ee ? atoi(ee) != 0 : true; }
-            { const char* e = getenv("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : (direct_ext_ ? 512 : 1024); if (full_threads_ != 256 && full_threads_ != 512 && full_threads_ != 1024) full_threads_ = direct_ext_ ? 512 : 1024; }
+            { const char* ee = ambi_env("AMBI_DIRECT_EXT"); direct_ext_ = ee ? atoi(ee) != 0 : true; }
+            { const char* e = ambi_env("AMBI_FULL_THREADS"); full_threads_ = e ? atoi(e) : (direct_ext_ ? 512 : 1024); if (full_threads_ != 256 && full_threads_ != 512 && full_threads_ != 1024) full_threads_ = direct_ext_ ? 512 : 1024; }
             if (first_ahead_ >= 2) { if ((rc = lease_stream(L, 2, 2, &first_stream_))) return rc; want_first_ = true; }
             {   // units that go straight to the full finish stage (env AMBI_DIRECT_FULL=0: none, they pass through the lean stage first)
-                const char* e7 = getenv("AMBI_DIRECT_FULL"); const bool on = e7 ? atoi(e7) != 0 : true;
-                const char* e8 = getenv("AMBI_DIRECT_GRID"); direct_grid_ = e8 ? atoi(e8) : 1024; if (direct_grid_ < 1) direct_grid_ = 1;   // one workgroup per unit up to 1024 (measured: 64 / 128 / 256 / 512 workgroups for 512 units = 1.63 / 1.37 / 1.25 / 1.23 ms per step; without this launch 1.30)
+                const char* e7 = ambi_env("AMBI_DIRECT_FULL"); const bool on = e7 ? atoi(e7) != 0 : true;
+                const char* e8 = ambi_env("AMBI_DIRECT_GRID"); direct_grid_ = e8 ? atoi(e8) : 1024; if (direct_grid_ < 1) direct_grid_ = 1;   // one workgroup per unit up to 1024 (measured: 64 / 128 / 256 / 512 workgroups for 512 units = 1.63 / 1.37 / 1.25 / 1.23 ms per step; without this launch 1.30)
                 if (on && lean_finish_) for (size_t u2 = 0; u2 < U; u2++) if (H.units[u2].direct_full) dl.push_back((int32_t)u2);
                 direct_n_ = (int)dl.size();
                 if (direct_n_ > 0) {
                     // the direct full-finish stream: default priority, or the lowest (AMBI_FULL_PRIORITY=1: a few per cent on some
                     // boxes).  The stream belongs to the lease and is never destroyed -- with round 2's per-batch create / destroy of
                     // this priority stream a long soak showed stray writes into host memory.
-                    const char* e9 = getenv("AMBI_FULL_PRIORITY"); const int fp = e9 ? atoi(e9) : 0;   // 0 default, 1 lowest, 2 highest priority
+                    const char* e9 = ambi_env("AMBI_FULL_PRIORITY"); const int fp = e9 ? atoi(e9) : 0;   // 0 default, 1 lowest, 2 highest priority
                     if ((rc = lease_stream(L, 1, fp == 1 ? 1 : (fp == 2 ? 2 : 0), &full_stream_))) return rc;
                     want_full_ = fp == 0;
                     if (direct_ext_) lds_finish_ext_ = (int)finish_work_bytes(H.max_n, H.max_m, H.max_bkp, 0, H.max_out);
-                    { const char* ed = getenv("AMBI_DIRECT_EDIT"); direct_edit_ = (ed ? atoi(ed) != 0 : true) && direct_ext_; }
-                    { const char* eg = getenv("AMBI_EDIT_GRID"); edit_grid_ = eg ? atoi(eg) : 1024; if (edit_grid_ < 1) edit_grid_ = 1; }
+                    { const char* ed = ambi_env("AMBI_DIRECT_EDIT"); direct_edit_ = (ed ? atoi(ed) != 0 : true) && direct_ext_; }
+                    { const char* eg = ambi_env("AMBI_EDIT_GRID"); edit_grid_ = eg ? atoi(eg) : 1024; if (edit_grid_ < 1) edit_grid_ = 1; }
                     lds_finish_edit_ = (int)finish_edit_work_bytes(H.max_n, H.max_m, H.max_bkp);
                     if (lds_finish_edit_ > kLdsLimit) direct_edit_ = false;
                 }
@@ -1571,15 +1571,15 @@ class HipBackend : public Backend {
             // AMBI_ENUM_LDS_FLOOR (experiments): make the enumerate kernel ask for more LDS than its image needs, i.e. fewer
             // of its workgroups per CU.  Measured (profiles/r01_slices.md): no floor is best -- the scan / finish
             // workgroups slip in as enumerate workgroups retire.
-            { const char* e6 = getenv("AMBI_ENUM_LDS_FLOOR"); const int floor_lds = e6 ? atoi(e6) : 0; if (lds_blocks_ < floor_lds && floor_lds <= kLdsLimit) lds_blocks_ = floor_lds; }
+            { const char* e6 = ambi_env("AMBI_ENUM_LDS_FLOOR"); const int floor_lds = e6 ? atoi(e6) : 0; if (lds_blocks_ < floor_lds && floor_lds <= kLdsLimit) lds_blocks_ = floor_lds; }
         }
         {   // express path: small batches only, and only if a unit's whole working set fits one workgroup's group memory
-            const char* e9 = getenv("AMBI_EXPRESS_UNITS"); express_units_ = e9 ? atoi(e9) : 32;
-            { const char* et = getenv("AMBI_EXPRESS_THREADS"); express_threads_ = et ? atoi(et) : 512; if (express_threads_ != 256 && express_threads_ != 1024) express_threads_ = 512; }   // (measured, one 256-segment sample: 256 / 512 / 1024 threads = 79.7 / 76.8 / 79.2 us run -> results)
+            const char* e9 = ambi_env("AMBI_EXPRESS_UNITS"); express_units_ = e9 ? atoi(e9) : 32;
+            { const char* et = ambi_env("AMBI_EXPRESS_THREADS"); express_threads_ = et ? atoi(et) : 512; if (express_threads_ != 256 && express_threads_ != 1024) express_threads_ = 512; }   // (measured, one 256-segment sample: 256 / 512 / 1024 threads = 79.7 / 76.8 / 79.2 us run -> results)
             lds_express_ = (int)express_work_bytes(H.max_n, H.max_m, H.max_k, H.max_bkp, finish_path_cells_, H.max_out) + 64;
             lds_lattice_ = (int)(64 * 8 + kPrepLatticeBytes + 64);
             lds_lattice_own_ = (int)lattice_own_bytes(H.max_k) + 64;
-            const char* e8 = getenv("AMBI_SIDE_LATTICE");
+            const char* e8 = ambi_env("AMBI_SIDE_LATTICE");
             side_lattice_ = (e8 ? atoi(e8) != 0 : true) && (int)U <= express_units_ && n_slices_ == 1;
             if (side_lattice_ && (rc = lease_stream(L, 2, 0, &lattice_stream_))) return rc;
             want_lattice_ = side_lattice_;
@@ -1604,7 +1604,7 @@ class HipBackend : public Backend {
             d_direct_cells_ = L->d_cells;
         }
         arena_bytes_ = cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : (int64_t)1 << 20;
-        { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); const bool capped = cap && atoll(cap) > 0;
+        { const char* cap = ambi_env("AMBI_ARENA_MAX_BYTES"); const bool capped = cap && atoll(cap) > 0;
           // a configured size or a memory budget is taken literally; otherwise whatever the lease already holds is used
           if (cfg.order_arena_bytes <= 0 && !capped && L->d_arena_bytes > arena_bytes_) arena_bytes_ = L->d_arena_bytes;
           if (capped && arena_bytes_ > atoll(cap)) arena_bytes_ = atoll(cap); }
@@ -1649,7 +1649,7 @@ class HipBackend : public Backend {
     int flush_upload(hipStream_t st) {
         if (!upload_pending_) return 0;
         Lease* L = lease_;
-        if (in_bytes_ + zero_bytes_ <= (8ll << 20) && L->dh_stage && !getenv("AMBI_NO_INGEST")) {   // (every part of the block is 256-byte aligned)
+        if (in_bytes_ + zero_bytes_ <= (8ll << 20) && L->dh_stage && !ambi_env("AMBI_NO_INGEST")) {   // (every part of the block is 256-byte aligned)
             const int64_t n16 = in_bytes_ / 16, z16 = zero_bytes_ / 16;
             int64_t blocks = (std::max(n16, z16) + 255) / 256;
             if (blocks > 1024) blocks = 1024;
@@ -1680,7 +1680,7 @@ class HipBackend : public Backend {
         A_.scratch_i32 = d_scratch_; A_.scratch_off = d_scratch_off_; A_.stage_clk = d_stage_clk_;
         A_.zero_pending = 0; A_.host_pending = nullptr; A_.host_needed = nullptr; A_.blocks_done = d_blocks_done_;
         A_.inject_valid = d_inject_; A_.inject_off = d_inject_off_; A_.refin_list = d_refin_list_; A_.refin_count = d_refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
-        { const char* ec = getenv("AMBI_EDIT_RUN_CAP"); A_.edit_cap_limit = ec ? atoi(ec) : 0; }
+        { const char* ec = ambi_env("AMBI_EDIT_RUN_CAP"); A_.edit_cap_limit = ec ? atoi(ec) : 0; }
         A_.wide = n_wide_ > 0 ? d_wide_ : nullptr; A_.wide_index = n_wide_ > 0 ? d_wide_index_ : nullptr;
         A_.mail = mail_on_ ? lease_->dh_mail : nullptr; A_.mail_off = d_mail_off_;
         {   // the finish stages leave the final paths in run-length form in the block of this run's parity (the other one may still be on its way to the host)
@@ -1690,7 +1690,7 @@ class HipBackend : public Backend {
         }
         A_.lat_R = d_lat_R_; A_.lat_status = d_lat_status_; A_.lat_sum = d_lat_sum_; A_.lat_seq = &lease_->dh_words->lat_seq; A_.lat_unsure = &lease_->dh_words->lat_unsure;
         A_.plan_seq = &lease_->dh_words->plan_seq; A_.late_flag = &lease_->dh_words->late_flag; A_.run_seq = run_seq_;
-        A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = getenv("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
+        A_.all_bits = d_all_bits_; A_.all_off = d_all_off_; A_.all_count = d_all_count_; A_.all_flags = d_all_flags_; A_.all_rank = all_rank_; A_.all_world = all_world_; { const char* e = ambi_env("AMBI_ALL_TABLE"); A_.all_rows_from_table = (e && atoi(e) != 0) ? 1 : 0; }
     }
     BatchArgs slice_args(int s) const {
         BatchArgs A = A_;
@@ -1772,7 +1772,7 @@ class HipBackend : public Backend {
             // beside the plan kernel (one workgroup, 25 us during which the chip is otherwise idle) and the ramp of the
             // enumerate kernel, instead of queueing behind 4096 enumerate workgroups for group memory.
             first_launched_ = false;
-            static const bool one_event = [] { const char* e = getenv("AMBI_ONE_FRONT_EVENT"); return e && atoi(e) != 0; }();   // experiment: see below
+            static const bool one_event = [] { const char* e = ambi_env("AMBI_ONE_FRONT_EVENT"); return e && atoi(e) != 0; }();   // experiment: see below
             if (overlap_back_ && first_ahead_ == 3 && !(one_event && !lazy_)) {
                 (void)hipEventRecord(ev_prep_, st);
                 hipStream_t sf = first_stream_ ? first_stream_ : back_stream_;
@@ -1792,7 +1792,7 @@ class HipBackend : public Backend {
         // (express chain: the lattice kernel reads the status, so the scan of the units the express kernel left stays behind
         // the plan kernel there)
         {
-            static const bool one_event = [] { const char* e = getenv("AMBI_ONE_FRONT_EVENT"); return e && atoi(e) != 0; }();
+            static const bool one_event = [] { const char* e = ambi_env("AMBI_ONE_FRONT_EVENT"); return e && atoi(e) != 0; }();
             if (one_event && !express_ && !lazy_ && overlap_back_ && first_ahead_ == 3) {
                 // experiment: ONE event on the caller's stream between prepare and the order-table kernel (behind the plan kernel) instead
                 // of one on either side of the plan kernel; the scan then starts behind the plan kernel
@@ -1964,7 +1964,7 @@ class HipBackend : public Backend {
         if (classed_ && (want_back_ || want_full_ || want_first_ || want_lattice_)) {
             // side streams that dispatch beside THIS caller's stream (learnt once per stream and device: a few probe launches; a
             // stream seen before costs a look-up)
-            static const bool first_prio = [] { const char* e = getenv("AMBI_FIRST_PRIORITY"); return e && atoi(e) != 0; }();
+            static const bool first_prio = [] { const char* e = ambi_env("AMBI_FIRST_PRIORITY"); return e && atoi(e) != 0; }();
             if (stream_ != classed_for_) {
                 hipStream_t sd[3] = {nullptr, nullptr, nullptr};
                 const int rc = classified_side_streams(device_, stream_, (int)(lease_->uses & 1), sd);
@@ -1974,7 +1974,7 @@ class HipBackend : public Backend {
             }
             if (want_back_ && classed_streams_[0]) back_stream_ = classed_streams_[0];
             if (want_full_ && classed_streams_[1]) full_stream_ = classed_streams_[1];
-            static const bool first_on_back = [] { const char* e = getenv("AMBI_FIRST_ON_BACK"); return e && atoi(e) != 0; }();   // experiment: the scan on the lean finish kernel's stream (no event between the two)
+            static const bool first_on_back = [] { const char* e = ambi_env("AMBI_FIRST_ON_BACK"); return e && atoi(e) != 0; }();   // experiment: the scan on the lean finish kernel's stream (no event between the two)
             if (want_first_ && !first_prio && classed_streams_[2]) first_stream_ = first_on_back ? classed_streams_[0] : classed_streams_[2];
             if (want_lattice_ && classed_streams_[2]) lattice_stream_ = classed_streams_[2];
         }
@@ -2048,7 +2048,7 @@ class HipBackend : public Backend {
     // AMBI_ARENA_MAX_BYTES: an upper limit for the arena (a memory budget; the tests use it to reach this path).  Every stream idle.
     bool grow_arena(int64_t total) {
         int64_t want = total;
-        { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }
+        { const char* cap = ambi_env("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }
         bool grown = false;
         uint8_t* fresh = nullptr;
         want = (want + 4095) & ~int64_t(4095);
@@ -2132,7 +2132,7 @@ class HipBackend : public Backend {
                 // units needed in this first run plus a quarter (53 KB there, three per CU; longer paths then go through the
                 // list kernel) -- measured SLOWER, 1.18 vs 1.155 ms per step: more of these 16-wave workgroups get onto the
                 // CUs while the table is being written and take the places of enumerate workgroups.
-                const char* e = getenv("AMBI_DIRECT_CELLS");
+                const char* e = ambi_env("AMBI_DIRECT_CELLS");
                 direct_cells_ = e ? atoi(e) : 0;
                 if (direct_cells_ < 0) {
                     std::vector<UnitOut> hdr(hb().units.size());
@@ -2322,7 +2322,7 @@ class HipBackend : public Backend {
     int wait_results() override {
         DeviceGuard dg_(device_);
         if (!ran_) return 0;
-        static const bool lat = getenv("AMBI_DEBUG_LATENCY") != nullptr;   // diagnostics: when the two pinned words arrived, from the start of run()
+        static const bool lat = ambi_env("AMBI_DEBUG_LATENCY") != nullptr;   // diagnostics: when the two pinned words arrived, from the start of run()
         auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run_).count(); };
         if (express_ && !(A_.flags & FLAG_ALL) && ev_express_ && !late_refusal_ && (!lazy_ || arena_checked_)) {
             // the kernel's last workgroup stores the run's sequence number into pinned host memory: a short spin on it
@@ -2456,7 +2456,7 @@ class HipBackend : public Backend {
     int runs_to_host(int which, int slot, int with_headers, void* stream) override {
         DeviceGuard dg_(device_);
         if (!ran_ || slot < 0 || slot > 1) return ST_ERR_BAD_INPUT;
-        static const bool no_direct = getenv("AMBI_RUNS_PACK") != nullptr;   // env AMBI_RUNS_PACK=1: always through the pack kernels
+        static const bool no_direct = ambi_env("AMBI_RUNS_PACK") != nullptr;   // env AMBI_RUNS_PACK=1: always through the pack kernels
         if (which == 1 && run_total_ > 0 && runs_parity_ >= 0 && !no_direct) {
             Lease* L = lease_;
             const int64_t U = (int64_t)hb().units.size();
@@ -2610,7 +2610,7 @@ class HipBackend : public Backend {
             if (timing_) { HIP_CK(hipEventCreate(&ea)); HIP_CK(hipEventCreate(&eb)); HIP_CK(hipEventRecord(ea, stream_)); }
             // units with a short breakpoint path (the rule): one thread per order; the others: one wavefront per order
             int lane_cap = 0, lanes_units = 0, wave_units = 0;
-            { const char* e = getenv("AMBI_ALL_LANES"); lane_cap = (e && atoi(e) == 0) ? 0 : kAllLaneMaxCells; }
+            { const char* e = ambi_env("AMBI_ALL_LANES"); lane_cap = (e && atoi(e) == 0) ? 0 : kAllLaneMaxCells; }
             auto lane_unit = [&](int u) { return hb().units[u].bkp_cap <= lane_cap && hb().units[u].n_elem <= kMaxNodes; };
             for (int u = 0; u < U; u++) if (all_off_[u + 1] > all_off_[u]) { if (lane_unit(u)) lanes_units++; else wave_units++; }
             int max_lane_cells = 8;
@@ -2620,13 +2620,13 @@ class HipBackend : public Backend {
             // Measured (4096 bench units): 0 / 4096 / 8192 bytes = 561 / 489 / 390 M orders/s -- the kernel lives on the number
             // of resident wavefronts (group-memory latency), and every KB of group memory costs some.
             int auto_bytes = 0;
-            { const char* e = getenv("AMBI_ALL_AUTO_LDS"); if (e) auto_bytes = atoi(e) & ~15; if (auto_bytes < 0) auto_bytes = 0; }
+            { const char* e = ambi_env("AMBI_ALL_AUTO_LDS"); if (e) auto_bytes = atoi(e) & ~15; if (auto_bytes < 0) auto_bytes = 0; }
             int max_k_lane = 1;
             for (const UnitIn& un : hb().units) if (un.n_elem <= kMaxNodes && un.n_elem > max_k_lane) max_k_lane = un.n_elem;   // (wide units: ambi_all_kernel)
             const int rows_bytes = 64 * ((max_k_lane + 3) & ~3);   // transposed orders: one 64-lane row per position
             const int lane_wave_lds = (head_bytes + rows_bytes + max_lane_cells * 64 * (int)sizeof(cell_t) + auto_bytes + 15) & ~15;
             int lane_waves = 1;   // wavefronts per workgroup (measured 1 / 2 / 4 = 563 / 553 / 379 M orders/s: group-memory allocation granularity)
-            { const char* e = getenv("AMBI_ALL_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 4) lane_waves = atoi(e); }
+            { const char* e = ambi_env("AMBI_ALL_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 4) lane_waves = atoi(e); }
             int64_t lblk = (chunks + lane_waves - 1) / lane_waves;
             if (lblk > (1 << 20)) lblk = 1 << 20;
             for (int pass = 0; pass < 2; pass++) {

@@ -90,7 +90,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.slices > 0:
-        os.environ["AMBI_SLICES"] = str(args.slices)
+        os.environ["AMBI_SLICES"] = str(args.slices); os.environ["AMBI_EXPERIMENTS"] = "1"   # (an experiment switch: honoured only with the second one set)
     # the HIP engine; raises if it has not been built (no CPU fallback).  AMBI_BENCH_LIB: another BUILD of the same engine
     # library (profiles/tools/ab.sh compares two builds on one box with it)
     lib = api.load(os.environ.get("AMBI_BENCH_LIB") or None)

@@ -2,6 +2,7 @@
 # A/B runs of bench.py on ONE box (boxes of the pool differ by several per cent, so only runs of one call compare):
 #   bash profiles/tools/ab.sh <reps> "ENV1=.. ENV2=.." "ENV.." ...
 # prints reconstructions/s, ms per step and the enumerate / finish kernel times of every configuration, interleaved.
+export AMBI_EXPERIMENTS=1   # the engine honours its AMBI_* switches only with this
 reps=$1; shift
 for r in $(seq 1 $reps); do
   i=0

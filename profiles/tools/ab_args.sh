@@ -1,5 +1,6 @@
 #!/bin/bash
 # like ab.sh, with extra bench.py arguments:  bash profiles/tools/ab_args.sh <reps> "<bench args>" "ENV.." "ENV.." ...
+export AMBI_EXPERIMENTS=1   # the engine honours its AMBI_* switches only with this
 reps=$1; shift; args=$1; shift
 for r in $(seq 1 $reps); do
   i=0

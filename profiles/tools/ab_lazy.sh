@@ -1,5 +1,6 @@
 #!/bin/bash
 # like ab.sh, printing also the step without order tables (AMBI_FLAG_LAZY_ORDERS) and the scan kernel's time
+export AMBI_EXPERIMENTS=1   # the engine honours its AMBI_* switches only with this
 reps=$1; shift
 for r in $(seq 1 $reps); do
   i=0

@@ -1,5 +1,6 @@
 #!/bin/bash
 # like ab.sh, for the two-resident-batches leg: prints plain and pipelined ms per step of every configuration, interleaved
+export AMBI_EXPERIMENTS=1   # the engine honours its AMBI_* switches only with this
 reps=$1; shift
 for r in $(seq 1 $reps); do
   i=0

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the --all leg of bench.py on ONE box:  bash profiles/tools/all_ab.sh "ENV=.." "ENV=.." ...
+export AMBI_EXPERIMENTS=1   # the engine honours its AMBI_* switches only with this
 for r in 1 2; do
 for cfg in "$@"; do
 env $cfg timeout -k 10 300 python3 bench.py --cpu-seconds 0 --single-reps 0 --pipelined 0 --steps 3 --all-steps 2 > gpurun_out/allb.log 2>&1

@@ -4,6 +4,7 @@
 # Every pass is its own rocprofv3 run (counters never share a run with traces other than --kernel-trace); the rocpd
 # databases go to gpurun_out/prof_<tag>/, the summaries (CSV / JSON) to gpurun_out/profiles_<tag>/ for copying into
 # profiles/.
+export AMBI_EXPERIMENTS=1   # the engine honours its AMBI_* switches only with this
 set -eo pipefail
 TAG=${1:-r04}
 ROOT=$(pwd)

@@ -2,6 +2,7 @@
 """Where the end-to-end latency of ONE sample goes (packed unit on the host -> final path on the host): per-call host times of
 upload / run / fetch_paths / unit_path, and (AMBI_DEBUG_LATENCY=1) when the express and plan words arrived."""
 import os, sys, time, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -2,6 +2,7 @@
 """Shader-clock marks inside the full finish stage for units that carry path-editing SVs (run with AMBI_STAGE_PROFILE=1):
 python3 profiles/tools/finish_profile.py [units]  -- marks 17..21 are cycles from the stage's first mark (16)."""
 import os, sys, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The ILP fill kernel alone (one 256-segment model, 56.5 M non-zeros), for rocprofv3 passes:  python3 profiles/tools/ilp_fill_probe.py [reps]"""
 import os, sys, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from ambigram_amd import api, synth

@@ -3,6 +3,7 @@
 Each library runs the bench batch (4096 units, K = 19) in its own child process, interleaved; prints ms per step and the
 enumerate kernel's event time."""
 import os, subprocess, sys
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import os, sys, tempfile, time

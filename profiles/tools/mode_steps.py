@@ -4,6 +4,7 @@
 the last argument: which stream the batch runs on -- torch's current (legacy default) stream, a torch stream of the caller's own created
 after / before the engine has created its side streams, and the same with a one-rank RCCL group initialised first."""
 import os, sys, tempfile, time
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -4,6 +4,7 @@ wrapped as a torch tensor through the CUDA array interface and goes through dist
     python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 profiles/tools/rccl_one_rank_all.py
 """
 import os, sys, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch

@@ -2,6 +2,7 @@
 """Single-sample latencies of bench.py's `single_sample` leg alone (no 4096-batch): inputs resident (run -> wait_results), with the
 order table (run -> wait), end to end (upload -> run -> fetch_paths -> unit_path)."""
 import os, sys, time, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

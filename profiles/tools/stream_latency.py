@@ -1,4 +1,5 @@
 import os, sys, time, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 sys.path.insert(0, "/root/repo")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch

@@ -1,6 +1,7 @@
 """Does the order in which the host application creates streams change the step?  4096-sample bench batch on the default stream or on a stream
 of the caller's own, with N torch streams created BEFORE the engine's side streams:  python3 queue_probe_check.py default|own N"""
 import os, sys, time, tempfile
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 sys.path.insert(0, "/root/repo")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch

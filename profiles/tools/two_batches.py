@@ -2,6 +2,7 @@
 """Experiment: two resident batches on two HIP streams, steps alternating between them (double buffering), against one
 batch on one stream.  python3 profiles/tools/two_batches.py [batch] [steps]"""
 import os, sys, tempfile, time
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# the engine honours its experiment / diagnostic switches (AMBI_*) only with this set (csrc/ambi_common.hpp: ambi_env); the tests use several
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

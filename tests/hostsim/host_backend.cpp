@@ -56,7 +56,7 @@ class HostSimBackend : public Backend {
         rows_per_lane_.assign(U, 1); blk_off_.assign(U + 1, 0);
         scratch_.assign((size_t)hb.scratch_ints + 8, 0);
         // env AMBI_HOSTSIM_TABLE_SCAN=1: the scan for the first valid order reads the order table (the other supported source)
-        if (!getenv("AMBI_HOSTSIM_TABLE_SCAN")) first_rows_.assign(U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride, 0);
+        if (!ambi_env("AMBI_HOSTSIM_TABLE_SCAN")) first_rows_.assign(U * (size_t)(cfg.first_budget > 0 ? cfg.first_budget : 1) * kFirstRowStride, 0);
         else first_rows_.clear();
         arena_.assign((size_t)(cfg.order_arena_bytes > 0 ? cfg.order_arena_bytes : 0), 0);
         wide_.assign((size_t)hb.n_wide, WideUnit{});
@@ -67,7 +67,7 @@ class HostSimBackend : public Backend {
     void bind(uint32_t flags) {
         A_.n_units = (int32_t)units_.size(); A_.unit_base = 0; A_.arena_base = 0;   // one slice
         A_.flags = flags; A_.order_align = 4096 /* as HipBackend's default */; A_.first_budget = cfg_.first_budget; A_.target_lanes = cfg_.target_lanes;
-        { const char* envm = getenv("AMBI_BLOCK_MAX"); int bm = envm ? atoi(envm) : cfg_.block_max;   // as HipBackend::upload
+        { const char* envm = ambi_env("AMBI_BLOCK_MAX"); int bm = envm ? atoi(envm) : cfg_.block_max;   // as HipBackend::upload
           if (bm < 1) bm = 1; if (bm > kBlockMaxLimit) bm = kBlockMaxLimit; A_.block_max = bm; }
         A_.ideal_pos = ipos_.data(); A_.auto_avail = aavail_.data(); A_.auto_cnt = acnt_.data();
         A_.auto_cbase = acbase_.data(); A_.auto_child = achild_.data(); A_.auto_nblk = anblk_.data(); A_.auto_depth = adepth_.data();
@@ -82,7 +82,7 @@ class HostSimBackend : public Backend {
         A_.scratch_i32 = scratch_.data(); A_.scratch_off = hb_.scratch_off.data(); A_.stage_clk = nullptr;
         refin_list_.assign(units_.size() + 1, 0); refin_count_ = 0;
         A_.refin_list = refin_list_.data(); A_.refin_count = &refin_count_; A_.direct_full_on = 0; A_.finish_retry = 0;
-        { const char* ec = getenv("AMBI_EDIT_RUN_CAP"); A_.edit_cap_limit = ec ? atoi(ec) : 0; }
+        { const char* ec = ambi_env("AMBI_EDIT_RUN_CAP"); A_.edit_cap_limit = ec ? atoi(ec) : 0; }
         A_.wide = wide_.empty() ? nullptr : wide_.data(); A_.wide_index = wide_.empty() ? nullptr : hb_.wide_index.data();
         A_.inject_valid = hb_.inject.empty() ? nullptr : hb_.inject.data();
         A_.inject_off = hb_.inject.empty() ? nullptr : hb_.inject_off.data();
@@ -97,7 +97,7 @@ class HostSimBackend : public Backend {
         HostGroup g;
         const int64_t total = blk_off_[units_.size()];
         std::vector<uint8_t> stacks((size_t)enum_stack_bytes(64));
-        const char* env = getenv("AMBI_BLOCK_LDS");
+        const char* env = ambi_env("AMBI_BLOCK_LDS");
         const int64_t block_lds = env ? atoll(env) : cfg_.block_lds;
         const int block_max = A_.block_max;
         std::vector<uint8_t> image((size_t)(block_lds > 64 ? block_lds : 64));
@@ -139,7 +139,7 @@ class HostSimBackend : public Backend {
                 fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, block_max, bscratch.data(), (int64_t)bscratch.size(),
                                          image.data(), block_lds, H);
                 dfs = false;
-                if (getenv("AMBI_HOSTSIM_TRACE")) { BuildTables d2; fprintf(stderr, "hostsim: unit %d K=%d R=%lld nI=%d nC=%d nB=%d suf_words=%d image_bytes=%d scratch=%lld\n", u, K, (long long)R, H.nI, H.nC, H.nB, H.suf_words, H.image_bytes, (long long)carve_build_tables(bscratch.data(), H.nI, H.nC, d2)); }
+                if (ambi_env("AMBI_HOSTSIM_TRACE")) { BuildTables d2; fprintf(stderr, "hostsim: unit %d K=%d R=%lld nI=%d nC=%d nB=%d suf_words=%d image_bytes=%d scratch=%lld\n", u, K, (long long)R, H.nI, H.nC, H.nB, H.suf_words, H.image_bytes, (long long)carve_build_tables(bscratch.data(), H.nI, H.nC, d2)); }
                 if (!fast) {   // ambi_blocks_build_kernel's second form: tables + suffix rows, walked at emission
                     BuildTables dummy;
                     const int64_t scr = carve_build_tables(bscratch.data(), tbl.counter[0], tbl.counter[1], dummy);
@@ -148,7 +148,7 @@ class HostSimBackend : public Backend {
                         fast = build_block_image(g, tbl, K, row_stride(K) / 4, R, bm, bscratch.data(), (int64_t)bscratch.size(),
                                                  image.data(), budget, H, nullptr, false);
                     if (fast) { dfs = true; (void)carve_build_tables(bscratch.data(), tbl.counter[0], tbl.counter[1], Bt); }
-                    if (getenv("AMBI_HOSTSIM_TRACE")) fprintf(stderr, "hostsim: unit %d (K=%d, R=%lld): %s\n", u, K, (long long)R, fast ? "directory-free block walk" : "general path");
+                    if (ambi_env("AMBI_HOSTSIM_TRACE")) fprintf(stderr, "hostsim: unit %d (K=%d, R=%lld): %s\n", u, K, (long long)R, fast ? "directory-free block walk" : "general path");
                 }
                 built_unit = u;
             }
@@ -176,7 +176,7 @@ class HostSimBackend : public Backend {
     // chunk always reports before an early one) or "shuffle" -- which is what concurrency on the GPU amounts to.
     void search_pending() {
         HostGroup g;
-        const char* ord = getenv("AMBI_HOSTSIM_SEARCH_ORDER");
+        const char* ord = ambi_env("AMBI_HOSTSIM_SEARCH_ORDER");
         const int mode = !ord ? 0 : (!strcmp(ord, "desc") ? 1 : (!strcmp(ord, "shuffle") ? 2 : 0));
         const int chunk = 16;
         for (size_t u = 0; u < units_.size(); u++) {
@@ -213,7 +213,7 @@ class HostSimBackend : public Backend {
         const int Un = (int)units_.size();
         // small batches: the express stage (whole reconstruction of units whose first order assembles) in front, the lattice
         // stage behind it, as the HIP backend launches them (env AMBI_EXPRESS_UNITS, default 32; 0 = never)
-        const char* ex = getenv("AMBI_EXPRESS_UNITS");
+        const char* ex = ambi_env("AMBI_EXPRESS_UNITS");
         const int express_units = ex ? atoi(ex) : 32;
         const bool express = Un <= express_units && hb_.n_wide == 0;   // (as HipBackend::run)
         if (express)
@@ -235,7 +235,7 @@ class HostSimBackend : public Backend {
             plan_serial(A_);
             if (orders_needed_ <= (int64_t)arena_.size()) break;
             int64_t want = orders_needed_;
-            { const char* cap = getenv("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }   // as HipBackend::run
+            { const char* cap = ambi_env("AMBI_ARENA_MAX_BYTES"); if (cap && atoll(cap) > 0 && want > atoll(cap)) want = atoll(cap); }   // as HipBackend::run
             if (want <= (int64_t)arena_.size()) break;   // cannot grow further: the units beyond it end with ORDERS_CAPACITY
             arena_.assign((size_t)want, 0);              // grow the arena and redo (first run only)
             bind(flags);
@@ -252,7 +252,7 @@ class HostSimBackend : public Backend {
         }
         if (n_pending_ > 0) search_pending();
         // lean finish stage first, the full one for the units it hands over (AMBI_HOSTSIM_LEAN_FINISH=0: full stage only)
-        const char* lf = getenv("AMBI_HOSTSIM_LEAN_FINISH");
+        const char* lf = ambi_env("AMBI_HOSTSIM_LEAN_FINISH");
         const bool lean = lf ? atoi(lf) != 0 : true;
         for (int u = 0; u < Un && lean; u++) {
             const UnitIn& U = units_[u];
@@ -265,13 +265,13 @@ class HostSimBackend : public Backend {
             if (lean && unit_out(A_.results, u)->status != ST_REFINISH) continue;
             // units with deletion / duplication candidates: the form with the path cells outside the work area (what the HIP
             // backend's direct full-stage launch runs), in buffers of exactly its sizes; AMBI_HOSTSIM_EXT_PATH=0: the ordinary form
-            const char* ep = getenv("AMBI_HOSTSIM_EXT_PATH");
-            const char* ed = getenv("AMBI_HOSTSIM_EDIT");
+            const char* ep = ambi_env("AMBI_HOSTSIM_EXT_PATH");
+            const char* ed = ambi_env("AMBI_HOSTSIM_EDIT");
             if (U.direct_full && !(ed && atoi(ed) == 0)) {   // what the HIP backend's direct launch runs first: the edits on the runs of the path
                 std::vector<uint8_t> work((size_t)finish_edit_work_bytes(U.n_seg, U.n_junc, U.bkp_cap));
                 stage_finish_edit(g, A_, u, work.data());
                 const bool handed_on = unit_out(A_.results, u)->status == ST_REFINISH;
-                if (getenv("AMBI_HOSTSIM_DEBUG")) fprintf(stderr, "hostsim: unit %d through the edit stage: %s\n", u, handed_on ? "handed on" : "done");
+                if (ambi_env("AMBI_HOSTSIM_DEBUG")) fprintf(stderr, "hostsim: unit %d through the edit stage: %s\n", u, handed_on ? "handed on" : "done");
 #if defined(AMBI_EDIT_TRACE_ON)
                 fprintf(stderr, "edit counts unit %d: table builds %ld sweeps %ld chain scans %ld (runs %d)\n", u, g_edit_count[0], g_edit_count[1], g_edit_count[2], 0); g_edit_count[0] = g_edit_count[1] = g_edit_count[2] = 0;
 #endif
@@ -327,7 +327,7 @@ class HostSimBackend : public Backend {
                 FirstWork W = carve_first(work.data(), U.n_seg, U.bkp_cap, wide);
                 load_first_work(g, A_, u, W);
                 // as the HIP backend: one thread per order for units with a short breakpoint path, the wavefront form otherwise
-                const char* el = getenv("AMBI_ALL_LANES");
+                const char* el = ambi_env("AMBI_ALL_LANES");
                 const bool lanes = !(el && atoi(el) == 0) && U.bkp_cap <= kAllLaneMaxCells && !wide;
                 std::vector<cell_t> cells(lanes ? (size_t)U.bkp_cap * 64 : 1);
                 for (int64_t c = 0; c < all_words(R); c++) {

@@ -5,6 +5,7 @@ the parallel search of both passes; NOTE no known input has a first valid order 
 the statistics stays 0 -- the search for a deeper one is tested with injected verdicts, engine_checks.check_injected_validity)
 and synthetic samples of every tier with imperfect fold-backs and path-editing SVs, engine against the oracle."""
 import os, sys, tempfile, time
+os.environ.setdefault("AMBI_EXPERIMENTS", "1")   # the engine honours its AMBI_* switches only with this (ambi_common.hpp: ambi_env)
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import engine_checks as ec
