@@ -1076,13 +1076,16 @@ AMBI_HD void stage_finish_lean(const G& g, const BatchArgs& A, int u, uint8_t* w
     g.sync();
     AMBI_MARK(A, g, u, 17);
     const int P = run_offsets(g, W.bkp, L, W.offs);
+    LEAN_DIAG_MARK(g, 1);
     if (P > U.path_cap) { if (g.tid() == 0) out->status = ST_ERR_PATH_CAPACITY; g.sync(); return; }
     IndelScratch S{W.sv, W.taken, W.has_ext, nullptr, W.first, W.last};
     const int nsv = pre_nsv >= 0 ? pre_nsv : indel_collect(g, n, W.ends, m, S);
+    LEAN_DIAG_MARK(g, 2);
     if (nsv > 0) {
         for (int i = g.tid(); i < 2 * n + 1; i += g.size()) { W.first[i] = 0x7fffffff; W.last[i] = -1; }
         g.sync();
     }
+    LEAN_DIAG_MARK(g, 3);
     expand_runs(g, W.bkp, np, W.offs, gpath, base, n, nsv > 0 ? W.first : nullptr, W.last, mirror);
     AMBI_MARK(A, g, u, 18);
     auto refinish = [&]() {   // chaining or editing SVs: the full stage redoes this unit
