@@ -168,7 +168,9 @@ void HostBatch::finalize() {
     for (size_t u = 0; u < units.size(); u++) {
         const UnitIn& U = units[u];
         const int64_t base = U.bkp_cap / 2 + 8;
-        run_slot[u + 1] = run_slot[u] + (((U.direct_full ? 2 * base + 32 : base + 8) + 3) & ~int64_t(3));
+        int64_t want = U.direct_full ? 2 * base + 32 : base + 8;
+        { const char* lim = ambi_env("AMBI_RUN_SLOTS"); if (lim && atoll(lim) > 0 && atoll(lim) < want) want = atoll(lim); }   // tests: small slots, so that the route for paths whose runs outgrow them is reached
+        run_slot[u + 1] = run_slot[u] + ((want + 3) & ~int64_t(3));
     }
     wide_index.assign(units.size(), -1);
     n_wide = 0;

@@ -77,6 +77,27 @@ def test_edit_stage_on_the_host_simulation(hostsim_lib, workdir):
 
 
 @pytest.mark.gpu
+def test_runs_that_outgrow_their_slots_on_the_gpu(hip_lib, workdir):
+    """run slots limited to 8 runs per unit (AMBI_RUN_SLOTS, a test hook): the finish stages flag the units whose final path has more, and
+    ambi_batch_runs_wait then serves the batch through the pack kernels -- the expanded runs still equal the final paths"""
+    os.environ["AMBI_RUN_SLOTS"] = "8"
+    try:
+        b, keep = _batch(hip_lib, workdir, "ro", 80, 9700)
+        b.upload(); b.run(0); b.wait()
+        b.runs_to_host(1, 0); v = b.runs_wait(0)
+        runs = [b.runs_unit_path(0, u).tolist() for u in range(80)]
+        b.download()
+        assert sum(len(r) > 0 for r in runs) == 80 and v["n_runs"] > 8 * 80 // 2     # really more runs than the slots held
+        for u in range(80):
+            assert runs[u] == b.unit_path(u, 1).tolist(), u
+        b.close()
+        for g in keep:
+            g.close()
+    finally:
+        os.environ.pop("AMBI_RUN_SLOTS", None)
+
+
+@pytest.mark.gpu
 def test_edit_stage_on_the_gpu(hip_lib, workdir):
     check_edit_stage(hip_lib, workdir, "eg", "AMBI_DIRECT_EDIT", n_units=200, seed0=8600)
     check_hand_over(hip_lib, workdir, "egh", "AMBI_DIRECT_EDIT")
